@@ -1,0 +1,83 @@
+"""ctypes binding of libcoma_hip.so (the C ABI declared in include/coma_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call is made with tensors
+that are not on a HIP device, this module raises.  The CPU oracle under oracle/ is test
+infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcoma_hip.so")
+
+_lib = None
+
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_fp3 = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every function declared in include/coma_hip.h
+SIGNATURES = {
+    "coma_abi_version": (_i, []),
+    "coma_last_error": (C.c_char_p, []),
+    "coma_contact_accumulate_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _fp3, _fp3, _f, _f, _f, _f,
+                                         _vp, _vp, _vp, _vp, _vp, _vp]),
+    "coma_contact_map_f32": (_i, [_vp, _vp, _fp3, _vp, _vp, _i64, _i, _f, _vp, _vp]),
+    "coma_significant_pairs_u8": (_i, [_vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    "coma_masked_max_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "coma_entropy_f32": (_i, [_vp, _i64, _i, _f, _f, _vp, _vp]),
+    "coma_occupancy_splat": (_i, [_vp, _i, _i, _i, _vp, _d, _d, _vp, _vp]),
+    "coma_occupancy_reduce": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "coma_nearest_vertex_i64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+}
+
+
+class ComaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ComaHipError(
+                f"{LIB_PATH} is missing: build it with `python -m coma_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)      # AttributeError here = header/library mismatch
+            fn.restype, fn.argtypes = res, args
+        if h.coma_abi_version() != 1:
+            raise ComaHipError(f"ABI version mismatch: library reports {h.coma_abi_version()}")
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise ComaHipError(f"{what} failed ({rc}): {lib().coma_last_error().decode()}")
+
+
+def ptr(t: torch.Tensor | None, dtype=None, name="tensor"):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ComaHipError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise ComaHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ComaHipError(f"{name} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def vec3(v):
+    return (C.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))

@@ -1,0 +1,179 @@
+"""Voxel-occupancy accumulator on MI355X: host mirror of the reference's ``utils/coma_occupancy.py``.
+
+Reference map: load_voxelgrid utils/coma_occupancy.py:160-183; ComA_Occupancy.__init__ :190-249;
+aggregate_single_sample_for_occupancy :272-295; normalize/return_aggregated_spatial_grids :297-312;
+export/load :315-343.  Same names/attributes/pickle keys; the splat and the reducer run in
+libcoma_hip.so (coma_occupancy_splat / coma_occupancy_reduce), bit-exact counts.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import pickle
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from . import _lib
+from .misc import get_3d_indexgrid_ijk, to_np_torch_recursive
+
+MAX_SAMPLES_PER_LAUNCH = 4096
+
+
+def load_voxelgrid(gridsize=3.0, resolution=24, center=[0, 0, 0]):
+    """Voxel centres [3,R,R,R] (f64), index grid and metadata.  Note: ``voxel_size * index`` is formed
+    in f32 (the index grid is cast to f32 and the Python scalar does not promote it) before the f64
+    additions -- the centres are therefore not exactly start + voxel*(i+1/2); reproduced on purpose."""
+    length_x = length_y = length_z = gridsize
+    N_x = N_y = N_z = resolution
+    voxel_size = gridsize / resolution
+    center = np.array(center)
+    start_point = center - np.array([length_x / 2, length_y / 2, length_z / 2])
+    indexgrid = get_3d_indexgrid_ijk(N_x, N_y, N_z)
+    canon_grid = start_point.reshape(3, 1, 1, 1) + voxel_size * indexgrid.astype(np.float32) + voxel_size / 2
+    grid_metadata = dict(length_x=length_x, length_y=length_y, length_z=length_z, N_x=N_x, N_y=N_y, N_z=N_z,
+                         start_point=start_point, voxel_size=voxel_size)
+    return canon_grid, indexgrid, grid_metadata
+
+
+class ComA_Occupancy:
+    selected_obj_idxs = [0]
+
+    def __init__(self, scale_tolerance: float, human_res: int, obj_res: int, normal_res: int, spatial_res: int,
+                 proximity_settings=dict(), principle_vec=[0, 0, 1], sub_principle_vec=[0, 1, 0],
+                 rel_dist_method: str = "dist", normal_gaussian_sigma: float = 0.1, selected_obj_idx: int = None,
+                 eps: float = 1e-8, device: str = "cuda"):
+        self.device = device
+        self.human_res = human_res
+        self.obj_res = obj_res
+        self.normal_res = normal_res
+        self.spatial_res = spatial_res
+        assert normal_res == 0, "In this version, normal res is 0."
+
+        self.spatial_grid, self.spatial_indexgrid, self.spatial_grid_metadata = load_voxelgrid(
+            gridsize=2.4, resolution=self.spatial_res, center=[0, 0, 0])
+        self.N_x = self.spatial_grid_metadata["N_x"]
+        self.N_y = self.spatial_grid_metadata["N_y"]
+        self.N_z = self.spatial_grid_metadata["N_z"]
+        self.spatial_grid = torch.from_numpy(self.spatial_grid).to(device)   # f64 [3,R,R,R]
+
+        self.spatial_occupancy_grids = torch.zeros([self.human_res, self.N_x, self.N_y, self.N_z], dtype=torch.float32,
+                                                   device=device)
+        self.cache_count = 0
+        self.used_count = 0
+        self.cache = dict()
+        self.used = dict()
+
+        self.principle_vec = torch.tensor(principle_vec, dtype=torch.float32).to(device)
+        self.sub_principle_vec = torch.tensor(sub_principle_vec, dtype=torch.float32).to(device)
+
+        assert rel_dist_method in ["dist", "sdf"], f"rel_dist_method: '{rel_dist_method}' not allowed"
+        self.rel_dist_method = rel_dist_method
+        self.rel_dist_thres = self.spatial_grid_metadata["voxel_size"] * scale_tolerance
+        self.normal_gaussian_sigma = normal_gaussian_sigma
+        self.eps = eps
+        self.debug_obj_vert = None
+        self.debug_obj_normal = None
+
+    def register_sample_to_cache(self, **kwargs):
+        self.cache[f"{self.cache_count:05}"] = kwargs
+        self.cache_count = len(self.cache.keys())
+
+    def aggregate_all_samples(self):
+        keys = list(self.cache.keys())
+        for i0 in range(0, len(keys), MAX_SAMPLES_PER_LAUNCH):
+            self._accumulate([self.cache[k] for k in keys[i0:i0 + MAX_SAMPLES_PER_LAUNCH]])
+        for k in keys:
+            self.used[f"{self.used_count:05}"] = self.cache[k]
+            self.used_count = len(self.used.keys())
+        self.cache = {}
+        self.cache_count = 0
+
+    def aggregate_single_sample(self, **kwargs):
+        self.aggregate_single_sample_for_occupancy(**kwargs)
+
+    def aggregate_single_sample_for_occupancy(self, human_verts, human_normals, obj_verts, obj_normals, **kwargs):
+        self._accumulate([dict(human_verts=human_verts, human_normals=human_normals, obj_verts=obj_verts,
+                               obj_normals=obj_normals)])
+
+    def _accumulate(self, samples):
+        if not samples:
+            return
+        assert list(self.selected_obj_idxs) == [0], "only object point 0 is supported (as shipped in the reference)"
+        qs = []
+        for s in samples:
+            obj_vert = np.asarray(s["obj_verts"])[0]
+            obj_normal = np.asarray(s["obj_normals"])[0]
+            # the reference asserts that the object point and its normal never change across samples
+            if self.debug_obj_vert is None:
+                self.debug_obj_vert = obj_vert
+            else:
+                assert np.allclose(self.debug_obj_vert, obj_vert)
+            if self.debug_obj_normal is None:
+                self.debug_obj_normal = obj_normal
+            else:
+                assert np.allclose(self.debug_obj_normal, obj_normal)
+            hv = np.asarray(s["human_verts"])
+            assert hv.shape[0] == self.human_res
+            qs.append((hv - obj_vert[None]).astype(np.float32))      # subtract in the input dtype, then f32
+        q = torch.from_numpy(np.ascontiguousarray(np.stack(qs))).to(self.device)
+        self.accumulate_device(q)
+
+    def _axis_centers(self):
+        g = self.spatial_grid.to(torch.float64)
+        return torch.stack([g[0, :, 0, 0], g[1, 0, :, 0], g[2, 0, 0, :]]).contiguous()
+
+    def accumulate_device(self, q):
+        """q: f32 [S,H,3] on the HIP device, already relative to object point 0."""
+        L = _lib.lib()
+        S, H, R = q.shape[0], self.human_res, self.spatial_res
+        assert tuple(q.shape) == (S, H, 3) and self.N_x == self.N_y == self.N_z == R
+        centers = self._axis_centers()
+        rc = L.coma_occupancy_splat(_lib.ptr(q, torch.float32, "q"), S, H, R, _lib.ptr(centers, torch.float64),
+                                    float(self.spatial_grid_metadata["voxel_size"]), float(self.rel_dist_thres),
+                                    _lib.ptr(self.spatial_occupancy_grids, torch.float32, "spatial_occupancy_grids"),
+                                    _lib.stream_ptr(q.device))
+        _lib.check(rc, "coma_occupancy_splat")
+
+    def _reduce(self, human_indices):
+        L = _lib.lib()
+        H = self.human_res
+        R3 = self.N_x * self.N_y * self.N_z
+        g = self.spatial_occupancy_grids
+        dev = g.device
+        sel = None
+        if human_indices is not None:
+            sel = torch.zeros([H], dtype=torch.uint8, device=dev)
+            sel[torch.as_tensor(list(human_indices), dtype=torch.long, device=dev)] = 1
+        rowsum = torch.empty([H], dtype=torch.float32, device=dev)
+        out = torch.empty([self.N_x, self.N_y, self.N_z], dtype=torch.float32, device=dev)
+        rc = L.coma_occupancy_reduce(_lib.ptr(g, torch.float32), _lib.ptr(sel), H, R3, _lib.ptr(rowsum), _lib.ptr(out),
+                                     _lib.stream_ptr(dev))
+        _lib.check(rc, "coma_occupancy_reduce")
+        return out
+
+    def normalize_prob_grid_for_spatials(self):
+        self._reduce(None)
+
+    def normalize_prob_grid_for_spatials_v2(self):
+        self.spatial_occupancy_grids = self.spatial_occupancy_grids / self.used_count
+
+    def return_aggregated_spatial_grids(self, human_indices=None):
+        """Normalise every row in place (0/0 -> NaN for a vertex never inside the grid, as in the
+        reference) and return max over the selected human vertices, [R,R,R] f32 on the device."""
+        return self._reduce(human_indices)
+
+    def export(self, save_pth=None):
+        to_export = {k: v for k, v in vars(self).items() if k not in ("cache", "used") and not k.startswith("_")}
+        to_export = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else deepcopy(v)) for k, v in to_export.items()}
+        to_export = to_np_torch_recursive(to_export, use_torch=False, device="cpu")
+        if save_pth is None:
+            return to_export
+        with open(save_pth, "wb") as handle:
+            pickle.dump(to_export, handle, protocol=pickle.HIGHEST_PROTOCOL)
+
+    def load(self, load_pth):
+        with open(load_pth, "rb") as handle:
+            loadables = pickle.load(handle)
+        loadables = to_np_torch_recursive(loadables, use_torch=True, device=self.device)
+        for k, v in loadables.items():
+            setattr(self, k, v)

@@ -1,0 +1,62 @@
+"""Multi-GPU layer of the ComA path: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in CPU tests).  SURVEY.md 8e:
+
+  * contact/orientation: samples are sharded across ranks, every state tensor is a plain sum over
+    samples, so ONE all-reduce(SUM) of the five tensors (2*H*O*N + 3*H*O floats) at the end rebuilds the
+    single-process ComA.  The two [H,O,N] histograms are reduced in place (no 3.8 GB staging copy);
+    the three [H,O] maps travel as one flat bucket.  used_count is summed as an int.
+  * occupancy: human vertices (rows) are sharded, each rank reduces its rows locally and the [R,R,R]
+    result is combined with all-reduce(MAX) (NaN-propagating like the single-process reducer).
+
+The reference has no collective at all (its workers only share files); this step is new by design.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_slice(n_items: int, rank: int, world: int):
+    """Balanced contiguous slice of ``n_items`` work items for ``rank`` (sizes differ by at most 1)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def reference_slice(n_items: int, rank: int, world: int):
+    """The reference's per-GPU slice arithmetic (src/generation/inpaint.py:271-274): sub_length =
+    len // n + 1, so 512 items over 8 ranks give 65,65,...,57.  Kept for the inpainting work list."""
+    sub = n_items // world + 1
+    return min(rank * sub, n_items), min((rank + 1) * sub, n_items)
+
+
+def all_reduce_coma(coma, group=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    big = [coma.prob_grid_canon_human_wrt_obj, coma.prob_grid_canon_obj_wrt_human]
+    small = [coma.contact_dist_expectation_grid_nom, coma.contact_dist_expectation_grid_denom,
+             coma.significant_contact_count]
+    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in big]
+    flat = torch.cat([t.reshape(-1) for t in small])
+    works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    cnt = torch.tensor([coma.used_count], dtype=torch.int64, device=flat.device)
+    works.append(dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    off = 0
+    for t in small:
+        t.copy_(flat[off:off + t.numel()].view_as(t))
+        off += t.numel()
+    coma.used_count = int(cnt.item())
+
+
+def all_reduce_max_nan(t: torch.Tensor, group=None):
+    """all-reduce(MAX) that propagates NaN the way torch.max does on one device."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    nan = torch.isnan(t).to(torch.float32)
+    clean = torch.nan_to_num(t, nan=float("-inf"))
+    dist.all_reduce(clean, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(nan, op=dist.ReduceOp.MAX, group=group)
+    t.copy_(torch.where(nan > 0, torch.full_like(clean, float("nan")), clean))
+    return t

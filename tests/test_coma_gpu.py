@@ -1,0 +1,365 @@
+"""GPU parity: the HIP path (through the C ABI, via the host mirror) against the golden vectors captured from
+the reference and against the CPU oracle on seeded inputs.
+
+Bars (BASELINE.json north_star): float histograms <= 1e-3 relative (denominator max(|ref|, 1e-6*max|ref|),
+SURVEY.md 8d); counts, significant pairs, index vectors, occupancy counts and nearest-vertex maps bit-exact.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coma_oracle as orc
+from tests.synth import cfg1_samples, make_samples
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return "cuda:0"
+
+
+def _coma(H, O, N, size, thres, sigma, dev, eps=1e-10):
+    from utils.coma import ComA
+    return ComA(H, O, N, 0, proximity_settings=dict(spatial_grid_size=size, spatial_grid_thres=thres),
+                principle_vec=[0, 0, 1], sub_principle_vec=[0, 1, 0], rel_dist_method="dist",
+                normal_gaussian_sigma=sigma, eps=eps, device=dev)
+
+
+def _gsamples(g, prefix, S):
+    return [dict(human_verts=g[f"{prefix}_in{i}_human_verts"], human_normals=g[f"{prefix}_in{i}_human_normals"],
+                 obj_verts=g[f"{prefix}_in{i}_obj_verts"], obj_normals=g[f"{prefix}_in{i}_obj_normals"]) for i in range(S)]
+
+
+def _fill(coma, samples):
+    for s in samples:
+        coma.register_sample_to_cache(**copy.deepcopy(s))
+    coma.aggregate_all_samples()
+    return coma
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------- K1-K3
+def test_golden_state_h32_o8_n250(golden, dev, hip_lib):
+    coma = _fill(_coma(32, 8, 250, 0.07, 0.03, 0.25, dev), _gsamples(golden, "g4", 4))
+    assert coma.used_count == 4 and coma.cache_count == 0
+    assert np.array_equal(_np(coma.significant_contact_count), golden["g4_significant_contact_count"])
+    assert np.array_equal(_np(coma.contact_dist_expectation_grid_denom), golden["g4_contact_dist_expectation_grid_denom"])
+    assert orc.max_rel_err(_np(coma.contact_dist_expectation_grid_nom), golden["g4_contact_dist_expectation_grid_nom"]) <= 1e-5
+    for k in ("prob_grid_canon_human_wrt_obj", "prob_grid_canon_obj_wrt_human"):
+        err = orc.max_rel_err(_np(getattr(coma, k)), golden[f"g4_{k}"])
+        assert err <= RTOL, (k, err)
+        assert orc.mae_normalised(_np(getattr(coma, k)), golden[f"g4_{k}"]) <= 1e-7
+
+
+def test_golden_varying_objects_n70(golden, dev, hip_lib):
+    coma = _fill(_coma(12, 5, 70, 0.15, 0.05, 0.2, dev), _gsamples(golden, "g4v", 3))
+    assert np.array_equal(_np(coma.significant_contact_count), golden["g4v_significant_contact_count"])
+    assert orc.max_rel_err(_np(coma.contact_dist_expectation_grid_nom), golden["g4v_contact_dist_expectation_grid_nom"]) <= 1e-5
+    for k in ("prob_grid_canon_human_wrt_obj", "prob_grid_canon_obj_wrt_human"):
+        assert orc.max_rel_err(_np(getattr(coma, k)), golden[f"g4v_{k}"]) <= RTOL
+
+
+def test_golden_midsize_h256_o180(golden, dev, hip_lib):
+    samples = make_samples(256, 180, 3, int(golden["g4m_seed"]), 0.03)
+    coma = _fill(_coma(256, 180, 250, 0.07, 0.03, 0.25, dev), samples)
+    assert np.array_equal(_np(coma.significant_contact_count).astype(np.uint8), golden["g4m_count_u8"])
+    assert golden["g4m_count_u8"].sum() > 100
+    assert orc.max_rel_err(_np(coma.contact_dist_expectation_grid_nom), golden["g4m_nom"]) <= 1e-5
+    rows = golden["g4m_rows"]
+    for tag, k in (("h", "prob_grid_canon_human_wrt_obj"), ("o", "prob_grid_canon_obj_wrt_human")):
+        P = _np(getattr(coma, k))
+        assert orc.max_rel_err(P.reshape(-1, 250)[rows], golden[f"g4m_rows_{tag}"]) <= RTOL
+        assert orc.max_rel_err(P.astype(np.float64).sum(-1), golden[f"g4m_rowsum_{tag}"]) <= 1e-5
+
+
+def test_accumulation_composes_over_batches_and_single_samples(golden, dev, hip_lib):
+    samples = _gsamples(golden, "g4", 4)
+    a = _fill(_coma(32, 8, 250, 0.07, 0.03, 0.25, dev), samples)
+    b = _coma(32, 8, 250, 0.07, 0.03, 0.25, dev)
+    _fill(b, samples[:1])
+    for s in samples[1:3]:
+        b.aggregate_single_sample(**s)
+    _fill(b, samples[3:])
+    assert np.array_equal(_np(a.significant_contact_count), _np(b.significant_contact_count))
+    assert orc.max_rel_err(_np(b.prob_grid_canon_human_wrt_obj), _np(a.prob_grid_canon_human_wrt_obj)) <= 1e-5
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 250, 256, 257, 600])
+def test_bin_counts_ragged_and_multi_chunk(N, dev, hip_lib):
+    H, O, S = 9, 7, 3     # H*O = 63: not a multiple of the 8-pair wave tile
+    samples = make_samples(H, O, S, seed=100 + N, thres=0.05, const_obj=False)
+    coma = _fill(_coma(H, O, N, 0.1, 0.05, 0.3, dev), samples)
+    m = orc.ComAOracle(H, O, N, 0.1, 0.05, sigma=0.3, eps=1e-10)
+    for s in samples:
+        m.aggregate_sample(**s)
+    assert np.array_equal(_np(coma.significant_contact_count), m.cnt)
+    assert orc.max_rel_err(_np(coma.prob_grid_canon_human_wrt_obj), m.P_h_wrt_o) <= RTOL
+    assert orc.max_rel_err(_np(coma.prob_grid_canon_obj_wrt_human), m.P_o_wrt_h) <= RTOL
+
+
+@pytest.mark.parametrize("S", [1, 7, 8, 9, 17])
+def test_sample_counts_around_the_chunk_size(S, dev, hip_lib):
+    H, O, N = 16, 4, 250
+    samples = make_samples(H, O, S, seed=S, thres=0.03)
+    coma = _fill(_coma(H, O, N, 0.07, 0.03, 0.25, dev), samples)
+    m = orc.ComAOracle(H, O, N, 0.07, 0.03, sigma=0.25, eps=1e-10)
+    for s in samples:
+        m.aggregate_sample(**s)
+    assert np.array_equal(_np(coma.significant_contact_count), m.cnt)
+    assert np.array_equal(_np(coma.contact_dist_expectation_grid_denom), m.den)
+    assert orc.max_rel_err(_np(coma.prob_grid_canon_human_wrt_obj), m.P_h_wrt_o) <= RTOL
+
+
+def test_antiparallel_normals_and_sigma_02(dev, hip_lib):
+    H, O, N = 8, 6, 250
+    samples = make_samples(H, O, 2, seed=5, thres=0.1)
+    for s in samples:
+        s["obj_normals"] = s["obj_normals"].copy()
+        s["obj_normals"][0] = [0, 0, -1]      # exactly opposite of p -> mirrored branch of K2
+        s["obj_normals"][1] = [0, 0, 1]
+        s["human_normals"][0] = [0, 0, -1]
+        s["human_normals"][1] = [0, 0, 2.5]   # un-normalised input
+    coma = _fill(_coma(H, O, N, 0.03, 0.1, 0.2, dev), samples)
+    m = orc.ComAOracle(H, O, N, 0.03, 0.1, sigma=0.2, eps=1e-10)
+    for s in samples:
+        m.aggregate_sample(**s)
+    assert orc.max_rel_err(_np(coma.prob_grid_canon_human_wrt_obj), m.P_h_wrt_o) <= RTOL
+    assert orc.max_rel_err(_np(coma.prob_grid_canon_obj_wrt_human), m.P_o_wrt_h) <= RTOL
+
+
+def test_contact_count_bit_exact_dense_near_threshold(dev, hip_lib):
+    """65k pairs whose distances straddle the f32 threshold within a few ulps: the count must be bit-exact."""
+    H, O, thres = 512, 128, 0.03
+    rng = np.random.default_rng(7)
+    ov = rng.normal(size=(O, 3)) * 0.2
+    on = rng.normal(size=(O, 3))
+    hv = np.empty((H, 3))
+    for h in range(H):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        hv[h] = ov[h % O] + d * np.float64(np.float32(thres)) * (1 + rng.integers(-6, 7) * 3e-8)
+    smp = dict(human_verts=hv, human_normals=rng.normal(size=(H, 3)), obj_verts=ov, obj_normals=on)
+    coma = _fill(_coma(H, O, 16, 0.07, thres, 0.25, dev), [smp])
+    m = orc.ComAOracle(H, O, 16, 0.07, thres, sigma=0.25, eps=1e-10)
+    m.aggregate_sample(**smp)
+    assert 100 < m.cnt.sum() < H * O
+    assert np.array_equal(_np(coma.significant_contact_count), m.cnt)
+
+
+def test_cfg1_full_size_vs_oracle(dev, hip_lib):
+    """BASELINE.json config 1 (H=1000, O=180, N=250), 2 samples: full-state parity with the oracle."""
+    samples = cfg1_samples(2, seed=0)
+    coma = _fill(_coma(1000, 180, 250, 0.07, 0.03, 0.25, dev), samples)
+    m = orc.ComAOracle(1000, 180, 250, 0.07, 0.03, sigma=0.25, eps=1e-10)
+    for s in samples:
+        m.aggregate_sample(**s)
+    assert np.array_equal(_np(coma.significant_contact_count), m.cnt)
+    assert orc.max_rel_err(_np(coma.contact_dist_expectation_grid_nom), m.nom) <= 1e-5
+    for a, b in ((coma.prob_grid_canon_human_wrt_obj, m.P_h_wrt_o), (coma.prob_grid_canon_obj_wrt_human, m.P_o_wrt_h)):
+        assert orc.max_rel_err(_np(a), b) <= RTOL
+        assert orc.mae_normalised(_np(a), b) <= 1e-8
+
+
+def test_full_smplx_size_properties(dev, hip_lib):
+    """BASELINE config 4 per-GPU slice shape (H=10475, O=180, N=250): size-independent properties.
+    (i) linearity: state(A+B) == state(A) + state(B);  (ii) den == S everywhere;  (iii) every histogram row of a
+    unit-normal pair integrates to the same constant for both grids (the kernel only rotates the normals)."""
+    H, O, N, S = 10475, 180, 250, 4
+    samples = cfg1_samples(S, seed=3, H=H, O=O)
+    a = _fill(_coma(H, O, N, 0.07, 0.03, 0.25, dev), samples)
+    b = _fill(_coma(H, O, N, 0.07, 0.03, 0.25, dev), samples[:2])
+    c = _fill(_coma(H, O, N, 0.07, 0.03, 0.25, dev), samples[2:])
+    assert torch.equal(a.significant_contact_count, b.significant_contact_count + c.significant_contact_count)
+    assert bool((a.contact_dist_expectation_grid_denom == S).all())
+    s_ab = b.prob_grid_canon_human_wrt_obj + c.prob_grid_canon_human_wrt_obj
+    assert float(((a.prob_grid_canon_human_wrt_obj - s_ab).abs() / (s_ab.abs() + 1e-30)).max()) <= 1e-5
+    # spot-check 64 random rows against the oracle's row formula
+    rng = np.random.default_rng(0)
+    rows = rng.integers(0, H * O, size=64)
+    grid = orc.fibonacci_sphere(N)
+    for r in rows:
+        h, o = divmod(int(r), O)
+        acc1 = np.zeros(N, np.float32)
+        for s in samples:
+            c1 = orc.canonicalize(s["human_normals"][h:h + 1].astype(np.float32), s["obj_normals"][o:o + 1].astype(np.float32),
+                                  np.array([0, 0, 1], np.float32), np.array([0, 1, 0], np.float32), 1e-10)
+            acc1 += orc.geodesic_gaussian(grid, c1, 0.25, 1e-10)[0, 0]
+        got = a.prob_grid_canon_human_wrt_obj[h, o].cpu().numpy()
+        assert orc.max_rel_err(got, acc1) <= RTOL
+
+
+# ------------------------------------------------------------------------------------------- K4
+def test_reducers_golden(golden, dev, hip_lib):
+    from utils.coma import get_aggregated_contact, get_nonphysical_score
+    base = _fill(_coma(32, 8, 250, 0.07, 0.03, 0.25, dev), _gsamples(golden, "g4", 4))
+
+    def fresh():
+        c = _coma(32, 8, 250, 0.07, 0.03, 0.25, dev)
+        for k in c._STATE_KEYS:
+            getattr(c, k).copy_(getattr(base, k))
+        c.used_count = base.used_count
+        return c
+
+    cm = fresh().compute_contact_map("both", as_numpy=True)
+    assert cm["human"].dtype == np.float32
+    assert orc.max_rel_err(cm["human"], golden["g5_contact_map_human"]) <= RTOL
+    assert orc.max_rel_err(cm["obj"], golden["g5_contact_map_obj"]) <= RTOL
+    for ratio in (0.1, 0.3, 0.75):
+        pairs = fresh().significant_contact_pairs(ratio, as_numpy=True)
+        assert pairs.dtype == np.bool_ and np.array_equal(pairs, golden[f"g5_pairs_{ratio:g}"])
+        for which in ("human", "obj"):
+            agg, idx = get_aggregated_contact(fresh(), which, ratio)
+            assert orc.max_rel_err(agg, golden[f"g5_agg_{which}_{ratio:g}"]) <= RTOL
+            assert idx.dtype == np.int64 and np.array_equal(idx, golden[f"g5_idx_{which}_{ratio:g}"])
+    assert orc.max_rel_err(get_nonphysical_score(fresh(), "human"), golden["g6_nonphys_human"]) <= RTOL
+    assert orc.max_rel_err(get_nonphysical_score(fresh(), "obj"), golden["g6_nonphys_obj"]) <= RTOL
+    # reducers normalise the state in place, like the reference
+    c = fresh()
+    c.normalize_prob_grid_for_normals()
+    sums = c.prob_grid_canon_human_wrt_obj.sum(-1)
+    assert float((sums - 1).abs().max()) < 1e-5
+
+
+def test_reference_pickle_loads_and_reduces(golden, dev, hip_lib, tmp_path):
+    """A ComA pickle WRITTEN BY THE REFERENCE loads here, reduces to the reference's outputs, and re-exports
+    with the same keys/dtypes (file-format drop-in)."""
+    import pickle
+    from utils.coma import get_aggregated_contact
+    c = _coma(6, 4, 16, 0.07, 0.03, 0.25, dev)
+    c.load(os.path.join(ROOT, "tests", "golden", "ref_coma_small.pickle"))
+    assert c.canon_normal_grid.dtype == torch.float32 and c.used_count == 2
+    agg, idx = get_aggregated_contact(c, "human", 0.1)
+    assert orc.max_rel_err(agg, golden["g7b_agg_human"]) <= RTOL
+    assert np.array_equal(idx, golden["g7b_idx_human"])
+    c.export(str(tmp_path / "out.pickle"))
+    mine = pickle.load(open(tmp_path / "out.pickle", "rb"))
+    theirs = pickle.load(open(os.path.join(ROOT, "tests", "golden", "ref_coma_small.pickle"), "rb"))
+    assert sorted(mine) == sorted(theirs)
+    for k in theirs:
+        assert type(mine[k]) is type(theirs[k]), k
+        if isinstance(theirs[k], np.ndarray):
+            assert mine[k].dtype == theirs[k].dtype and mine[k].shape == theirs[k].shape, k
+
+
+# ------------------------------------------------------------------------------------------- K5/K6
+def _occ(H, R, dev):
+    from utils.coma_occupancy import ComA_Occupancy
+    return ComA_Occupancy(scale_tolerance=3.0, human_res=H, obj_res=3, normal_res=0, spatial_res=R, device=dev)
+
+
+def test_occupancy_golden_counts_bit_exact(golden, dev, hip_lib):
+    occ = _occ(16, 8, dev)
+    for s in range(4):
+        hv = golden[f"g9_in{s}_human_verts"]
+        occ.register_sample_to_cache(human_verts=hv, human_normals=np.zeros_like(hv), obj_verts=golden["g9_obj_verts"],
+                                     obj_normals=golden["g9_obj_normals"])
+    occ.aggregate_all_samples()
+    assert np.array_equal(_np(occ.spatial_occupancy_grids), golden["g9_counts"])
+    out = _np(occ.return_aggregated_spatial_grids())
+    assert np.array_equal(out, golden["g10_grid_with_nan"], equal_nan=True)
+    occ2 = _occ(16, 8, dev)
+    occ2.spatial_occupancy_grids.copy_(torch.from_numpy(golden["g9_counts"]))
+    out = _np(occ2.return_aggregated_spatial_grids(human_indices=[int(i) for i in golden["g10_sel"]]))
+    assert np.array_equal(out, golden["g10_grid_sel"], equal_nan=True)
+
+
+def test_occupancy_empty_row_poisons_grid_like_reference(golden, dev, hip_lib):
+    from utils.coma_occupancy import ComA_Occupancy
+    occ = ComA_Occupancy(scale_tolerance=3.0, human_res=4, obj_res=1, normal_res=0, spatial_res=8, device=dev)
+    for s in range(2):
+        hv = golden[f"g10b_in{s}_human_verts"]
+        occ.register_sample_to_cache(human_verts=hv, human_normals=np.zeros_like(hv), obj_verts=np.zeros((1, 3)),
+                                     obj_normals=np.ones((1, 3)))
+    occ.aggregate_all_samples()
+    assert np.array_equal(_np(occ.spatial_occupancy_grids), golden["g10b_counts"])
+    counts = occ.spatial_occupancy_grids.clone()
+    assert np.isnan(_np(occ.return_aggregated_spatial_grids())).all()
+    occ.spatial_occupancy_grids.copy_(counts)
+    assert np.array_equal(_np(occ.return_aggregated_spatial_grids(human_indices=[0, 1, 2])), golden["g10b_grid_sel012"])
+
+
+@pytest.mark.parametrize("R", [30, 37])
+def test_occupancy_vs_oracle_shipped_preset_size(R, dev, hip_lib):
+    """R=30 is the shipped preset (constants/coma/qual.py); ~21 % of the points fall outside the grid."""
+    H, S = 96, 5
+    rng = np.random.default_rng(R)
+    ov = rng.normal(scale=0.05, size=(3, 3))
+    occ = _occ(H, R, dev)
+    m = orc.OccupancyOracle(H, R, 3.0)
+    for s in range(S):
+        hv = rng.uniform(-1.3, 1.3, size=(H, 3))
+        occ.register_sample_to_cache(human_verts=hv, human_normals=np.zeros_like(hv), obj_verts=ov, obj_normals=np.ones_like(ov))
+        m.aggregate_sample(hv, ov)
+    occ.aggregate_all_samples()
+    assert m.occ.sum() > 0
+    assert np.array_equal(_np(occ.spatial_occupancy_grids), m.occ)
+    assert np.array_equal(_np(occ.return_aggregated_spatial_grids()), m.aggregated_grid(), equal_nan=True)
+
+
+def test_occupancy_r128_properties(dev, hip_lib):
+    """BASELINE config 5 resolution (R=128) on a slice of vertices: every in-grid interior vertex lights the
+    same number of voxels per sample, and splatting the same samples twice doubles every count."""
+    H, S, R = 64, 3, 128
+    rng = np.random.default_rng(5)
+    occ = _occ(H, R, dev)
+    qs = []
+    for s in range(S):
+        hv = rng.uniform(-1.0, 1.0, size=(H, 3))
+        qs.append(hv)
+        occ.register_sample_to_cache(human_verts=hv, human_normals=np.zeros_like(hv), obj_verts=np.zeros((3, 3)),
+                                     obj_normals=np.ones((3, 3)))
+    occ.aggregate_all_samples()
+    once = occ.spatial_occupancy_grids.clone()
+    per_vertex = once.reshape(H, -1).sum(-1).cpu().numpy()
+    assert (np.abs(per_vertex / S - 113.1) < 6).all()        # 4/3*pi*3^3 voxels inside the threshold sphere
+    m = orc.OccupancyOracle(2, R, 3.0)
+    for hv in qs:
+        m.aggregate_sample(hv[:2], np.zeros((3, 3)))
+    assert np.array_equal(once[:2].cpu().numpy(), m.occ)
+    for hv in qs:
+        occ.register_sample_to_cache(human_verts=hv, human_normals=np.zeros_like(hv), obj_verts=np.zeros((3, 3)),
+                                     obj_normals=np.ones((3, 3)))
+    occ.aggregate_all_samples()
+    assert torch.equal(occ.spatial_occupancy_grids, 2 * once)
+
+
+def test_reference_occupancy_pickle_loads(golden, dev, hip_lib):
+    from utils.coma_occupancy import ComA_Occupancy
+    occ = ComA_Occupancy(scale_tolerance=3.0, human_res=5, obj_res=2, normal_res=0, spatial_res=6, device=dev)
+    occ.load(os.path.join(ROOT, "tests", "golden", "ref_occupancy_small.pickle"))
+    assert np.array_equal(_np(occ.return_aggregated_spatial_grids()), golden["g7b_occ_grid"], equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------- K7
+def test_nearest_vertex_golden_and_ties(golden, dev, hip_lib):
+    from utils.coma import nearest_vertex_indices
+    idx = nearest_vertex_indices(golden["g11_points"], golden["g11_verts"], device=dev)
+    assert idx.dtype == np.int64 and np.array_equal(idx, golden["g11_idx"])
+
+
+def test_nearest_vertex_smplx_size(dev, hip_lib):
+    from utils.coma import nearest_vertex_indices
+    rng = np.random.default_rng(1)
+    verts = rng.normal(size=(10475, 3))
+    verts[5000:5010] = verts[10:20]                          # duplicated vertices -> ties
+    pts = np.concatenate([verts[rng.integers(0, 10475, 990)] + rng.normal(scale=1e-3, size=(990, 3)), verts[5000:5010]])
+    assert np.array_equal(nearest_vertex_indices(pts, verts, device=dev), orc.nearest_vertex(pts, verts))
+
+
+def test_product_path_refuses_cpu_tensors(hip_lib):
+    from coma_amd._lib import ComaHipError
+    c = _coma(4, 2, 8, 0.07, 0.03, 0.25, "cpu")
+    smp = make_samples(4, 2, 1, 0, 0.03)[0]
+    with pytest.raises(ComaHipError):
+        c.aggregate_single_sample(**smp)

@@ -1,0 +1,164 @@
+"""CPU: host-side logic of the ComA path (no kernels): dtype rules, state schema, cache bookkeeping,
+sharding arithmetic, the 2-rank all-reduce over gloo, and the 'no CPU fallback' guarantee."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from coma_amd import dist as cdist
+from coma_amd._lib import ComaHipError
+from coma_amd.misc import to_np_torch_recursive
+from tests.synth import make_samples
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _coma(H=6, O=4, N=16):
+    from utils.coma import ComA
+    return ComA(H, O, N, 0, proximity_settings=dict(spatial_grid_size=0.07, spatial_grid_thres=0.03),
+                normal_gaussian_sigma=0.25, eps=1e-10, device="cpu")
+
+
+def test_dtype_table_matches_reference(golden):
+    table = []
+    for dt in [np.float64, np.float32, np.float16, np.int64, np.int32, np.int16, np.uint8, np.bool_]:
+        t = to_np_torch_recursive(np.zeros(2, dt), use_torch=True, device="cpu")
+        n = to_np_torch_recursive(torch.zeros(2, dtype=t.dtype), use_torch=False, device="cpu")
+        table.append(f"{np.dtype(dt).name}->{t.dtype}->{n.dtype}")
+    assert table == list(golden["g12_dtype_table"])
+
+
+def test_recursive_walk_on_nested_containers():
+    x = dict(a=np.zeros(2, np.float64), b=[np.zeros(1, np.int32), dict(c=torch.zeros(1, dtype=torch.float64))], d="s", e=3)
+    y = to_np_torch_recursive(x, use_torch=True, device="cpu")
+    assert y["a"].dtype == torch.float32 and y["b"][0].dtype == torch.int64 and y["b"][1]["c"].dtype == torch.float32
+    assert y["d"] == "s" and y["e"] == 3
+
+
+def test_state_schema_matches_reference_export(golden):
+    c = _coma(32, 8, 250)
+    exp = c.export()
+    assert sorted(exp.keys()) == list(golden["g4_export_keys"])
+    got = [f"{k}:{getattr(exp[k], 'dtype', type(exp[k]).__name__)}" for k in sorted(exp.keys())]
+    assert got == list(golden["g4_export_dtypes"])
+    assert c.canon_normal_grid.dtype == torch.float64          # f64 while learning
+    assert np.array_equal(c.canon_normal_grid.numpy(), golden["g1_sphere250"])
+
+
+def test_export_pickle_is_loadable_and_names_utils_coma(tmp_path):
+    c = _coma()
+    p = tmp_path / "c.pickle"
+    c.export(str(p))
+    raw = open(p, "rb").read()
+    assert b"utils.coma" in raw and b"negative_exp" in raw     # the reference un-pickles this symbol path
+    d = pickle.load(open(p, "rb"))
+    assert d["contact_dist_func"].func.__name__ == "negative_exp"
+    c2 = _coma()
+    c2.load(str(p))
+    assert c2.canon_normal_grid.dtype == torch.float32          # f32 after load, as in the reference
+
+
+def test_reference_written_pickle_loads_on_host():
+    c = _coma(6, 4, 16)
+    c.load(os.path.join(ROOT, "tests", "golden", "ref_coma_small.pickle"))
+    assert c.used_count == 2 and tuple(c.prob_grid_canon_human_wrt_obj.shape) == (6, 4, 16)
+    assert float(c.contact_dist_expectation_grid_denom.min()) == 2.0
+
+
+def test_cache_bookkeeping_and_shape_asserts():
+    c = _coma()
+    smp = make_samples(6, 4, 2, 0, 0.03)
+    for s in smp:
+        c.register_sample_to_cache(**s)
+    assert c.cache_count == 2 and list(c.cache) == ["00000", "00001"]
+    bad = dict(smp[0], human_verts=smp[0]["human_verts"][:5])
+    with pytest.raises(AssertionError):
+        c.aggregate_single_sample(**bad)
+    with pytest.raises(AssertionError):
+        c.compute_contact_map("nope")
+
+
+def test_no_cpu_fallback():
+    c = _coma()
+    with pytest.raises(ComaHipError):
+        c.aggregate_single_sample(**make_samples(6, 4, 1, 0, 0.03)[0])
+    with pytest.raises(ComaHipError):
+        c.compute_contact_map("human")
+    from utils.coma_occupancy import ComA_Occupancy
+    o = ComA_Occupancy(scale_tolerance=3.0, human_res=4, obj_res=1, normal_res=0, spatial_res=4, device="cpu")
+    with pytest.raises(ComaHipError):
+        o.return_aggregated_spatial_grids()
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "coma_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_voxelgrid_host_matches_golden(golden):
+    from utils.coma_occupancy import load_voxelgrid
+    for R in (4, 30):
+        g, ig, md = load_voxelgrid(2.4, R, [0, 0, 0])
+        assert g.dtype == np.float64 and md["voxel_size"] == float(golden[f"g8_voxel_{R}"])
+        assert np.array_equal(np.stack([g[0, :, 0, 0], g[1, 0, :, 0], g[2, 0, 0, :]]), golden[f"g8_axis_{R}"])
+
+
+def test_shard_arithmetic():
+    assert [cdist.shard_slice(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert sum(b - a for a, b in (cdist.shard_slice(512, r, 8) for r in range(8))) == 512
+    # the reference's slice rule: 512 items on 8 ranks -> 65 x 7 + 57 (src/generation/inpaint.py:271-274)
+    sizes = [b - a for a, b in (cdist.reference_slice(512, r, 8) for r in range(8))]
+    assert sizes == [65] * 7 + [57]
+
+
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from coma_amd import dist as cdist
+from utils.coma import ComA
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+c = ComA(5, 3, 8, 0, proximity_settings=dict(spatial_grid_size=0.07, spatial_grid_thres=0.03), device="cpu")
+g = torch.Generator().manual_seed(rank)
+for k in c._STATE_KEYS:
+    getattr(c, k).copy_(torch.rand(getattr(c, k).shape, generator=g))
+c.used_count = 3 + rank
+c.all_reduce()
+exp = {}
+for k in c._STATE_KEYS:
+    tot = 0
+    for r in range(world):
+        gg = torch.Generator().manual_seed(r)
+        for kk in c._STATE_KEYS:
+            t = torch.rand(getattr(c, kk).shape, generator=gg)
+            if kk == k:
+                tot = tot + t
+    assert torch.allclose(getattr(c, k), tot), k
+assert c.used_count == sum(3 + r for r in range(world))
+t = torch.tensor([1.0, float("nan") if rank == 1 else 0.5, -2.0 + rank])
+cdist.all_reduce_max_nan(t)
+assert t[0] == 1.0 and torch.isnan(t[1]) and t[2] == -2.0 + (world - 1)
+dist.destroy_process_group()
+print("RANK_OK", rank)
+'''
+
+
+def test_two_rank_all_reduce_over_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, out
