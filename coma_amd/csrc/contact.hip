@@ -48,29 +48,39 @@ struct ContactArgs {
   float* cnt;
 };
 
-// acos(|x|) = sqrt(1-|x|) * poly(|x|): degree-7 interpolant at Chebyshev nodes of acos(x)/sqrt(1-x) on
-// [0,1]; |error| <= 2.9e-8 in exact arithmetic, 2.5e-7 evaluated in f32 (fit: DESIGN.md "acos").
-__device__ __forceinline__ float acos_poly(float ax) {
-  float r = -0.001211737748235464f;
-  r = fmaf(r, ax, 0.006491521373391151f);
-  r = fmaf(r, ax, -0.01684105210006237f);
-  r = fmaf(r, ax, 0.03072212263941765f);
-  r = fmaf(r, ax, -0.05011430382728577f);
-  r = fmaf(r, ax, 0.08896885067224503f);
-  r = fmaf(r, ax, -0.214598149061203f);
-  r = fmaf(r, ax, 1.570796251296997f);
-  return r;
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// 2^64 * exp(-acos(clip(g.c))^2 / sigma^2)            reference: utils/coma.py:108-110
-__device__ __forceinline__ float bin_weight(float gx, float gy, float gz, float cx, float cy, float cz,
-                                            float cexp) {
-  float x = fmaf(gz, cz, fmaf(gy, cy, gx * cx));
-  float ax = fabsf(x);
-  float t = fmaxf(1.0f - ax, 0.0f);                  // also clips |x| > 1 (f32 image of the f64 clip)
-  float r = __builtin_amdgcn_sqrtf(t) * acos_poly(ax);
-  float th = (x < 0.0f) ? (kPi - r) : r;
-  return __builtin_amdgcn_exp2f(fmaf(th * th, cexp, 64.0f));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+
+// Two bin weights at once (same bin, the two histograms), written on float2 so that the Horner chain,
+// the dot product and the exponent argument issue as v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: a plain
+// v_fma_f32 costs ~3 cycles per wave64 on gfx950, a packed one 4 cycles for two results.
+//
+//   w = 2^64 * exp(-acos(clip(g.c))^2 / sigma^2)                       reference: utils/coma.py:108-110
+//   acos(|x|) = sqrt(1-|x|) * P(|x|), P = degree-7 interpolant of acos(x)/sqrt(1-x) at Chebyshev nodes of
+//   [0,1] (|error| <= 2.9e-8 exact, 2.5e-7 evaluated in f32);  acos(x) = pi/2 + sign(x) * (acos(|x|) - pi/2).
+//   sqrt(|1-|x||) stands in for the clip: |x| exceeds 1 by at most 2 ulp, which moves theta by < 5e-4 near
+//   theta = 0 or pi where d w / d theta vanishes (relative effect on w < 1e-5).
+__device__ __forceinline__ f32x2 bin_weight2(float gx, float gy, float gz, f32x2 cx, f32x2 cy, f32x2 cz,
+                                             f32x2 cexp) {
+  f32x2 x = pk_fma(splat(gz), cz, pk_fma(splat(gy), cy, splat(gx) * cx));
+  f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+  f32x2 t = splat(1.0f) - ax;
+  f32x2 r = splat(-0.001211737748235464f);
+  r = pk_fma(r, ax, splat(0.006491521373391151f));
+  r = pk_fma(r, ax, splat(-0.01684105210006237f));
+  r = pk_fma(r, ax, splat(0.03072212263941765f));
+  r = pk_fma(r, ax, splat(-0.05011430382728577f));
+  r = pk_fma(r, ax, splat(0.08896885067224503f));
+  r = pk_fma(r, ax, splat(-0.214598149061203f));
+  r = pk_fma(r, ax, splat(1.570796251296997f));
+  f32x2 s = {__builtin_amdgcn_sqrtf(fabsf(t.x)), __builtin_amdgcn_sqrtf(fabsf(t.y))};
+  f32x2 u = pk_fma(s, r, splat(-0.5f * kPi));                       // acos(|x|) - pi/2
+  f32x2 sg = {__builtin_copysignf(1.0f, x.x), __builtin_copysignf(1.0f, x.y)};
+  f32x2 th = pk_fma(sg, u, splat(0.5f * kPi));
+  f32x2 e = pk_fma(th * th, cexp, splat(64.0f));
+  return f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
 }
 
 struct V3 {
@@ -130,11 +140,12 @@ __global__ __launch_bounds__(kWavesPerBlock* kWave) void contact_accumulate_kern
     gz[b] = ok ? A.grid[3 * k + 2] : 0.0f;
   }
 
-  float acc1[PT][NB], acc2[PT][NB];
+  f32x2 acc[PT][NB];   // .x: human-wrt-object histogram, .y: object-wrt-human histogram
 #pragma unroll
   for (int p = 0; p < PT; ++p)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc1[p][b] = acc2[p][b] = 0.0f;
+    for (int b = 0; b < NB; ++b) acc[p][b] = splat(0.0f);
+  const f32x2 cexp2 = splat(A.cexp);
 
   // scalar role of this lane: pair (lane & 7), sample slot (lane >> 3)
   const int64_t my_pair = pair0 + (lane & (PT - 1));
@@ -170,13 +181,11 @@ __global__ __launch_bounds__(kWavesPerBlock* kWave) void contact_accumulate_kern
 #pragma unroll
       for (int q = 0; q < PT; ++q) {
         const int j = s * PT + q;
-        const float c1x = bcast(c1.x, j), c1y = bcast(c1.y, j), c1z = bcast(c1.z, j);
-        const float c2x = bcast(c2.x, j), c2y = bcast(c2.y, j), c2z = bcast(c2.z, j);
+        const f32x2 cx = {bcast(c1.x, j), bcast(c2.x, j)};
+        const f32x2 cy = {bcast(c1.y, j), bcast(c2.y, j)};
+        const f32x2 cz = {bcast(c1.z, j), bcast(c2.z, j)};
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          acc1[q][b] += bin_weight(gx[b], gy[b], gz[b], c1x, c1y, c1z, A.cexp);
-          acc2[q][b] += bin_weight(gx[b], gy[b], gz[b], c2x, c2y, c2z, A.cexp);
-        }
+        for (int b = 0; b < NB; ++b) acc[q][b] += bin_weight2(gx[b], gy[b], gz[b], cx, cy, cz, cexp2);
       }
     }
   }
@@ -192,8 +201,8 @@ __global__ __launch_bounds__(kWavesPerBlock* kWave) void contact_accumulate_kern
         const int k = kbase + b * kWave + lane;
         if (k < A.N) {
           const int64_t idx = pair * A.N + k;
-          A.P1[idx] += acc1[q][b] * kUnscale;
-          A.P2[idx] += acc2[q][b] * kUnscale;
+          A.P1[idx] += acc[q][b].x * kUnscale;
+          A.P2[idx] += acc[q][b].y * kUnscale;
         }
       }
     }
