@@ -32,6 +32,17 @@ SIGNATURES = {
     "coma_occupancy_splat": (_i, [_vp, _i, _i, _i, _vp, _d, _d, _vp, _vp]),
     "coma_occupancy_reduce": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "coma_nearest_vertex_i64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    # include/sd_hip.h
+    "sd_conv_gemm_f16": (_i, [_vp, _vp]),
+    "sd_groupnorm_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
+    "sd_layernorm_f16": (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp]),
+    "sd_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "sd_softmax_f16": (_i, [_vp, _i64, _i, _i, _f, _vp]),
+    "sd_cfg_ddim_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp]),
+    "sd_timestep_embedding_f16": (_i, [_vp, _i, _i, _vp, _vp]),
+    "sd_nchw_to_nhwc_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "sd_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "sd_image_to_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 

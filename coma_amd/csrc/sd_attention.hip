@@ -1,0 +1,225 @@
+// sd_attention.hip -- fused multi-head attention with online softmax for the UNet transformer blocks (gfx950).
+//
+// replaces: diffusers' Attention processor (softmax(q k^T / sqrt(d)) v) reached from the reference through
+// self.unet(...) (utils/adaptive_mask_inpainting.py:1001-1007); self-attention at L = 4096/1024/256/64 with
+// d = 40/80/160/160 and cross-attention over 77 text tokens.
+//
+// Formulation ("swapped", so that softmax state is lane-local): with v_mfma_f32_32x32x16_f16
+//     S^T[key, q] = K[key, :] . Q[q, :]        A = K tile (LDS, ds_read_b128), B = Q (registers, loaded once)
+//     O^T[dd, q] += V^T[dd, key] . P^T[key, q]  A = V^T tile (LDS, 2 x ds_read_b64), B = P (from the S accumulators)
+// the C layout puts query q = lane & 31 in every accumulator register of a lane, so the running max, the
+// running sum and the rescale factor are one scalar per lane (two lanes share a query and exchange one value
+// per tile).  The contraction index of the second product is the key; because a sum is invariant under a
+// permutation of its index, P is fed to the MFMA in the order the accumulator registers already hold it and the
+// V^T fragment is read in the matching order (keys {0-3, 8-11}+4*half per 16-key step) -- no cross-lane traffic.
+// V must be supplied TRANSPOSED ([heads*d, keys]); the projection GEMM produces that layout directly
+// (sd_conv_gemm_f16 with the weight as the A operand), so no transpose pass exists anywhere.
+//
+// Block = 4 waves x 32 queries = 128 queries of one (batch, head); K / V^T tiles of 64 keys staged in LDS with
+// padded rows (stride/16 B odd for the b128 reads, stride/8 B odd for the b64 reads -> conflict-free).
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "../../include/sd_hip.h"
+
+namespace sd {
+
+using coma::check_launch;
+using coma::fail;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int BKV = 64;            // keys per tile
+constexpr int VT_STRIDE = BKV + 4; // halves (136 B rows)
+
+struct AttnArgs {
+  const _Float16* q;
+  const _Float16* k;
+  const _Float16* vt;
+  _Float16* out;
+  int heads, lq, lk, d;
+  int ldq, ldk, ldv, ldo;
+  float scale_log2;   // scale * log2(e)
+};
+
+template <int KS, int DVT>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+  constexpr int DQK = KS * 16;
+  constexpr int K_STRIDE = DQK + 8;     // halves
+  constexpr int DV = DVT * 32;
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[BKV * K_STRIDE];
+  __shared__ __attribute__((aligned(16))) _Float16 Vs[DV * VT_STRIDE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int d = a.d;
+
+  // zero both tiles once: pad columns / pad rows must hold finite values
+  for (int i = tid; i < BKV * K_STRIDE / 8; i += 256) reinterpret_cast<uint4*>(Ks)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = tid; i < DV * VT_STRIDE / 4; i += 256) reinterpret_cast<uint2*>(Vs)[i] = make_uint2(0, 0);
+
+  // Q fragments (B operand): lane (query ql, half hh) holds dd = ks*16 + hh*8 .. +7
+  half8 qf[KS];
+  {
+    const int qi = q0 + ql;
+    const _Float16* qp = a.q + ((long long)b * a.lq + (qi < a.lq ? qi : 0)) * a.ldq + h * d;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int dd = ks * 16 + hh * 8;
+      if (qi < a.lq && dd < d) {
+        qf[ks] = *reinterpret_cast<const half8*>(qp + dd);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (_Float16)0.0f;
+      }
+    }
+  }
+
+  float16v o[DVT];
+#pragma unroll
+  for (int t = 0; t < DVT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+  float m_run = -__builtin_inff(), l_run = 0.0f;
+
+  const _Float16* kbase = a.k + (long long)b * a.lk * a.ldk + h * d;
+  const _Float16* vbase = a.vt + ((long long)b * a.heads + h) * d * (long long)a.ldv;
+  const int kchunks = d / 8;            // 16-byte chunks per K row
+  __syncthreads();
+
+  for (int key0 = 0; key0 < a.lk; key0 += BKV) {
+    // ---- stage K tile [64 keys][d] and V^T tile [d][64 keys]
+    for (int it = tid; it < BKV * kchunks; it += 256) {
+      const int row = it / kchunks, ch = it - row * kchunks;
+      const int key = key0 + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (key < a.lk) v = *reinterpret_cast<const uint4*>(kbase + (long long)key * a.ldk + ch * 8);
+      *reinterpret_cast<uint4*>(&Ks[row * K_STRIDE + ch * 8]) = v;
+    }
+    for (int it = tid; it < d * (BKV / 8); it += 256) {
+      const int row = it >> 3, ch = it & 7;
+      const int key = key0 + ch * 8;
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+      if (key + 8 <= a.lk) {
+        v = *reinterpret_cast<const half8*>(vbase + (long long)row * a.ldv + key);
+      } else if (key < a.lk) {
+        const _Float16* p = vbase + (long long)row * a.ldv + key;
+        for (int j = 0; j < a.lk - key; ++j) v[j] = p[j];
+      }
+      // 8 halves = two 8-byte LDS writes (rows are 8-byte aligned, not 16)
+      half4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<half4*>(&Vs[row * VT_STRIDE + ch * 8]) = lo;
+      *reinterpret_cast<half4*>(&Vs[row * VT_STRIDE + ch * 8 + 4]) = hi;
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T  (two 32-key tiles)
+    float16v s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        half8 kf = *reinterpret_cast<const half8*>(&Ks[(t * 32 + ql) * K_STRIDE + ks * 16 + hh * 8]);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (per-lane scalars; the partner lane holds the other 32 keys of this query)
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float v = s[t][r] * a.scale_log2;
+        v = key < a.lk ? v : -__builtin_inff();
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);            // finite: every tile has at least one valid key
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.0f;
+    half8 pf[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = __builtin_amdgcn_exp2f(s[t][r] - m_new);
+        psum += p;
+        pf[t * 2 + (r >> 3)][r & 7] = (_Float16)p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    // ---- O^T += V^T P^T, 16 keys per MFMA, keys in accumulator-register order
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int base = (st >> 1) * 32 + (st & 1) * 16 + 4 * hh;
+#pragma unroll
+      for (int t = 0; t < DVT; ++t) {
+        const _Float16* vp = &Vs[(t * 32 + ql) * VT_STRIDE + base];
+        half4 lo = *reinterpret_cast<const half4*>(vp);
+        half4 hi = *reinterpret_cast<const half4*>(vp + 8);
+        half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane (query, half) owns dd = t*32 + 8*(r>>2) + 4*hh + (r&3)
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int qi = q0 + ql;
+  if (qi < a.lq) {
+    _Float16* op = a.out + ((long long)b * a.lq + qi) * a.ldo + h * d;
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = t * 32 + 8 * g + 4 * hh;
+        if (dd < d) {
+          half4 v = {(_Float16)(o[t][g * 4 + 0] * inv), (_Float16)(o[t][g * 4 + 1] * inv),
+                     (_Float16)(o[t][g * 4 + 2] * inv), (_Float16)(o[t][g * 4 + 3] * inv)};
+          *reinterpret_cast<half4*>(op + dd) = v;
+        }
+      }
+  }
+}
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq,
+                                int lk, int d, int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
+  if (!q || !k || !vt || !out) return fail(COMA_E_INVALID, "sd_attention_f16: null pointer");
+  if (batch <= 0 || heads <= 0 || lq <= 0 || lk <= 0) return fail(COMA_E_INVALID, "sd_attention_f16: bad sizes");
+  if (d % 8 || d <= 0 || d > 160) return fail(COMA_E_INVALID, "sd_attention_f16: head dim %d unsupported (multiple of 8, <= 160)", d);
+  if (ldq < heads * d || ldk < heads * d || ldo < heads * d || ldv < lk || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
+    return fail(COMA_E_INVALID, "sd_attention_f16: bad leading dimensions");
+  AttnArgs a;
+  a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.vt = (const _Float16*)vt; a.out = (_Float16*)out;
+  a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  dim3 grid((unsigned)((lq + 127) / 128), (unsigned)heads, (unsigned)batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (d <= 48) hipLaunchKernelGGL((attention_kernel<3, 2>), grid, dim3(256), 0, s, a);
+  else if (d <= 64) hipLaunchKernelGGL((attention_kernel<4, 2>), grid, dim3(256), 0, s, a);
+  else if (d <= 80) hipLaunchKernelGGL((attention_kernel<5, 3>), grid, dim3(256), 0, s, a);
+  else if (d <= 96) hipLaunchKernelGGL((attention_kernel<6, 3>), grid, dim3(256), 0, s, a);
+  else if (d <= 128) hipLaunchKernelGGL((attention_kernel<8, 4>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attention_kernel<10, 5>), grid, dim3(256), 0, s, a);
+  return check_launch("attention_kernel");
+}

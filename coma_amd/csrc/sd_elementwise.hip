@@ -1,0 +1,150 @@
+// sd_elementwise.hip -- the small elementwise pieces of the inpainting loop (gfx950): CFG + DDIM step + next-input
+// assembly in one pass, sinusoidal timestep embedding, boundary layout conversions, image -> uint8.
+// replaces: utils/adaptive_mask_inpainting.py:990-996, :1010-1017, :1111-1115 and diffusers' DDIMScheduler.step /
+// get_timestep_embedding / VaeImageProcessor.postprocess (third party, diffusers==0.20.2).
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "../../include/sd_hip.h"
+
+namespace sd {
+
+using coma::check_launch;
+using coma::fail;
+
+// one thread per (b, pixel)
+__global__ void cfg_ddim_kernel(const _Float16* __restrict__ eps_uc, int eps_ld, float* __restrict__ latents,
+                                float* __restrict__ x0_out, const _Float16* __restrict__ mask,
+                                const _Float16* __restrict__ masked, _Float16* __restrict__ unet_in, int batch, int hw,
+                                float guidance, float sa_t, float s1ma_t, float sa_p, float s1ma_p, int write_latents) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)batch * hw) return;
+  float x[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float xt = latents[i * 4 + c];
+    if (eps_uc) {
+      float eu = (float)eps_uc[i * eps_ld + c];
+      float ec = (float)eps_uc[(i + (long long)batch * hw) * eps_ld + c];
+      float e = eu + guidance * (ec - eu);
+      float x0 = (xt - s1ma_t * e) / sa_t;
+      if (x0_out) x0_out[i * 4 + c] = x0;
+      xt = sa_p * x0 + s1ma_p * e;
+      if (write_latents) latents[i * 4 + c] = xt;
+    }
+    x[c] = xt;
+  }
+  if (unet_in) {
+    // channels: latents(4) | mask(1) | masked_image_latents(4) | zero pad to 32; identical for the two CFG halves
+    _Float16 v[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = (_Float16)0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (_Float16)x[c];
+    v[4] = mask[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[5 + c] = masked[i * 4 + c];
+    uint4* o0 = reinterpret_cast<uint4*>(unet_in + i * 32);
+    uint4* o1 = reinterpret_cast<uint4*>(unet_in + (i + (long long)batch * hw) * 32);
+    const uint4* src = reinterpret_cast<const uint4*>(v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      o0[q] = src[q];
+      o1[q] = src[q];
+    }
+  }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int batch, int dim, _Float16* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch * dim) return;
+  int b = i / dim, j = i - b * dim, half = dim / 2;
+  int k = j < half ? j : j - half;
+  float freq = __expf(-9.210340371976184f * (float)k / (float)half);   // ln(10000)
+  float a = t[b] * freq;
+  out[i] = (_Float16)(j < half ? cosf(a) : sinf(a));                    // flip_sin_to_cos: [cos | sin]
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int batch, int c, int hw, int cpad,
+                                    _Float16* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)batch * hw * cpad) return;
+  int ch = (int)(i % cpad);
+  long long bp = i / cpad;
+  int p = (int)(bp % hw);
+  int b = (int)(bp / hw);
+  out[i] = ch < c ? (_Float16)x[((long long)b * c + ch) * hw + p] : (_Float16)0.0f;
+}
+
+__global__ void nhwc_to_nchw_kernel(const _Float16* __restrict__ x, int batch, int c, int hw, int ld,
+                                    float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)batch * c * hw) return;
+  int p = (int)(i % hw);
+  long long bc = i / hw;
+  int ch = (int)(bc % c);
+  int b = (int)(bc / c);
+  out[i] = (float)x[((long long)b * hw + p) * ld + ch];
+}
+
+__global__ void image_to_u8_kernel(const _Float16* __restrict__ x, long long npix, int ld, int round_mode,
+                                   uint8_t* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix * 3) return;
+  long long p = i / 3;
+  int c = (int)(i - p * 3);
+  float v = (float)x[p * ld + c] * 0.5f + 0.5f;
+  v = fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f;
+  out[i] = (uint8_t)(round_mode ? rintf(v) : v);   // astype(uint8) truncates; PIL path rounds
+}
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" int sd_cfg_ddim_step(const void* eps_uc, int eps_ld, float* latents, float* x0_out, const void* mask,
+                                const void* masked_latents, void* unet_in, int batch, int hw, float guidance, float alpha_t,
+                                float alpha_prev, int write_latents, void* stream) {
+  if (!latents) return fail(COMA_E_INVALID, "sd_cfg_ddim_step: null latents");
+  if (unet_in && (!mask || !masked_latents)) return fail(COMA_E_INVALID, "sd_cfg_ddim_step: mask inputs missing");
+  if (batch <= 0 || hw <= 0) return fail(COMA_E_INVALID, "sd_cfg_ddim_step: bad sizes");
+  if (eps_uc && (!(alpha_t > 0.f) || alpha_t > 1.f || alpha_prev < 0.f || alpha_prev > 1.f))
+    return fail(COMA_E_INVALID, "sd_cfg_ddim_step: alphas out of range");
+  long long n = (long long)batch * hw;
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)eps_uc, eps_ld, latents, x0_out, (const _Float16*)mask, (const _Float16*)masked_latents,
+                     (_Float16*)unet_in, batch, hw, guidance, sqrtf(alpha_t), sqrtf(1.0f - alpha_t), sqrtf(alpha_prev),
+                     sqrtf(1.0f - alpha_prev), write_latents);
+  return check_launch("cfg_ddim_kernel");
+}
+
+extern "C" int sd_timestep_embedding_f16(const float* timesteps, int batch, int dim, void* out, void* stream) {
+  if (!timesteps || !out || batch <= 0 || dim <= 0 || dim % 2) return fail(COMA_E_INVALID, "sd_timestep_embedding_f16: bad args");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((batch * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, timesteps,
+                     batch, dim, (_Float16*)out);
+  return check_launch("timestep_embedding_kernel");
+}
+
+extern "C" int sd_nchw_to_nhwc_f16(const float* x, int batch, int c, int hw, int cpad, void* out, void* stream) {
+  if (!x || !out || batch <= 0 || c <= 0 || hw <= 0 || cpad < c) return fail(COMA_E_INVALID, "sd_nchw_to_nhwc_f16: bad args");
+  long long n = (long long)batch * hw * cpad;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, batch, c, hw,
+                     cpad, (_Float16*)out);
+  return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int sd_nhwc_to_nchw_f32(const void* x, int batch, int c, int hw, int ld, float* out, void* stream) {
+  if (!x || !out || batch <= 0 || c <= 0 || hw <= 0 || ld < c) return fail(COMA_E_INVALID, "sd_nhwc_to_nchw_f32: bad args");
+  long long n = (long long)batch * hw * c;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x, batch, c, hw, ld, out);
+  return check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int sd_image_to_u8(const void* x, int batch, int hw, int ld, int round_mode, uint8_t* out, void* stream) {
+  if (!x || !out || batch <= 0 || hw <= 0 || ld < 3) return fail(COMA_E_INVALID, "sd_image_to_u8: bad args");
+  long long npix = (long long)batch * hw;
+  hipLaunchKernelGGL(image_to_u8_kernel, dim3((unsigned)((npix * 3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x, npix, ld, round_mode, out);
+  return check_launch("image_to_u8_kernel");
+}

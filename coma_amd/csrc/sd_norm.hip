@@ -1,0 +1,227 @@
+// sd_norm.hip -- GroupNorm(+SiLU), LayerNorm and row softmax over NHWC fp16 (gfx950).  HBM-bound kernels:
+// every global access is a 16-byte vector of 8 consecutive channels, statistics in fp32.
+//
+// GroupNorm runs as (1) per-(pixel-chunk) partial sums written to a scratch slab, (2) a tiny finalize that folds
+// the partials in a fixed order (deterministic, no atomics, no memset) into mean / rstd, (3) a fully coalesced
+// normalise + affine + SiLU pass.  It can read the channel concatenation of TWO tensors and writes one, which is
+// how the UNet's skip-connection torch.cat is materialised for free.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "../../include/sd_hip.h"
+
+namespace sd {
+
+using coma::check_launch;
+using coma::fail;
+using coma::kWave;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int GN_PIX = 64;       // pixels per partial-sum block
+constexpr int GN_MAX_GROUPS = 32;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
+__device__ __forceinline__ half8 load8(const _Float16* x0, const _Float16* x1, int c0, int c1, long long pix, int c) {
+  const _Float16* p = c < c0 ? x0 + pix * c0 + c : x1 + pix * c1 + (c - c0);
+  return *reinterpret_cast<const half8*>(p);
+}
+
+// partial[b][chunk][g][2] = (sum, sumsq) over GN_PIX pixels x (C/G) channels
+constexpr int GN_MAX_C = 2560;
+__global__ __launch_bounds__(256) void gn_partial_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
+                                                         int c0, int c1, int hw, int groups, float* __restrict__ partial) {
+  __shared__ float chs[GN_MAX_C], chq[GN_MAX_C];   // per-channel sums of this pixel chunk
+  const int C = c0 + c1, cg = C / groups;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int p0 = chunk * GN_PIX, p1 = min(hw, p0 + GN_PIX);
+  for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0f;
+    for (int p = p0; p < p1; ++p) {
+      half8 v = load8(x0, x1, c0, c1, (long long)b * hw + p, c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)v[j];
+        s[j] += f;
+        q[j] += f * f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      chs[c + j] = s[j];
+      chq[c + j] = q[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < groups) {   // fixed summation order -> bitwise reproducible statistics
+    float s = 0.0f, q = 0.0f;
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) {
+      s += chs[c];
+      q += chq[c];
+    }
+    float* p = partial + ((long long)b * nchunk + chunk) * groups * 2 + threadIdx.x * 2;
+    p[0] = s;
+    p[1] = q;
+  }
+}
+
+// stats[b][g] = (mean, rstd)
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int groups, float count, float eps,
+                                   float* __restrict__ stats, int total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // (b, g)
+  if (i >= total) return;
+  int b = i / groups, g = i - b * groups;
+  float s = 0.0f, q = 0.0f;
+  for (int c = 0; c < nchunk; ++c) {
+    const float* p = partial + ((long long)b * nchunk + c) * groups * 2 + g * 2;
+    s += p[0];
+    q += p[1];
+  }
+  float mean = s / count;
+  float var = fmaxf(q / count - mean * mean, 0.0f);
+  stats[2 * i] = mean;
+  stats[2 * i + 1] = rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
+                                                       int c0, int c1, int hw, int groups, const float* __restrict__ stats,
+                                                       const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
+                                                       int silu, _Float16* __restrict__ out, long long total8) {
+  const int C = c0 + c1, cg = C / groups, c8 = C / 8;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total8) return;
+  long long pix = i / c8;
+  int c = (int)(i - pix * c8) * 8;
+  int b = (int)(pix / hw);
+  half8 v = load8(x0, x1, c0, c1, pix, c);
+  half8 ga = *reinterpret_cast<const half8*>(gamma + c);
+  half8 be = *reinterpret_cast<const half8*>(beta + c);
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int g = (c + j) / cg;
+    float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
+    float y = ((float)v[j] - mean) * rstd * (float)ga[j] + (float)be[j];
+    if (silu) y = y / (1.0f + __expf(-y));
+    o[j] = (_Float16)y;
+  }
+  *reinterpret_cast<half8*>(out + pix * C + c) = o;
+}
+
+// one wave per row; C <= 64*8*4
+__global__ __launch_bounds__(256) void layernorm_kernel(const _Float16* __restrict__ x, long long rows, int C, float eps,
+                                                        const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
+                                                        _Float16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c8 = C / 8;
+  half8 v[4];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ch = lane + i * 64;
+    if (ch < c8) {
+      v[i] = *reinterpret_cast<const half8*>(x + row * C + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ch = lane + i * 64;
+    if (ch < c8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float d = (float)v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ch = lane + i * 64;
+    if (ch < c8) {
+      half8 ga = *reinterpret_cast<const half8*>(gamma + ch * 8);
+      half8 be = *reinterpret_cast<const half8*>(beta + ch * 8);
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)v[i][j] - mean) * rstd * (float)ga[j] + (float)be[j]);
+      *reinterpret_cast<half8*>(out + row * C + ch * 8) = o;
+    }
+  }
+}
+
+// in-place softmax(scale * x) over each row of fp16 [rows, n] (block per row)
+__global__ __launch_bounds__(256) void softmax_kernel(_Float16* __restrict__ x, int n, int ld, float scale) {
+  __shared__ float red[4];
+  _Float16* row = x + (long long)blockIdx.x * ld;
+  float m = -__builtin_inff();
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, (float)row[i] * scale);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < n; i += 256) s += __expf((float)row[i] * scale - m);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+  for (int i = threadIdx.x; i < n; i += 256) row[i] = (_Float16)(__expf((float)row[i] * scale - m) * inv);
+}
+
+}  // namespace sd
+
+using namespace sd;
+
+extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                                const void* gamma, const void* beta, int silu, void* out, float* stats, void* stream) {
+  if (!x0 || !gamma || !beta || !out || !stats) return fail(COMA_E_INVALID, "sd_groupnorm_f16: null pointer");
+  if (c1 > 0 && !x1) return fail(COMA_E_INVALID, "sd_groupnorm_f16: x1 missing");
+  const int C = c0 + c1;
+  if (batch <= 0 || hw <= 0 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || c1 % 8 || C > GN_MAX_C)
+    return fail(COMA_E_INVALID, "sd_groupnorm_f16: bad shape C=%d groups=%d", C, groups);
+  const int nchunk = (hw + GN_PIX - 1) / GN_PIX;
+  // scratch layout: [batch*groups*2] final stats, then [batch*nchunk*groups*2] partials
+  float* partial = stats + (size_t)batch * groups * 2;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, s, (const _Float16*)x0, (const _Float16*)x1, c0, c1,
+                     hw, groups, partial);
+  const int total = batch * groups;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 63) / 64), dim3(64), 0, s, partial, nchunk, groups,
+                     (float)hw * (float)(C / groups), eps, stats, total);
+  const long long total8 = (long long)batch * hw * (C / 8);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const _Float16*)x0,
+                     (const _Float16*)x1, c0, c1, hw, groups, stats, (const _Float16*)gamma, (const _Float16*)beta, silu,
+                     (_Float16*)out, total8);
+  return check_launch("groupnorm kernels");
+}
+
+extern "C" int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* gamma, const void* beta,
+                                void* out, void* stream) {
+  if (!x || !gamma || !beta || !out) return fail(COMA_E_INVALID, "sd_layernorm_f16: null pointer");
+  if (rows <= 0 || c <= 0 || c % 8 || c > 2048) return fail(COMA_E_INVALID, "sd_layernorm_f16: bad shape c=%d", c);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)x, (long long)rows, c, eps, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)out);
+  return check_launch("layernorm_kernel");
+}
+
+extern "C" int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream) {
+  if (!x) return fail(COMA_E_INVALID, "sd_softmax_f16: null pointer");
+  if (rows <= 0 || n <= 0 || ld < n) return fail(COMA_E_INVALID, "sd_softmax_f16: bad shape");
+  hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (_Float16*)x, n, ld, scale);
+  return check_launch("softmax_kernel");
+}

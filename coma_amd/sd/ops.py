@@ -1,0 +1,114 @@
+"""Thin Python bindings of the sd_* C ABI (include/sd_hip.h).  Activations are NHWC fp16 tensors on a HIP device;
+every function launches on torch's current stream and raises ComaHipError on failure.  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+EPI_NONE, EPI_GEGLU, EPI_SILU, EPI_BIAS_ROWS = 0, 1, 2, 4
+F16 = torch.float16
+
+
+class ConvGemmDesc(C.Structure):
+    _fields_ = [("a0", C.c_void_p), ("a1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
+                ("batch", C.c_int), ("in_h", C.c_int), ("in_w", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int),
+                ("taps", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("pad", C.c_int), ("n", C.c_int),
+                ("w", C.c_void_p), ("bias", C.c_void_p), ("bias_bn", C.c_void_p), ("ldbb", C.c_int), ("res", C.c_void_p), ("ldr", C.c_int),
+                ("out", C.c_void_p), ("ldo", C.c_int), ("epi", C.c_int), ("nbatch_z", C.c_int),
+                ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64)]
+
+
+def _p(t, name="tensor", dtype=F16):
+    if t is None:
+        return None
+    return _lib.ptr(t, dtype, name).value
+
+
+def _stream(t):
+    return _lib.stream_ptr(t.device)
+
+
+def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a1=None, c1=0, taps=1, stride=1, upsample=0,
+              pad=1, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, epi=EPI_NONE, nbatch_z=1, stride_a=0, stride_w=0,
+              stride_out=0, stride_res=0):
+    d = ConvGemmDesc()
+    d.a0, d.a1, d.c0, d.c1 = _p(a0, "a0"), _p(a1, "a1"), c0, c1
+    d.batch, d.in_h, d.in_w = batch, in_h, in_w
+    d.out_h = out_h if out_h is not None else in_h
+    d.out_w = out_w if out_w is not None else in_w
+    d.taps, d.stride, d.upsample, d.pad, d.n = taps, stride, upsample, pad, n
+    d.ldbb = ldbb
+    d.w, d.bias, d.bias_bn, d.res, d.ldr = _p(w, "w"), _p(bias, "bias"), _p(bias_bn, "bias_bn"), _p(res, "res"), ldr
+    d.out, d.ldo, d.epi, d.nbatch_z = _p(out, "out"), ldo, epi, nbatch_z
+    d.stride_a, d.stride_w, d.stride_out, d.stride_res = stride_a, stride_w, stride_out, stride_res
+    _lib.check(_lib.lib().sd_conv_gemm_f16(C.byref(d), _stream(out)), "sd_conv_gemm_f16")
+    return out
+
+
+def linear(x, w, out, *, rows, k, n, bias=None, res=None, epi=EPI_NONE, ldo=0):
+    """out[rows, n] = x[rows, k] @ w[n, k]^T (+bias)(+res)."""
+    return conv_gemm(x, w, out, batch=rows, in_h=1, in_w=1, c0=k, n=n, bias=bias, res=res, epi=epi, ldo=ldo)
+
+
+def groupnorm(x0, gamma, beta, out, stats, *, batch, hw, c0, x1=None, c1=0, groups=32, eps=1e-5, silu=True):
+    rc = _lib.lib().sd_groupnorm_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, hw, groups, eps, _p(gamma), _p(beta),
+                                     1 if silu else 0, _p(out, "out"), _p(stats, "stats", torch.float32), _stream(out))
+    _lib.check(rc, "sd_groupnorm_f16")
+    return out
+
+
+def gn_scratch_floats(batch, hw, groups=32):
+    return batch * groups * 2 * (1 + (hw + 63) // 64)
+
+
+def layernorm(x, gamma, beta, out, *, rows, c, eps=1e-5):
+    _lib.check(_lib.lib().sd_layernorm_f16(_p(x), rows, c, eps, _p(gamma), _p(beta), _p(out), _stream(out)), "sd_layernorm_f16")
+    return out
+
+
+def attention(q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale):
+    rc = _lib.lib().sd_attention_f16(_p(q, "q"), _p(k, "k"), _p(vt, "vt"), _p(out, "out"), batch, heads, lq, lk, d, ldq, ldk,
+                                     ldv, ldo, scale, _stream(out))
+    _lib.check(rc, "sd_attention_f16")
+    return out
+
+
+def softmax_(x, *, rows, n, ld, scale):
+    _lib.check(_lib.lib().sd_softmax_f16(_p(x), rows, n, ld, scale, _stream(x)), "sd_softmax_f16")
+    return x
+
+
+def cfg_ddim_step(eps_uc, eps_ld, latents, x0_out, mask, masked_latents, unet_in, *, batch, hw, guidance, alpha_t, alpha_prev,
+                  write_latents=True):
+    f32 = torch.float32
+    rc = _lib.lib().sd_cfg_ddim_step(_p(eps_uc, "eps"), eps_ld, _p(latents, "latents", f32), _p(x0_out, "x0", f32), _p(mask),
+                                     _p(masked_latents), _p(unet_in), batch, hw, guidance, alpha_t, alpha_prev,
+                                     1 if write_latents else 0, _stream(latents))
+    _lib.check(rc, "sd_cfg_ddim_step")
+
+
+def timestep_embedding(t, out, *, batch, dim):
+    _lib.check(_lib.lib().sd_timestep_embedding_f16(_p(t, "t", torch.float32), batch, dim, _p(out), _stream(out)),
+               "sd_timestep_embedding_f16")
+    return out
+
+
+def nchw_to_nhwc(x, out, *, batch, c, hw, cpad):
+    _lib.check(_lib.lib().sd_nchw_to_nhwc_f16(_p(x, "x", torch.float32), batch, c, hw, cpad, _p(out), _stream(out)),
+               "sd_nchw_to_nhwc_f16")
+    return out
+
+
+def nhwc_to_nchw(x, out, *, batch, c, hw, ld):
+    _lib.check(_lib.lib().sd_nhwc_to_nchw_f32(_p(x), batch, c, hw, ld, _p(out, "out", torch.float32), _stream(out)),
+               "sd_nhwc_to_nchw_f32")
+    return out
+
+
+def image_to_u8(x, out, *, batch, hw, ld, round_mode=0):
+    _lib.check(_lib.lib().sd_image_to_u8(_p(x), batch, hw, ld, round_mode, _p(out, "out", torch.uint8), _stream(out)),
+               "sd_image_to_u8")
+    return out

@@ -1,0 +1,112 @@
+/*
+ * sd_hip.h -- C ABI of the diffusion operators in libcoma_hip.so (MI355X / gfx950, fp16 storage, fp32 accumulate).
+ *
+ * The reference drives Stable-Diffusion-1.5-inpainting through diffusers modules
+ * (utils/adaptive_mask_inpainting.py:1001-1007 `self.unet(...)`, :1086/:1112 `self.vae.decode`, :677-680
+ * `self.vae.encode`, :1015-1017 `self.scheduler.step`); diffusers itself is a third-party dependency that is
+ * not under the reference tree (pinned diffusers==0.20.2, INSTALL.md:31).  These entry points are the
+ * operators those modules decompose into; the Python host mirror (coma_amd/sd) builds the UNet / VAE graphs
+ * out of them behind the same call signatures the reference pipeline uses.
+ *
+ * Layout: every activation is NHWC fp16, i.e. a row-major [batch*H*W, C] matrix, so a 1x1 convolution, an
+ * nn.Linear and a token sequence [B, HW, C] are the same buffer.  Weights are [C_out][taps][C_in] fp16
+ * (K-contiguous).  Same conventions as coma_hip.h: int return codes, coma_last_error(), caller-owned device
+ * buffers, explicit hipStream_t.
+ */
+#ifndef SD_HIP_H
+#define SD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogue flags of sd_conv_gemm_f16 */
+#define SD_EPI_NONE 0
+#define SD_EPI_GEGLU 1      /* out[:, j] = v_j * gelu(g_j); weight rows pre-interleaved per 64 columns: [32 v | 32 g] */
+#define SD_EPI_SILU 2       /* out = silu(acc + bias) */
+#define SD_EPI_BIAS_ROWS 4  /* bias indexed by output row instead of column (A = weights, W = activations) */
+
+/* out[m, n] = sum_k A[m, k] * W[n, k] (+ epilogue) with A gathered from one or two NHWC sources:
+ *   m = (b, oy, ox), k = (tap, ci);  taps = 9: 3x3, zero pad 1;  taps = 1: 1x1 / linear
+ *   upsample = 1: the 3x3 window slides over the nearest-x2 upsampling of the [in_h, in_w] input
+ *   ci runs over the concatenation [a0 (c0 channels) | a1 (c1 channels)]; c0, c1 multiples of 32
+ * replaces: torch.nn.Conv2d / nn.Linear / torch.cat / F.interpolate(nearest) inside diffusers'
+ *           UNet2DConditionModel and AutoencoderKL (call sites utils/adaptive_mask_inpainting.py:1001, :1086, :680). */
+typedef struct sd_conv_gemm_desc {
+  const void* a0;       /* fp16 [batch, in_h, in_w, c0] */
+  const void* a1;       /* fp16 [batch, in_h, in_w, c1] or NULL */
+  int c0, c1;
+  int batch, in_h, in_w, out_h, out_w;
+  int taps, stride, upsample;
+  int pad;              /* zero padding on the low (top/left) side: 1 for a "same" 3x3, 0 for the VAE encoder's
+                           asymmetric (0,1,0,1) stride-2 convolution; the high side is bounds-checked */
+  int n;                /* output channels (rows of w) */
+  const void* w;        /* fp16 [n][taps*(c0+c1)] */
+  const void* bias;     /* fp16 [n] or NULL */
+  const void* bias_bn;  /* fp16 [batch][ldbb] or NULL: per-sample bias (time-embedding projection) */
+  int ldbb;             /* row stride of bias_bn (0 -> n) */
+  const void* res;      /* fp16 [M][ldr] residual added after the activation, or NULL */
+  int ldr;
+  void* out;            /* fp16 [M][ldo]  (ldo = 0 -> n, or n/2 with GEGLU) */
+  int ldo;
+  int epi;
+  int nbatch_z;         /* >1: independent problems along grid z with the element strides below */
+  int64_t stride_a, stride_w, stride_out, stride_res;
+} sd_conv_gemm_desc;
+
+int sd_conv_gemm_f16(const sd_conv_gemm_desc* desc, void* stream);
+
+/* GroupNorm (+ optional SiLU) over NHWC fp16, reading the channel concatenation of two sources and writing one
+ * tensor [batch, hw, c0+c1].  replaces: nn.GroupNorm(groups, C, eps) + nn.SiLU in diffusers ResnetBlock2D /
+ * Transformer2DModel / VAE (and the torch.cat feeding the UNet up blocks).
+ * stats: fp32 scratch [batch*groups*2]. */
+int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                     const void* gamma, const void* beta, int silu, void* out, float* stats, void* stream);
+
+/* LayerNorm over the last dim of fp16 [rows, c].  replaces: nn.LayerNorm(C) in BasicTransformerBlock. */
+int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* gamma, const void* beta, void* out,
+                     void* stream);
+
+/* Fused multi-head attention (online softmax), fp16 in/out, fp32 accumulate.
+ *   q   : [batch, lq, ldq]   head h at columns [h*d, (h+1)*d)          (ldq >= heads*d)
+ *   k   : [batch, lk, ldk]   same column convention
+ *   vt  : [batch, heads*d, ldv]  V TRANSPOSED: row h*d+i holds component i of every key (ldv >= lk, mult. of 8)
+ *   out : [batch, lq, ldo]
+ * out = softmax(q k^T * scale) v per (batch, head).  d in {40, 64, 80, 160} (multiples of 8, <= 160).
+ * replaces: diffusers Attention (xformers / AttnProcessor2_0 scaled_dot_product_attention) in the UNet. */
+int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk,
+                     int d, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+
+/* Row softmax in place over fp16 [rows, n] with scale (VAE mid-block attention, un-fused). */
+int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream);
+
+/* Classifier-free guidance + DDIM step (eta = 0) + assembly of the next UNet input, one elementwise pass.
+ *   eps = eps_u + s (eps_c - eps_u);  x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);  x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+ * eps_uc: fp16 NHWC [2B, hw, cpad] UNet output (first B = unconditional, last B = conditional, 4 valid channels)
+ * latents: fp32 [B, hw, 4] in/out;  x0_out: fp32 [B, hw, 4] or NULL (pred_original_sample)
+ * mask: fp16 [B, hw] ; masked_latents fp16 [B, hw, 4]
+ * unet_in: fp16 NHWC [2B, hw, 32]: channels [latents(4) | mask(1) | masked_latents(4) | zero pad] for both halves.
+ * replaces: utils/adaptive_mask_inpainting.py:990-996 (input assembly), :1010-1012 (CFG), :1015-1017 (DDIM step). */
+int sd_cfg_ddim_step(const void* eps_uc, int eps_ld, float* latents, float* x0_out, const void* mask,
+                     const void* masked_latents, void* unet_in, int batch, int hw, float guidance, float alpha_t,
+                     float alpha_prev, int write_latents, void* stream);
+
+/* Sinusoidal timestep embedding (flip_sin_to_cos, shift 0) -> fp16 [batch, dim]. */
+int sd_timestep_embedding_f16(const float* timesteps, int batch, int dim, void* out, void* stream);
+
+/* NCHW fp32 <-> NHWC fp16 with channel padding / cropping (boundary conversions of the module API). */
+int sd_nchw_to_nhwc_f16(const float* x, int batch, int c, int hw, int cpad, void* out, void* stream);
+int sd_nhwc_to_nchw_f32(const void* x, int batch, int c, int hw, int ld, float* out, void* stream);
+
+/* VAE decode epilogue: NHWC fp16 [B, hw, ld] (3 valid channels, range ~[-1,1]) -> uint8 HWC image
+ * (x/2+0.5).clamp(0,1)*255, truncated (round_mode 0: the `.astype(np.uint8)` of utils/adaptive_mask_inpainting.py:1114)
+ * or rounded half-to-even (round_mode 1: diffusers' numpy_to_pil used for the final image, :1097). */
+int sd_image_to_u8(const void* x, int batch, int hw, int ld, int round_mode, uint8_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_HIP_H */

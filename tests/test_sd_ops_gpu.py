@@ -1,0 +1,208 @@
+"""GPU parity of every sd_* operator against a torch fp32 reference of the same op on the same fp16-rounded
+inputs (oracle/sd_oracle.py).  Tolerance: fp16 storage / fp32 accumulation -> |err| <= 3e-3 * max|ref| unless a
+test states otherwise (GroupNorm/attention outputs are O(1), so this is ~1.5 fp16 ulps of the largest values)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_oracle as so
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F16 = torch.float16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(F16)
+
+
+def close(got, ref, tol=3e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs().max().item()
+    lim = tol * ref.abs().max().item() + 1e-6
+    assert err <= lim, f"max abs err {err:.3e} > {lim:.3e}"
+
+
+@pytest.fixture(scope="module")
+def ops(hip_lib):
+    assert torch.cuda.is_available()
+    from coma_amd.sd import ops
+    return ops
+
+
+@pytest.mark.parametrize("rows,k,n", [(300, 320, 640), (128, 64, 320), (77, 768, 1280), (1000, 1280, 64), (5, 320, 1280)])
+def test_linear_bias_residual(ops, rows, k, n):
+    x, w, b, r = rnd(rows, k, seed=1), rnd(n, k, seed=2, scale=k**-0.5), rnd(n, seed=3), rnd(rows, n, seed=4)
+    out = torch.empty(rows, n, dtype=F16, device=DEV)
+    ops.linear(x.to(DEV), w.to(DEV), out, rows=rows, k=k, n=n, bias=b.to(DEV), res=r.to(DEV))
+    close(out, x.float() @ w.float().t() + b.float() + r.float())
+
+
+def test_linear_is_transpose_sensitive(ops):
+    """A = I against an asymmetric W: a swapped row/col mapping in the MFMA C layout cannot pass."""
+    k = n = 128
+    x = torch.eye(k, dtype=F16)
+    w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 97 / 97).to(F16)
+    out = torch.empty(k, n, dtype=F16, device=DEV)
+    ops.linear(x.to(DEV), w.to(DEV), out, rows=k, k=k, n=n)
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("cfg", [dict(c0=64, c1=0, n=128, stride=1, up=0), dict(c0=32, c1=64, n=64, stride=1, up=0),
+                                 dict(c0=64, c1=0, n=64, stride=2, up=0), dict(c0=32, c1=0, n=128, stride=1, up=1),
+                                 dict(c0=96, c1=32, n=320, stride=1, up=0)])
+def test_conv3x3_variants(ops, cfg):
+    B, H, W = 2, 12, 10
+    c0, c1, n = cfg["c0"], cfg["c1"], cfg["n"]
+    x0, x1 = rnd(B * H * W, c0, seed=1), (rnd(B * H * W, c1, seed=2) if c1 else None)
+    w = rnd(n, 9, c0 + c1, seed=3, scale=(9 * (c0 + c1)) ** -0.5)
+    b, tb = rnd(n, seed=4), rnd(B, n, seed=5)
+    oh, ow = (H // 2, W // 2) if cfg["stride"] == 2 else ((2 * H, 2 * W) if cfg["up"] else (H, W))
+    out = torch.empty(B * oh * ow, n, dtype=F16, device=DEV)
+    ops.conv_gemm(x0.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, in_h=H, in_w=W, out_h=oh, out_w=ow, c0=c0, n=n,
+                  a1=x1.to(DEV) if c1 else None, c1=c1, taps=9, stride=cfg["stride"], upsample=cfg["up"], bias=b.to(DEV),
+                  bias_bn=tb.to(DEV))
+    xc = torch.cat([x0, x1], -1) if c1 else x0
+    ref = so.conv_ref(xc, w, batch=B, h=H, w_=W, taps=9, stride=cfg["stride"], upsample=bool(cfg["up"]), bias=b, bias_bn=tb)
+    close(out, ref)
+
+
+def test_conv1x1_two_sources_and_silu(ops):
+    B, H, W, c0, c1, n = 3, 8, 8, 64, 32, 128
+    x0, x1, w, b = rnd(B * H * W, c0, seed=1), rnd(B * H * W, c1, seed=2), rnd(n, 1, c0 + c1, seed=3, scale=0.1), rnd(n, seed=4)
+    out = torch.empty(B * H * W, n, dtype=F16, device=DEV)
+    ops.conv_gemm(x0.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, in_h=H, in_w=W, c0=c0, n=n, a1=x1.to(DEV), c1=c1,
+                  bias=b.to(DEV), epi=ops.EPI_SILU)
+    close(out, so.conv_ref(torch.cat([x0, x1], -1), w, batch=B, h=H, w_=W, bias=b, silu=True))
+
+
+def test_geglu_epilogue(ops):
+    from coma_amd.sd.weights import geglu_interleave
+    rows, k, inner = 200, 320, 1280                      # proj: k -> 2*inner
+    x, w, b = rnd(rows, k, seed=1), rnd(2 * inner, k, seed=2, scale=k**-0.5), rnd(2 * inner, seed=3)
+    wi, bi = geglu_interleave(w, b)
+    out = torch.empty(rows, inner, dtype=F16, device=DEV)
+    ops.linear(x.to(DEV), wi.to(DEV), out, rows=rows, k=k, n=2 * inner, bias=bi.to(DEV), epi=ops.EPI_GEGLU)
+    close(out, so.geglu_ref(x, w, b))
+
+
+def test_batched_weight_as_a_operand_gives_v_transposed(ops):
+    """V^T[b] = Wv . X_b^T : A = weight (shared), W operand = per-batch activations, bias per row."""
+    B, L, C = 3, 200, 320
+    x, wv, b = rnd(B, L, C, seed=1), rnd(C, C, seed=2, scale=C**-0.5), rnd(C, seed=3)
+    ldv = 208
+    out = torch.zeros(B, C, ldv, dtype=F16, device=DEV)
+    ops.conv_gemm(wv.to(DEV), x.to(DEV), out, batch=C, in_h=1, in_w=1, c0=C, n=L, bias=b.to(DEV), epi=ops.EPI_BIAS_ROWS,
+                  ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv)
+    ref = torch.einsum("ck,blk->bcl", wv.float(), x.float()) + b.float()[None, :, None]
+    close(out[:, :, :L], ref)
+    assert float(out[:, :, L:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 256, True), (640, 320, 64, True), (1280, 640, 100, True), (128, 0, 300, False)])
+def test_groupnorm_two_sources(ops, c0, c1, hw, silu):
+    B = 2
+    x0, x1 = rnd(B * hw, c0, seed=1) + 0.5, (rnd(B * hw, c1, seed=2, scale=2.0) if c1 else None)
+    ga, be = rnd(c0 + c1, seed=3) * 0.2 + 1, rnd(c0 + c1, seed=4) * 0.2
+    out = torch.empty(B * hw, c0 + c1, dtype=F16, device=DEV)
+    stats = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+    ops.groupnorm(x0.to(DEV), ga.to(DEV), be.to(DEV), out, stats, batch=B, hw=hw, c0=c0, x1=x1.to(DEV) if c1 else None, c1=c1,
+                  eps=1e-5, silu=silu)
+    xc = torch.cat([x0, x1], -1) if c1 else x0
+    close(out, so.groupnorm_ref(xc, ga, be, batch=B, hw=hw, eps=1e-5, silu=silu))
+
+
+@pytest.mark.parametrize("c", [320, 640, 1280])
+def test_layernorm(ops, c):
+    rows = 77
+    x, ga, be = rnd(rows, c, seed=1) * 2 + 0.3, rnd(c, seed=2) * 0.1 + 1, rnd(c, seed=3) * 0.1
+    out = torch.empty(rows, c, dtype=F16, device=DEV)
+    ops.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), out, rows=rows, c=c)
+    close(out, torch.nn.functional.layer_norm(x.float(), (c,), ga.float(), be.float(), 1e-5))
+
+
+@pytest.mark.parametrize("heads,d,lq,lk", [(8, 40, 200, 200), (8, 40, 256, 77), (8, 80, 130, 130), (8, 160, 64, 64),
+                                           (2, 64, 33, 500), (8, 160, 70, 77)])
+def test_attention(ops, heads, d, lq, lk):
+    B, C = 2, heads * d
+    q, k, v = rnd(B, lq, C, seed=1), rnd(B, lk, C, seed=2), rnd(B, lk, C, seed=3)
+    ldv = (lk + 7) // 8 * 8
+    vt = torch.zeros(B, C, ldv, dtype=F16)
+    vt[:, :, :lk] = v.transpose(1, 2)
+    out = torch.empty(B, lq, C, dtype=F16, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), out, batch=B, heads=heads, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=ldv, ldo=C,
+                  scale=d**-0.5)
+    close(out, so.attention_ref(q, k, v, heads, d**-0.5), tol=4e-3)
+
+
+def test_attention_peaked_scores_force_the_rescale_path(ops):
+    """One key dominates from the 3rd key tile on: exercises the online-softmax rescale with a large max jump."""
+    B, heads, d, L = 1, 1, 64, 256
+    q, k, v = rnd(B, L, d, seed=1), rnd(B, L, d, seed=2), rnd(B, L, d, seed=3)
+    k[0, 150] = q[0, 7] * 6.0
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.empty(B, L, d, dtype=F16, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), out, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=d, ldk=d, ldv=L, ldo=d,
+                  scale=d**-0.5)
+    close(out, so.attention_ref(q, k, v, heads, d**-0.5), tol=4e-3)
+
+
+def test_softmax_rows(ops):
+    rows, n = 37, 1000
+    x = rnd(rows, n, seed=1) * 3
+    xd = x.to(DEV).clone()
+    ops.softmax_(xd, rows=rows, n=n, ld=n, scale=0.7)
+    close(xd, torch.softmax(x.float() * 0.7, -1), tol=2e-3)
+
+
+def test_timestep_embedding(ops):
+    t = torch.tensor([961.0, 1.0, 500.0])
+    out = torch.empty(3, 320, dtype=F16, device=DEV)
+    ops.timestep_embedding(t.to(DEV), out, batch=3, dim=320)
+    assert float((out.float().cpu() - so.timestep_embedding_ref(t, 320)).abs().max()) <= 2e-3
+
+
+def test_cfg_ddim_step_closed_form(ops):
+    B, hw = 2, 64
+    alphas = so.ddim_alphas()
+    ts = so.ddim_timesteps(50)
+    assert ts[0] == 981 and ts[1] == 961 and ts[-1] == 1          # leading spacing, steps_offset=1
+    t = ts[1]
+    eps = rnd(2 * B, hw, 64, seed=1)
+    x = torch.randn(B, hw, 4, generator=torch.Generator().manual_seed(2))
+    mask, masked = (torch.rand(B, hw) > 0.5).to(F16), rnd(B, hw, 4, seed=3)
+    lat, x0 = x.to(DEV).clone(), torch.empty(B, hw, 4, device=DEV)
+    uin = torch.full((2 * B, hw, 32), 7.0, dtype=F16, device=DEV)
+    a_t, a_p = float(alphas[t]), float(alphas[t - 20])
+    ops.cfg_ddim_step(eps.to(DEV), 64, lat, x0, mask.to(DEV), masked.to(DEV), uin, batch=B, hw=hw, guidance=11.0,
+                      alpha_t=a_t, alpha_prev=a_p)
+    e = eps.float()[:B, :, :4] + 11.0 * (eps.float()[B:, :, :4] - eps.float()[:B, :, :4])
+    prev, x0r = so.ddim_step_ref(e, t, x, alphas)
+    assert float((lat.cpu() - prev.float()).abs().max()) <= 1e-4 * float(prev.abs().max())
+    assert float((x0.cpu() - x0r.float()).abs().max()) <= 1e-4 * float(x0r.abs().max())
+    u = uin.float().cpu()
+    assert torch.equal(u[:B], u[B:])
+    assert float((u[:B, :, :4] - lat.cpu()).abs().max()) <= 2e-3 * float(lat.abs().max())
+    assert torch.equal(u[:B, :, 4], mask.float()) and torch.equal(u[:B, :, 5:9], masked.float())
+    assert float(u[:, :, 9:].abs().max()) == 0.0
+
+
+def test_layout_conversions_and_u8(ops):
+    B, c, hw = 2, 9, 48
+    x = torch.randn(B, c, hw, generator=torch.Generator().manual_seed(0))
+    out = torch.empty(B, hw, 32, dtype=F16, device=DEV)
+    ops.nchw_to_nhwc(x.to(DEV), out, batch=B, c=c, hw=hw, cpad=32)
+    assert torch.equal(out.cpu()[:, :, :c], x.permute(0, 2, 1).to(F16)) and float(out[:, :, c:].abs().max()) == 0
+    back = torch.empty(B, c, hw, device=DEV)
+    ops.nhwc_to_nchw(out, back, batch=B, c=c, hw=hw, ld=32)
+    assert torch.equal(back.cpu(), x.to(F16).float())
+    img = (torch.rand(B, hw, 64, generator=torch.Generator().manual_seed(1)) * 2.4 - 1.2).to(F16)
+    for mode in (0, 1):
+        u8 = torch.empty(B, hw, 3, dtype=torch.uint8, device=DEV)
+        ops.image_to_u8(img.to(DEV), u8, batch=B, hw=hw, ld=64, round_mode=mode)
+        v = (img.float()[:, :, :3] * 0.5 + 0.5).clamp(0, 1) * 255
+        ref = (v.round() if mode else v.floor()).to(torch.uint8)
+        assert torch.equal(u8.cpu(), ref)
