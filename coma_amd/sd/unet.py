@@ -1,0 +1,232 @@
+"""SD-1.5-inpainting UNet on MI355X: the module the reference pipeline calls as
+``self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=None,
+return_dict=False)[0]`` (utils/adaptive_mask_inpainting.py:1001-1007), rebuilt as a static launch graph of
+hand-written gfx950 kernels (coma_amd/csrc/sd_*.hip) over NHWC fp16 buffers.
+
+Graph (public SD-1.5 architecture; diffusers itself is third party):
+conv_in -> 3 x [Res, Transformer] x2 + Down -> [Res x2] -> mid [Res, Transformer, Res] -> up blocks with skip
+concatenation -> GroupNorm/SiLU -> conv_out.  Fusions done here, none of which changes results beyond fp16 rounding:
+  * torch.cat of skip connections is never materialised (two-source GroupNorm / conv / shortcut GEMM);
+  * time-embedding projections of all 22 ResNet blocks are ONE GEMM; SiLU(temb) is the epilogue of linear_2;
+  * time-embedding bias, conv bias and the residual add are conv epilogues; GEGLU is the epilogue of ff.net.0;
+  * Q and K projections are one GEMM; V is produced transposed by swapping the GEMM operands (what the
+    attention kernel wants), so there is no transpose or head-split copy anywhere;
+  * nearest-x2 upsampling and stride-2 downsampling are index arithmetic inside the conv's operand gather;
+  * cross-attention K/V of the text context are computed once per prompt, not once per step.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .graph import F16, LaunchGraph
+from .weights import UNET_CFG, conv_weight, geglu_interleave, pad_vec
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class HipUNet2DConditionModel:
+    def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True):
+        self.cfgd = cfg
+        self.config = _Cfg(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"], sample_size=height)
+        self.device = torch.device(device)
+        self.batch, self.H, self.W, self.ctx_len = batch, height, width, ctx_len
+        self.heads = cfg["heads"]
+        self.ctx_dim = cfg["cross_attention_dim"]
+        self.use_graph = use_graph
+        self.dtype = F16
+        self.s = {k: v.to(self.device, F16) for k, v in state.items()}
+        self.g = LaunchGraph(self.device)        # per-step graph
+        self.gc = LaunchGraph(self.device)       # per-prompt graph (cross-attention K / V^T of the text context)
+        B, HW = batch, height * width
+        # static inputs / outputs
+        self.x_in = self.g.buf(B, HW, 32, zero=True)              # 9 valid channels (latents|mask|masked latents)
+        self.timesteps = self.g.buf(B, dtype=torch.float32, zero=True)
+        self.ctx = self.g.buf(B, ctx_len, self.ctx_dim, zero=True)
+        self.eps = None
+        self._build()
+        self._captured = False
+
+    # ------------------------------------------------------------------ graph construction
+    def _build(self):
+        g, s, B = self.g, self.s, self.batch
+        ch = self.cfgd["block_out_channels"]
+        temb_dim = 4 * ch[0]
+        # --- time embedding: sinusoid -> linear_1 + SiLU -> linear_2 (+ SiLU, the only way temb is consumed)
+        t_sin = g.buf(B, ch[0])
+        g.add(lambda: ops.timestep_embedding(self.timesteps, t_sin, batch=B, dim=ch[0]))
+        t1 = g.buf(B, temb_dim)
+        g.conv(t_sin, s["time_embedding.linear_1.weight"], t1, batch=B, in_h=1, in_w=1, c0=ch[0], n=temb_dim,
+               bias=s["time_embedding.linear_1.bias"], epi=ops.EPI_SILU)
+        semb = g.buf(B, temb_dim)
+        g.conv(t1, s["time_embedding.linear_2.weight"], semb, batch=B, in_h=1, in_w=1, c0=temb_dim, n=temb_dim,
+               bias=s["time_embedding.linear_2.bias"], epi=ops.EPI_SILU)
+        # --- all ResNet time projections in one GEMM
+        pref = sorted(k[:-len(".time_emb_proj.weight")] for k in s if k.endswith(".time_emb_proj.weight"))
+        self._tb_off, off = {}, 0
+        for p in pref:
+            self._tb_off[p] = off
+            off += s[p + ".time_emb_proj.weight"].shape[0]
+        self._tb_ld = off
+        w_all = torch.cat([s[p + ".time_emb_proj.weight"] for p in pref]).contiguous()
+        b_all = torch.cat([s[p + ".time_emb_proj.bias"] for p in pref]).contiguous()
+        self._tb = g.buf(B, off)
+        g.conv(semb, w_all, self._tb, batch=B, in_h=1, in_w=1, c0=temb_dim, n=off, bias=b_all)
+
+        # --- conv_in (9 -> 32 padded input channels)
+        H, W = self.H, self.W
+        w_in = conv_weight(s["conv_in.weight"], cin_pad=32)
+        h = g.buf(B * H * W, ch[0])
+        g.conv(self.x_in, w_in, h, batch=B, in_h=H, in_w=W, c0=32, n=ch[0], taps=9, bias=s["conv_in.bias"])
+        skips = [(h, ch[0], H, W)]
+        cin = ch[0]
+        for i, cout in enumerate(ch):
+            for j in range(self.cfgd["layers_per_block"]):
+                h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, cin, None, 0, cout, H, W)
+                if self.cfgd["down_has_attn"][i]:
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cout, H, W)
+                cin = cout
+                skips.append((h, cout, H, W))
+            if i < len(ch) - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                o = g.buf(B * (H // 2) * (W // 2), cout)
+                g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=H // 2, out_w=W // 2, c0=cout,
+                       n=cout, taps=9, stride=2, bias=s[p + ".bias"])
+                h, H, W = o, H // 2, W // 2
+                skips.append((h, cout, H, W))
+        h = self._resnet("mid_block.resnets.0", h, cin, None, 0, cin, H, W)
+        h = self._transformer("mid_block.attentions.0", h, cin, H, W)
+        h = self._resnet("mid_block.resnets.1", h, cin, None, 0, cin, H, W)
+        for i, cout in enumerate(reversed(ch)):
+            for j in range(self.cfgd["layers_per_block"] + 1):
+                sk, sc, sh, sw = skips.pop()
+                assert (sh, sw) == (H, W)
+                h = self._resnet(f"up_blocks.{i}.resnets.{j}", h, cin, sk, sc, cout, H, W)
+                if self.cfgd["up_has_attn"][i]:
+                    h = self._transformer(f"up_blocks.{i}.attentions.{j}", h, cout, H, W)
+                cin = cout
+            if i < len(ch) - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                o = g.buf(B * 4 * H * W, cout)
+                g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout,
+                       n=cout, taps=9, upsample=1, bias=s[p + ".bias"])
+                h, H, W = o, 2 * H, 2 * W
+        gn = g.buf(B * H * W, cin)
+        g.groupnorm(h, s["conv_norm_out.weight"], s["conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin, eps=1e-5, silu=True)
+        self.eps = g.buf(B * H * W, 64, zero=True)                # 4 valid output channels
+        g.conv(gn, conv_weight(s["conv_out.weight"], cout_pad=64), self.eps, batch=B, in_h=H, in_w=W, c0=cin, n=64, taps=9,
+               bias=pad_vec(s["conv_out.bias"], 64))
+
+    def _resnet(self, p, x0, c0, x1, c1, cout, H, W):
+        g, s, B = self.g, self.s, self.batch
+        M, cin = B * H * W, c0 + c1
+        n1 = g.buf(M, cin)
+        g.groupnorm(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=c0, x1=x1, c1=c1, eps=1e-5,
+                    silu=True)
+        h = g.buf(M, cout)
+        off = self._tb_off[p]
+        g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
+               bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld)
+        n2 = g.buf(M, cout)
+        g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
+        if p + ".conv_shortcut.weight" in s:
+            sc = g.buf(M, cout)
+            g.conv(x0, conv_weight(s[p + ".conv_shortcut.weight"]), sc, batch=B, in_h=H, in_w=W, c0=c0, n=cout, a1=x1, c1=c1,
+                   bias=s[p + ".conv_shortcut.bias"])
+        else:
+            assert x1 is None and c0 == cout
+            sc = x0
+        out = g.buf(M, cout)
+        g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
+               bias=s[p + ".conv2.bias"], res=sc)
+        return out
+
+    def _transformer(self, p, x, C, H, W):
+        g, s, B, heads = self.g, self.s, self.batch, self.heads
+        L, M, d = H * W, B * H * W, C // heads
+        t = p + ".transformer_blocks.0"
+        gn = g.buf(M, C)
+        g.groupnorm(x, s[p + ".norm.weight"], s[p + ".norm.bias"], gn, batch=B, hw=L, c0=C, eps=1e-6, silu=False)
+        h = g.buf(M, C)
+        g.conv(gn, conv_weight(s[p + ".proj_in.weight"]), h, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".proj_in.bias"])
+        # ---- self attention
+        n1 = g.buf(M, C)
+        g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
+        wqk = torch.cat([s[t + ".attn1.to_q.weight"], s[t + ".attn1.to_k.weight"]]).contiguous()
+        qk = g.buf(M, 2 * C)
+        g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
+        ldv = (L + 7) // 8 * 8
+        vt = g.buf(B, C, ldv, zero=True)
+        g.conv(s[t + ".attn1.to_v.weight"], n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C,
+               stride_out=C * ldv)
+        a = g.buf(M, C)
+        g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C)
+        h1 = g.buf(M, C)
+        g.conv(a, s[t + ".attn1.to_out.0.weight"], h1, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[t + ".attn1.to_out.0.bias"],
+               res=h)
+        # ---- cross attention (K, V^T of the context live in the per-prompt graph)
+        n2 = g.buf(M, C)
+        g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)
+        q2 = g.buf(M, C)
+        g.conv(n2, s[t + ".attn2.to_q.weight"], q2, batch=M, in_h=1, in_w=1, c0=C, n=C)
+        Lk, cd = self.ctx_len, self.ctx_dim
+        k2 = self.gc.buf(B * Lk, C)
+        self.gc.conv(self.ctx, s[t + ".attn2.to_k.weight"], k2, batch=B * Lk, in_h=1, in_w=1, c0=cd, n=C)
+        ldv2 = (Lk + 7) // 8 * 8
+        vt2 = self.gc.buf(B, C, ldv2, zero=True)
+        self.gc.conv(s[t + ".attn2.to_v.weight"], self.ctx, vt2, batch=C, in_h=1, in_w=1, c0=cd, n=Lk, ldo=ldv2, nbatch_z=B,
+                     stride_w=Lk * cd, stride_out=C * ldv2)
+        a2 = g.buf(M, C)
+        g.attention(q2, k2, vt2, a2, batch=B, heads=heads, lq=L, lk=Lk, d=d, ldq=C, ldk=C, ldv=ldv2, ldo=C)
+        h2 = g.buf(M, C)
+        g.conv(a2, s[t + ".attn2.to_out.0.weight"], h2, batch=M, in_h=1, in_w=1, c0=C, n=C,
+               bias=s[t + ".attn2.to_out.0.bias"], res=h1)
+        # ---- feed-forward (GEGLU)
+        n3 = g.buf(M, C)
+        g.layernorm(h2, s[t + ".norm3.weight"], s[t + ".norm3.bias"], n3, rows=M, c=C)
+        wff, bff = geglu_interleave(s[t + ".ff.net.0.proj.weight"], s[t + ".ff.net.0.proj.bias"])
+        f = g.buf(M, 4 * C)
+        g.conv(n3, wff, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=bff, epi=ops.EPI_GEGLU)
+        h3 = g.buf(M, C)
+        g.conv(f, s[t + ".ff.net.2.weight"], h3, batch=M, in_h=1, in_w=1, c0=4 * C, n=C, bias=s[t + ".ff.net.2.bias"], res=h2)
+        out = g.buf(M, C)
+        g.conv(h3, conv_weight(s[p + ".proj_out.weight"]), out, batch=M, in_h=1, in_w=1, c0=C, n=C,
+               bias=s[p + ".proj_out.bias"], res=x)
+        return out
+
+    # ------------------------------------------------------------------ execution
+    def set_context(self, encoder_hidden_states):
+        """[batch, ctx_len, 768]; recomputes the cross-attention K / V^T of every transformer block."""
+        self.ctx.copy_(encoder_hidden_states.to(self.device, F16).reshape(self.ctx.shape))
+        self.gc.run()
+
+    def forward_static(self):
+        """x_in / timesteps already written into the static buffers; result lands in self.eps ([B*HW, 64])."""
+        if self.use_graph:
+            if not self._captured:
+                self.g.capture()
+                self._captured = True
+            self.g.replay()
+        else:
+            self.g.run()
+        return self.eps
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, return_dict=False, **kw):
+        """diffusers-compatible call: sample NCHW [batch, 9, H, W] -> (noise_pred NCHW [batch, 4, H, W],)."""
+        B, HW = self.batch, self.H * self.W
+        assert tuple(sample.shape) == (B, self.config.in_channels, self.H, self.W), sample.shape
+        if encoder_hidden_states is not None:
+            self.set_context(encoder_hidden_states)
+        x = sample.to(self.device, torch.float32).contiguous()
+        ops.nchw_to_nhwc(x, self.x_in, batch=B, c=self.config.in_channels, hw=HW, cpad=32)
+        t = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
+        self.timesteps.copy_(t.expand(B) if t.numel() == 1 else t)
+        self.forward_static()
+        out = torch.empty(B, self.config.out_channels, self.H, self.W, dtype=torch.float32, device=self.device)
+        ops.nhwc_to_nchw(self.eps, out, batch=B, c=self.config.out_channels, hw=HW, ld=64)
+        out = out.to(sample.dtype) if sample.dtype in (torch.float16, torch.float32) else out
+        if return_dict:
+            return _Cfg(sample=out)
+        return (out,)

@@ -97,3 +97,84 @@ def ddim_step_ref(eps, t, x, alphas, num_inference_steps=50, num_train=1000):
     x0 = (x.double() - (1 - a_t).sqrt() * eps.double()) / a_t.sqrt()
     prev = a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps.double()
     return prev, x0
+
+
+# ------------------------------------------------------------------ UNet2DConditionModel (fp32, NCHW, diffusers semantics)
+def _gn(x, s, p, eps, groups=32):
+    return F.group_norm(x, groups, s[p + ".weight"].float(), s[p + ".bias"].float(), eps)
+
+
+def _conv(x, s, p, stride=1, padding=1):
+    return F.conv2d(x, s[p + ".weight"].float(), s[p + ".bias"].float(), stride=stride, padding=padding)
+
+
+def _lin(x, s, p, bias=True):
+    return F.linear(x, s[p + ".weight"].float(), s[p + ".bias"].float() if bias else None)
+
+
+def resnet_ref(x, semb, s, p, eps=1e-5):
+    h = _conv(F.silu(_gn(x, s, p + ".norm1", eps)), s, p + ".conv1")
+    if semb is not None:
+        h = h + _lin(semb, s, p + ".time_emb_proj")[:, :, None, None]
+    h = _conv(F.silu(_gn(h, s, p + ".norm2", eps)), s, p + ".conv2")
+    if p + ".conv_shortcut.weight" in s:
+        x = _conv(x, s, p + ".conv_shortcut", padding=0)
+    return x + h
+
+
+def _attn(xq, xkv, s, p, heads):
+    q = _lin(xq, s, p + ".to_q", bias=False)
+    k = _lin(xkv, s, p + ".to_k", bias=False)
+    v = _lin(xkv, s, p + ".to_v", bias=False)
+    d = q.shape[-1] // heads
+    return _lin(attention_ref(q, k, v, heads, d**-0.5), s, p + ".to_out.0")
+
+
+def transformer_ref(x, ctx, s, p, heads):
+    B, C, H, W = x.shape
+    h = _conv(_gn(x, s, p + ".norm", 1e-6), s, p + ".proj_in", padding=0)
+    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    t = p + ".transformer_blocks.0"
+    ln = lambda z, n: F.layer_norm(z, (C,), s[f"{t}.{n}.weight"].float(), s[f"{t}.{n}.bias"].float(), 1e-5)
+    n1 = ln(h, "norm1")
+    h = _attn(n1, n1, s, t + ".attn1", heads) + h
+    h = _attn(ln(h, "norm2"), ctx, s, t + ".attn2", heads) + h
+    y = _lin(ln(h, "norm3"), s, t + ".ff.net.0.proj")
+    a, gate = y.chunk(2, dim=-1)
+    h = _lin(a * F.gelu(gate), s, t + ".ff.net.2") + h
+    h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    return _conv(h, s, p + ".proj_out", padding=0) + x
+
+
+def unet_ref(state, sample, timesteps, ctx, cfg):
+    """sample [B,9,H,W], timesteps [B], ctx [B,77,768] -> noise prediction [B,4,H,W]; everything fp32."""
+    s = state
+    ch = cfg["block_out_channels"]
+    heads = cfg["heads"]
+    x = sample.float()
+    ctx = ctx.float()
+    emb = timestep_embedding_ref(timesteps, ch[0])
+    emb = _lin(F.silu(_lin(emb, s, "time_embedding.linear_1")), s, "time_embedding.linear_2")
+    semb = F.silu(emb)
+    h = _conv(x, s, "conv_in")
+    skips = [h]
+    for i in range(len(ch)):
+        for j in range(cfg["layers_per_block"]):
+            h = resnet_ref(h, semb, s, f"down_blocks.{i}.resnets.{j}")
+            if cfg["down_has_attn"][i]:
+                h = transformer_ref(h, ctx, s, f"down_blocks.{i}.attentions.{j}", heads)
+            skips.append(h)
+        if i < len(ch) - 1:
+            h = _conv(h, s, f"down_blocks.{i}.downsamplers.0.conv", stride=2)
+            skips.append(h)
+    h = resnet_ref(h, semb, s, "mid_block.resnets.0")
+    h = transformer_ref(h, ctx, s, "mid_block.attentions.0", heads)
+    h = resnet_ref(h, semb, s, "mid_block.resnets.1")
+    for i in range(len(ch)):
+        for j in range(cfg["layers_per_block"] + 1):
+            h = resnet_ref(torch.cat([h, skips.pop()], dim=1), semb, s, f"up_blocks.{i}.resnets.{j}")
+            if cfg["up_has_attn"][i]:
+                h = transformer_ref(h, ctx, s, f"up_blocks.{i}.attentions.{j}", heads)
+        if i < len(ch) - 1:
+            h = _conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), s, f"up_blocks.{i}.upsamplers.0.conv")
+    return _conv(F.silu(_gn(h, s, "conv_norm_out", 1e-5)), s, "conv_out")

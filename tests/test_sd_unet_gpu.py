@@ -1,0 +1,58 @@
+"""GPU: the whole UNet launch graph against the torch fp32 reference of the same architecture and the same seeded
+random weights (oracle/sd_oracle.py: unet_ref).  Full SD-1.5-inpainting widths (320/640/1280/1280, 8 heads, 77x768
+context); the latent is 16x16 so that the fp32 reference finishes in seconds on the host (every layer is
+resolution-agnostic; the 64x64 case is covered by properties in test_sd_pipeline_gpu.py).
+Tolerance: the graph stores every activation in fp16 through ~60 layers -> relative L2 error <= 2e-2 and
+cosine similarity >= 0.999 against the fp32 reference (an fp16 torch run of the same graph lands at ~5e-3)."""
+import pytest
+import torch
+
+from oracle import sd_oracle as so
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def setup(hip_lib):
+    from coma_amd.sd import weights
+    from coma_amd.sd.unet import HipUNet2DConditionModel
+    state = weights.random_state(weights.unet_shapes(), seed=0)
+    B, H = 2, 16
+    g = torch.Generator().manual_seed(1)
+    sample = torch.randn(B, 9, H, H, generator=g).half().float()
+    ctx = torch.randn(B, 77, 768, generator=g).half().float()
+    t = torch.tensor([961.0, 961.0])
+    ref = so.unet_ref(state, sample, t, ctx, weights.UNET_CFG)
+    return state, sample, ctx, t, ref, HipUNet2DConditionModel
+
+
+def _metrics(out, ref):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    rel = float((out - ref).norm() / ref.norm())
+    cos = float(torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0))
+    return rel, cos
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_unet_matches_fp32_reference(setup, use_graph):
+    state, sample, ctx, t, ref, UNet = setup
+    unet = UNet(state, batch=2, height=16, width=16, device=DEV, use_graph=use_graph)
+    out = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
+    assert tuple(out.shape) == (2, 4, 16, 16)
+    rel, cos = _metrics(out, ref)
+    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    out2 = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
+    assert torch.equal(out, out2), "graph replay must be bitwise reproducible"
+
+
+def test_unet_responds_to_timestep_and_context(setup):
+    state, sample, ctx, t, ref, UNet = setup
+    unet = UNet(state, batch=2, height=16, width=16, device=DEV, use_graph=True)
+    a = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))[0].clone()
+    b = unet(sample.to(DEV), torch.tensor([1.0, 1.0]).to(DEV), encoder_hidden_states=ctx.to(DEV))[0].clone()
+    c = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=(ctx * 0.5).to(DEV))[0].clone()
+    assert not torch.equal(a, b) and not torch.equal(a, c)
+    ref_b = so.unet_ref(state, sample, torch.tensor([1.0, 1.0]), ctx, __import__("coma_amd.sd.weights", fromlist=["x"]).UNET_CFG)
+    rel, cos = _metrics(b, ref_b)
+    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
