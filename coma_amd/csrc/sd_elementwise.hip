@@ -35,20 +35,20 @@ __global__ void cfg_ddim_kernel(const _Float16* __restrict__ eps_uc, int eps_ld,
     x[c] = xt;
   }
   if (unet_in) {
-    // channels: latents(4) | mask(1) | masked_image_latents(4) | zero pad to 32; identical for the two CFG halves
-    _Float16 v[32];
+    // channels: latents(4) | mask(1) | masked_image_latents(4) | zero pad to 64; identical for the two CFG halves
+    _Float16 v[64];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) v[c] = (_Float16)0.0f;
+    for (int c = 0; c < 64; ++c) v[c] = (_Float16)0.0f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] = (_Float16)x[c];
     v[4] = mask[i];
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[5 + c] = masked[i * 4 + c];
-    uint4* o0 = reinterpret_cast<uint4*>(unet_in + i * 32);
-    uint4* o1 = reinterpret_cast<uint4*>(unet_in + (i + (long long)batch * hw) * 32);
+    uint4* o0 = reinterpret_cast<uint4*>(unet_in + i * 64);
+    uint4* o1 = reinterpret_cast<uint4*>(unet_in + (i + (long long)batch * hw) * 64);
     const uint4* src = reinterpret_cast<const uint4*>(v);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 8; ++q) {
       o0[q] = src[q];
       o1[q] = src[q];
     }

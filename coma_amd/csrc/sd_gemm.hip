@@ -18,6 +18,8 @@
 // residual add, SiLU, and GEGLU (value/gate columns interleaved per wave at weight-prep time).
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/sd_hip.h"
 
@@ -31,8 +33,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 8;   // halves; 80-byte rows
+constexpr int BK = 64;
 
 struct GemmArgs {
   const _Float16* a0;
@@ -51,18 +52,44 @@ struct GemmArgs {
   _Float16* out;
   int ldo;
   int epi;
-  long long sa, sw, so, sr;   // per-blockIdx.z strides in elements
+  int ksplit;                 // >1: blockIdx.z selects a K range and fp32 partials go to `partial`
+  float* partial;             // [ksplit][M][N] fp32
+  long long sa, sw, so, sr;   // per-blockIdx.z strides in elements (batched mode, ksplit == 1)
 };
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// Shared epilogue math: v = acc (+bias)(+per-batch bias) -> SiLU -> (+residual)
+__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int row, int col, const _Float16* resp) {
+  if (g.bias) v += (float)g.bias[(g.epi & SD_EPI_BIAS_ROWS) ? row : col];
+  if (g.bias_bn) v += (float)g.bias_bn[(long long)(row / g.rows_per_batch) * g.ldbb + col];
+  if (g.epi & SD_EPI_SILU) v = silu(v);
+  if (resp) v += (float)resp[(long long)row * g.ldr + col];
+  return v;
+}
+
+// 128 bytes of zeros: the source of every out-of-image (zero padding) or out-of-range row of a tile
+__device__ __attribute__((aligned(128))) uint4 g_zero_page[8];
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS tile image: [rows][64 halves = 8 x 16 B], unpadded 128-byte rows filled by LDS-DMA (global_load_lds), so a
+// wave instruction writes 8 rows x 128 B lane-linearly.  Bank conflicts are removed by an XOR swizzle applied on the
+// SOURCE side: 16-byte slot p of row r holds K-chunk p ^ ((r >> 1) & 7).  A 256-byte bank row spans two tile rows,
+// so (r & 1, (r >> 1) & 7) enumerates the 16 slots and the 16 rows read by one ds_read_b128 lane group land on 16
+// distinct slots (conflict-free), for both the A and the W fragments.
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
 template <int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs g) {
-  constexpr int WN = BN / 64;          // MFMA n-tiles per wave
-  constexpr int B_ITEMS = BN * 4 / 256;  // 16-byte chunks of the W tile per thread
-  __shared__ __attribute__((aligned(16))) _Float16 As[2][BM * LDS_STRIDE];
-  __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BN * LDS_STRIDE];
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
+  constexpr int WN = BN / 64;                  // MFMA n-tiles per wave
+  constexpr int A_LD = BM / 32;                // glds instructions per wave for the A tile (8 rows each) = 4
+  constexpr int B_LD = BN / 32;
+  __shared__ __attribute__((aligned(1024))) _Float16 lds[2 * (BM + BN) * BK];
+  _Float16* const As0 = lds;
+  _Float16* const Bs0 = lds + 2 * BM * BK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,79 +97,87 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs g) {
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const long long z = blockIdx.z;
+  const bool split = g.ksplit > 1;
+  const long long z = split ? 0 : blockIdx.z;
   const _Float16* a0 = g.a0 + z * g.sa;
-  const _Float16* a1 = g.a1;
   const _Float16* wp = g.w + z * g.sw;
   const int ctot = g.c0 + g.c1;
-  const int pad = g.pad;
+  const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
+
+  // K range of this block (split-K) in units of BK tiles
+  const int nk_all = g.K / BK;
+  int kt0 = 0, nk = nk_all;
+  if (split) {
+    const int per = (nk_all + g.ksplit - 1) / g.ksplit;
+    kt0 = blockIdx.z * per;
+    nk = min(per, nk_all - kt0);
+    if (nk < 0) nk = 0;
+  }
+
+  // DMA role of this lane: instruction j of this wave covers tile rows (wave*A_LD + j)*8 .. +7; lane -> row +lane/8,
+  // LDS slot lane%8, which must receive K-chunk slot ^ swizzle(row)
+  const int l_row = lane >> 3, l_slot = lane & 7;
+  int a_n[A_LD], a_y[A_LD], a_x[A_LD], a_koff[A_LD];
+  bool a_ok[A_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    const int r = (wave * A_LD + j) * 8 + l_row;
+    a_koff[j] = swz(r, l_slot) * 8;
+    const int m = m0 + r;
+    a_ok[j] = m < g.M;
+    const int mm = a_ok[j] ? m : 0;
+    a_n[j] = mm / g.rows_per_batch;
+    const int rem = mm - a_n[j] * g.rows_per_batch;
+    const int oy = rem / g.out_w;
+    a_y[j] = oy * g.stride - g.pad;
+    a_x[j] = (rem - oy * g.out_w) * g.stride - g.pad;
+  }
+  const _Float16* b_ptr[B_LD];     // row pointer + swizzled chunk offset (or the zero page)
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int r = (wave * B_LD + j) * 8 + l_row;
+    const int n = n0 + r;
+    b_ptr[j] = n < g.N ? wp + (long long)n * g.K + swz(r, l_slot) * 8 : nullptr;
+  }
   const int lim_h = g.upsample ? 2 * g.in_h : g.in_h;
   const int lim_w = g.upsample ? 2 * g.in_w : g.in_w;
 
-  // A-tile staging role: two (row, 16-byte chunk) items per thread
-  int a_row[2], a_chunk[2], a_n[2], a_y[2], a_x[2];
-  bool a_ok[2];
+  // running position of the NEXT tile to load: tap index and channel offset inside the concatenation
+  int ld_tap = (kt0 * BK) / ctot;
+  int ld_ci = kt0 * BK - ld_tap * ctot;
+  long long a_off[A_LD];      // pixel index (n, iy, ix) of this lane's row for the current tap, or -1
+  auto retap = [&]() {
+    const int ky = g.taps == 9 ? ld_tap / 3 : 0;
+    const int kx = g.taps == 9 ? ld_tap - ky * 3 : 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int item = tid + i * 256;
-    a_row[i] = item >> 2;
-    a_chunk[i] = item & 3;
-    int m = m0 + a_row[i];
-    a_ok[i] = m < g.M;
-    int mm = a_ok[i] ? m : 0;
-    a_n[i] = mm / g.rows_per_batch;
-    int rem = mm - a_n[i] * g.rows_per_batch;
-    a_y[i] = rem / g.out_w;
-    a_x[i] = rem - a_y[i] * g.out_w;
-  }
-  int b_row[B_ITEMS], b_chunk[B_ITEMS];
-#pragma unroll
-  for (int i = 0; i < B_ITEMS; ++i) {
-    int item = tid + i * 256;
-    b_row[i] = item >> 2;
-    b_chunk[i] = item & 3;
-  }
-
-  uint4 ra[2], rb[B_ITEMS];
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / ctot;
-    int ci = k0 - tap * ctot;
-    const _Float16* src = a0;
-    int csrc = g.c0;
-    if (ci >= g.c0) { src = a1; csrc = g.c1; ci -= g.c0; }
-    const int ky = g.taps == 9 ? tap / 3 : 0;
-    const int kx = g.taps == 9 ? tap - ky * 3 : 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int iy = a_y[i] * g.stride + ky - pad;
-      int ix = a_x[i] * g.stride + kx - pad;
-      bool ok = a_ok[i] && iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w;
+    for (int j = 0; j < A_LD; ++j) {
+      int iy = a_y[j] + ky, ix = a_x[j] + kx;
+      const bool ok = a_ok[j] && iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w;
       if (g.upsample) { iy >>= 1; ix >>= 1; }
-      if (ok) {
-        const _Float16* p = src + (((long long)a_n[i] * g.in_h + iy) * g.in_w + ix) * csrc + ci + a_chunk[i] * 8;
-        ra[i] = *reinterpret_cast<const uint4*>(p);
-      } else {
-        ra[i] = make_uint4(0, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_ITEMS; ++i) {
-      int n = n0 + b_row[i];
-      if (n < g.N) {
-        rb[i] = *reinterpret_cast<const uint4*>(wp + (long long)n * g.K + k0 + b_chunk[i] * 8);
-      } else {
-        rb[i] = make_uint4(0, 0, 0, 0);
-      }
+      a_off[j] = ok ? ((long long)a_n[j] * g.in_h + iy) * g.in_w + ix : -1;
     }
   };
-  auto store_tile = [&](int buf) {
+  retap();
+
+  auto issue_tile = [&](int buf) {          // LDS-DMA of the tile at (ld_tap, ld_ci) into buffer `buf`; advances
+    const _Float16* src = a0;
+    int csrc = g.c0, ci = ld_ci;
+    if (ci >= g.c0) { src = g.a1; csrc = g.c1; ci -= g.c0; }
+    _Float16* ad = As0 + buf * (BM * BK) + wave * A_LD * 8 * BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<uint4*>(&As[buf][a_row[i] * LDS_STRIDE + a_chunk[i] * 8]) = ra[i];
+    for (int j = 0; j < A_LD; ++j) {
+      const _Float16* p = a_off[j] >= 0 ? src + a_off[j] * csrc + ci + a_koff[j] : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(ad + j * 8 * BK), 16, 0, 0);
+    }
+    const int k0 = ld_tap * ctot + ld_ci;
+    _Float16* bd = Bs0 + buf * (BN * BK) + wave * B_LD * 8 * BK;
 #pragma unroll
-    for (int i = 0; i < B_ITEMS; ++i)
-      *reinterpret_cast<uint4*>(&Bs[buf][b_row[i] * LDS_STRIDE + b_chunk[i] * 8]) = rb[i];
+    for (int j = 0; j < B_LD; ++j) {
+      const _Float16* p = b_ptr[j] ? b_ptr[j] + k0 : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(bd + j * 8 * BK), 16, 0, 0);
+    }
+    ld_ci += BK;
+    if (ld_ci >= ctot) { ld_ci = 0; ++ld_tap; retap(); }
   };
 
   float16v acc[2][WN];
@@ -153,41 +188,61 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk = g.K / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  const int frow = lane & 31;
-  const int fk = (lane >> 5) * 8;
+  // fragment addressing: row = base + (lane & 31), K-chunk = 2*ks + (lane >> 5), slot = chunk ^ swizzle(row)
+  const int frow = lane & 31, fhalf = lane >> 5;
+  int a_fr[2], b_fr[WN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a_fr[i] = wr * 64 + i * 32 + frow;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) b_fr[j] = wc * (BN / 2) + j * 32 + frow;
+
+  if (nk > 0) issue_tile(0);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    // the barrier's release carries vmcnt(0): tile kt has landed for every wave, and every wave is done reading
+    // the other buffer (it was consumed in iteration kt-1), so it can be refilled while tile kt is multiplied
+    __syncthreads();
+    if (kt + 1 < nk) issue_tile(cur ^ 1);
+    const _Float16* Ab = As0 + cur * (BM * BK);
+    const _Float16* Bb = Bs0 + cur * (BN * BK);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       half8 af[2], bf[WN];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const half8*>(&As[cur][(wr * 64 + i * 32 + frow) * LDS_STRIDE + ks * 16 + fk]);
+        af[i] = *reinterpret_cast<const half8*>(Ab + a_fr[i] * BK + swz(a_fr[i], 2 * ks + fhalf) * 8);
 #pragma unroll
       for (int j = 0; j < WN; ++j)
-        bf[j] = *reinterpret_cast<const half8*>(&Bs[cur][(wc * (BN / 2) + j * 32 + frow) * LDS_STRIDE + ks * 16 + fk]);
+        bf[j] = *reinterpret_cast<const half8*>(Bb + b_fr[j] * BK + swz(b_fr[j], 2 * ks + fhalf) * 8);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
-    __syncthreads();
   }
 
   // ---------------------------------------------------------------- epilogue
+  const int col_in_wave = lane & 31;
+  if (split) {
+    float* part = g.partial + (long long)blockIdx.z * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int col = n0 + wc * (BN / 2) + j * 32 + col_in_wave;
+          if (col < g.N) part[(long long)row * g.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
   _Float16* outp = g.out + z * g.so;
   const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
   const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
-  const bool act_silu = (g.epi & SD_EPI_SILU) != 0;
-  const bool bias_rows = (g.epi & SD_EPI_BIAS_ROWS) != 0;
-  const int col_in_wave = lane & 31;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -208,21 +263,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(GemmArgs g) {
         for (int j = 0; j < WN; ++j) {
           const int col = n0 + wc * (BN / 2) + j * 32 + col_in_wave;
           if (col >= g.N) continue;
-          float v = acc[i][j][r];
-          if (g.bias) v += (float)g.bias[bias_rows ? row : col];
-          if (g.bias_bn) v += (float)g.bias_bn[(long long)(row / g.rows_per_batch) * g.ldbb + col];
-          if (act_silu) v = silu(v);
-          if (resp) v += (float)resp[(long long)row * g.ldr + col];
-          outp[(long long)row * g.ldo + col] = (_Float16)v;
+          outp[(long long)row * g.ldo + col] = (_Float16)epilogue_value(g, acc[i][j][r], row, col, resp);
         }
       }
     }
   }
 }
 
+// sum the split-K slabs in a fixed order and apply the epilogue (8 columns per thread)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n8 = g.N / 8;
+  if (i >= (long long)g.M * n8) return;
+  const int row = (int)(i / n8), col0 = (int)(i - (long long)row * n8) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+  for (int s = 0; s < g.ksplit; ++s) {
+    const float4* p = reinterpret_cast<const float4*>(g.partial + ((long long)s * g.M + row) * g.N + col0);
+    float4 x = p[0], y = p[1];
+    v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+    v[4] += y.x; v[5] += y.y; v[6] += y.z; v[7] += y.w;
+  }
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)epilogue_value(g, v[j], row, col0 + j, g.res);
+  *reinterpret_cast<half8*>(g.out + (long long)row * g.ldo + col0) = o;
+}
+
 }  // namespace sd
 
 using namespace sd;
+
+extern "C" size_t sd_conv_gemm_workspace_bytes(void) { return (size_t)64 << 20; }
 
 extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (!d) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
@@ -254,13 +327,28 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   g.sa = d->stride_a; g.sw = d->stride_w; g.so = d->stride_out; g.sr = d->stride_res;
   if (geglu && (d->n % 128 != 0 || d->bias_bn || d->res))
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: GEGLU needs N %% 128 == 0 and no residual / batch bias");
-  const unsigned gx = (unsigned)((g.M + BM - 1) / BM);
-  if (d->n % 128 == 0 || d->n > 256) {
-    dim3 grid(gx, (unsigned)((d->n + 127) / 128), (unsigned)nz);
-    hipLaunchKernelGGL(conv_gemm_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, g);
-  } else {
-    dim3 grid(gx, (unsigned)((d->n + 63) / 64), (unsigned)nz);
-    hipLaunchKernelGGL(conv_gemm_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, g);
+  const bool wide = d->n % 128 == 0 || d->n > 256;
+  const int bn = wide ? 128 : 64;
+  const unsigned gx = (unsigned)((g.M + BM - 1) / BM), gy = (unsigned)((d->n + bn - 1) / bn);
+  // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 4 K tiles per split
+  g.ksplit = 1;
+  g.partial = (float*)d->workspace;
+  const long long blocks = (long long)gx * gy;
+  const int nk = g.K / BK;
+  if (nz == 1 && !geglu && d->workspace && blocks < 384 && nk >= 8 && d->n % 8 == 0 && g.ldo % 8 == 0) {
+    int s = (int)((512 + blocks - 1) / blocks);
+    if (s > nk / 4) s = nk / 4;
+    if (s > 16) s = 16;
+    while (s > 1 && (size_t)s * g.M * g.N * sizeof(float) > d->workspace_bytes) --s;
+    if (s > 1) g.ksplit = s;
+  }
+  dim3 grid(gx, gy, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
+  hipStream_t st = (hipStream_t)stream;
+  if (wide) hipLaunchKernelGGL(conv_gemm_kernel<128>, grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(conv_gemm_kernel<64>, grid, dim3(256), 0, st, g);
+  if (g.ksplit > 1) {
+    const long long n8 = (long long)g.M * (g.N / 8);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, g);
   }
   return check_launch("conv_gemm_kernel");
 }

@@ -17,9 +17,11 @@ class LaunchGraph:
     def __init__(self, device):
         self.device = torch.device(device)
         self.launches = []          # zero-argument closures
+        self.tags = []              # (description, flops) per launch, for profiling
         self.flops = 0              # algorithmic MFMA flops per run (2*M*N*K of every GEMM-shaped launch)
         self._graph = None
         self._gn_stats = None
+        self._ws = None             # split-K workspace shared by every GEMM of the graph (launches are serial)
 
     # ---- memory
     def buf(self, *shape, dtype=F16, zero=False):
@@ -32,38 +34,60 @@ class LaunchGraph:
         return self._gn_stats
 
     # ---- recording
-    def add(self, fn, flops=0):
+    def add(self, fn, flops=0, tag=""):
         self.launches.append(fn)
+        self.tags.append((tag, flops))
         self.flops += flops
 
     def conv(self, a0, w, out, *, batch, in_h, in_w, c0, n, out_h=None, out_w=None, a1=None, c1=0, taps=1, **kw):
         oh = out_h if out_h is not None else in_h
         ow = out_w if out_w is not None else in_w
         z = kw.get("nbatch_z", 1)
+        if self._ws is None:
+            self._ws = torch.empty(16 << 20, dtype=torch.float32, device=self.device)   # 64 MiB
+        kw.setdefault("workspace", self._ws)
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
                                        c1=c1, taps=taps, **kw),
-                 flops=2 * batch * oh * ow * n * taps * (c0 + c1) * z)
+                 flops=2 * batch * oh * ow * n * taps * (c0 + c1) * z,
+                 tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}")
         return out
 
     def groupnorm(self, x0, gamma, beta, out, *, batch, hw, c0, x1=None, c1=0, eps, silu):
         stats = self.gn_scratch(batch, hw)
-        self.add(lambda: ops.groupnorm(x0, gamma, beta, out, stats, batch=batch, hw=hw, c0=c0, x1=x1, c1=c1, eps=eps, silu=silu))
+        self.add(lambda: ops.groupnorm(x0, gamma, beta, out, stats, batch=batch, hw=hw, c0=c0, x1=x1, c1=c1, eps=eps, silu=silu),
+                 tag=f"groupnorm B={batch} hw={hw} C={c0 + c1}")
         return out
 
     def layernorm(self, x, gamma, beta, out, *, rows, c):
-        self.add(lambda: ops.layernorm(x, gamma, beta, out, rows=rows, c=c))
+        self.add(lambda: ops.layernorm(x, gamma, beta, out, rows=rows, c=c), tag=f"layernorm rows={rows} C={c}")
         return out
 
     def attention(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
         self.add(lambda: ops.attention(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv,
                                        ldo=ldo, scale=d ** -0.5),
-                 flops=4 * batch * heads * lq * lk * d)
+                 flops=4 * batch * heads * lq * lk * d, tag=f"attention B={batch} h={heads} lq={lq} lk={lk} d={d}")
         return out
 
     # ---- execution
     def run(self):
         for fn in self.launches:
             fn()
+
+    def profile(self, reps=3):
+        """Eager per-launch timing with HIP events -> list of (tag, flops, ms); for tuning only."""
+        dev = self.device
+        self.run()
+        torch.cuda.synchronize(dev)
+        out = []
+        for fn, (tag, fl) in zip(self.launches, self.tags):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize(dev)
+            out.append((tag, fl, a.elapsed_time(b) / reps))
+        return out
 
     def capture(self):
         """Capture the launch list into a HIP graph (warm-up run first, on a side stream as torch requires)."""

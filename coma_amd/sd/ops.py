@@ -18,7 +18,8 @@ class ConvGemmDesc(C.Structure):
                 ("taps", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("pad", C.c_int), ("n", C.c_int),
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("bias_bn", C.c_void_p), ("ldbb", C.c_int), ("res", C.c_void_p), ("ldr", C.c_int),
                 ("out", C.c_void_p), ("ldo", C.c_int), ("epi", C.c_int), ("nbatch_z", C.c_int),
-                ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64)]
+                ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 def _p(t, name="tensor", dtype=F16):
@@ -33,7 +34,7 @@ def _stream(t):
 
 def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a1=None, c1=0, taps=1, stride=1, upsample=0,
               pad=1, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, epi=EPI_NONE, nbatch_z=1, stride_a=0, stride_w=0,
-              stride_out=0, stride_res=0):
+              stride_out=0, stride_res=0, workspace=None):
     d = ConvGemmDesc()
     d.a0, d.a1, d.c0, d.c1 = _p(a0, "a0"), _p(a1, "a1"), c0, c1
     d.batch, d.in_h, d.in_w = batch, in_h, in_w
@@ -44,6 +45,8 @@ def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a
     d.w, d.bias, d.bias_bn, d.res, d.ldr = _p(w, "w"), _p(bias, "bias"), _p(bias_bn, "bias_bn"), _p(res, "res"), ldr
     d.out, d.ldo, d.epi, d.nbatch_z = _p(out, "out"), ldo, epi, nbatch_z
     d.stride_a, d.stride_w, d.stride_out, d.stride_res = stride_a, stride_w, stride_out, stride_res
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = _p(workspace, "workspace", torch.float32), workspace.numel() * 4
     _lib.check(_lib.lib().sd_conv_gemm_f16(C.byref(d), _stream(out)), "sd_conv_gemm_f16")
     return out
 

@@ -42,7 +42,7 @@ class HipUNet2DConditionModel:
         self.gc = LaunchGraph(self.device)       # per-prompt graph (cross-attention K / V^T of the text context)
         B, HW = batch, height * width
         # static inputs / outputs
-        self.x_in = self.g.buf(B, HW, 32, zero=True)              # 9 valid channels (latents|mask|masked latents)
+        self.x_in = self.g.buf(B, HW, 64, zero=True)              # 9 valid channels (latents|mask|masked latents)
         self.timesteps = self.g.buf(B, dtype=torch.float32, zero=True)
         self.ctx = self.g.buf(B, ctx_len, self.ctx_dim, zero=True)
         self.eps = None
@@ -75,11 +75,11 @@ class HipUNet2DConditionModel:
         self._tb = g.buf(B, off)
         g.conv(semb, w_all, self._tb, batch=B, in_h=1, in_w=1, c0=temb_dim, n=off, bias=b_all)
 
-        # --- conv_in (9 -> 32 padded input channels)
+        # --- conv_in (9 -> 64 padded input channels)
         H, W = self.H, self.W
-        w_in = conv_weight(s["conv_in.weight"], cin_pad=32)
+        w_in = conv_weight(s["conv_in.weight"], cin_pad=64)
         h = g.buf(B * H * W, ch[0])
-        g.conv(self.x_in, w_in, h, batch=B, in_h=H, in_w=W, c0=32, n=ch[0], taps=9, bias=s["conv_in.bias"])
+        g.conv(self.x_in, w_in, h, batch=B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9, bias=s["conv_in.bias"])
         skips = [(h, ch[0], H, W)]
         cin = ch[0]
         for i, cout in enumerate(ch):
@@ -220,7 +220,7 @@ class HipUNet2DConditionModel:
         if encoder_hidden_states is not None:
             self.set_context(encoder_hidden_states)
         x = sample.to(self.device, torch.float32).contiguous()
-        ops.nchw_to_nhwc(x, self.x_in, batch=B, c=self.config.in_channels, hw=HW, cpad=32)
+        ops.nchw_to_nhwc(x, self.x_in, batch=B, c=self.config.in_channels, hw=HW, cpad=64)
         t = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
         self.timesteps.copy_(t.expand(B) if t.numel() == 1 else t)
         self.forward_static()

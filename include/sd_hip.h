@@ -32,7 +32,7 @@ extern "C" {
 /* out[m, n] = sum_k A[m, k] * W[n, k] (+ epilogue) with A gathered from one or two NHWC sources:
  *   m = (b, oy, ox), k = (tap, ci);  taps = 9: 3x3, zero pad 1;  taps = 1: 1x1 / linear
  *   upsample = 1: the 3x3 window slides over the nearest-x2 upsampling of the [in_h, in_w] input
- *   ci runs over the concatenation [a0 (c0 channels) | a1 (c1 channels)]; c0, c1 multiples of 32
+ *   ci runs over the concatenation [a0 (c0 channels) | a1 (c1 channels)]; c0, c1 multiples of 64
  * replaces: torch.nn.Conv2d / nn.Linear / torch.cat / F.interpolate(nearest) inside diffusers'
  *           UNet2DConditionModel and AutoencoderKL (call sites utils/adaptive_mask_inpainting.py:1001, :1086, :680). */
 typedef struct sd_conv_gemm_desc {
@@ -55,9 +55,12 @@ typedef struct sd_conv_gemm_desc {
   int epi;
   int nbatch_z;         /* >1: independent problems along grid z with the element strides below */
   int64_t stride_a, stride_w, stride_out, stride_res;
+  void* workspace;      /* optional fp32 scratch for split-K (small M*N, deep K); NULL disables split-K */
+  size_t workspace_bytes;
 } sd_conv_gemm_desc;
 
 int sd_conv_gemm_f16(const sd_conv_gemm_desc* desc, void* stream);
+size_t sd_conv_gemm_workspace_bytes(void); /* recommended workspace size */
 
 /* GroupNorm (+ optional SiLU) over NHWC fp16, reading the channel concatenation of two sources and writing one
  * tensor [batch, hw, c0+c1].  replaces: nn.GroupNorm(groups, C, eps) + nn.SiLU in diffusers ResnetBlock2D /
@@ -88,7 +91,7 @@ int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stre
  * eps_uc: fp16 NHWC [2B, hw, cpad] UNet output (first B = unconditional, last B = conditional, 4 valid channels)
  * latents: fp32 [B, hw, 4] in/out;  x0_out: fp32 [B, hw, 4] or NULL (pred_original_sample)
  * mask: fp16 [B, hw] ; masked_latents fp16 [B, hw, 4]
- * unet_in: fp16 NHWC [2B, hw, 32]: channels [latents(4) | mask(1) | masked_latents(4) | zero pad] for both halves.
+ * unet_in: fp16 NHWC [2B, hw, 64]: channels [latents(4) | mask(1) | masked_latents(4) | zero pad] for both halves.
  * replaces: utils/adaptive_mask_inpainting.py:990-996 (input assembly), :1010-1012 (CFG), :1015-1017 (DDIM step). */
 int sd_cfg_ddim_step(const void* eps_uc, int eps_ld, float* latents, float* x0_out, const void* mask,
                      const void* masked_latents, void* unet_in, int batch, int hw, float guidance, float alpha_t,

@@ -33,12 +33,25 @@ def ops(hip_lib):
     return ops
 
 
-@pytest.mark.parametrize("rows,k,n", [(300, 320, 640), (128, 64, 320), (77, 768, 1280), (1000, 1280, 64), (5, 320, 1280)])
+@pytest.mark.parametrize("rows,k,n", [(300, 320, 640), (128, 64, 320), (77, 768, 1280), (1000, 1280, 64), (5, 320, 1280), (256, 23040, 128)])
 def test_linear_bias_residual(ops, rows, k, n):
     x, w, b, r = rnd(rows, k, seed=1), rnd(n, k, seed=2, scale=k**-0.5), rnd(n, seed=3), rnd(rows, n, seed=4)
     out = torch.empty(rows, n, dtype=F16, device=DEV)
     ops.linear(x.to(DEV), w.to(DEV), out, rows=rows, k=k, n=n, bias=b.to(DEV), res=r.to(DEV))
     close(out, x.float() @ w.float().t() + b.float() + r.float())
+
+
+def test_split_k_path_matches(ops):
+    """Small M*N with deep K takes the split-K route (fp32 slabs + fused-epilogue reduce) when a workspace is given."""
+    rows, k, n = 256, 11520, 256
+    x, w, b, r = rnd(rows, k, seed=1), rnd(n, k, seed=2, scale=k**-0.5), rnd(n, seed=3), rnd(rows, n, seed=4)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    for workspace in (None, ws):
+        out = torch.empty(rows, n, dtype=F16, device=DEV)
+        ops.conv_gemm(x.to(DEV), w.to(DEV), out, batch=rows, in_h=1, in_w=1, c0=k, n=n, bias=b.to(DEV), res=r.to(DEV),
+                      workspace=workspace)
+        close(out, ref)
 
 
 def test_linear_is_transpose_sensitive(ops):
@@ -51,9 +64,9 @@ def test_linear_is_transpose_sensitive(ops):
     assert torch.equal(out.cpu(), w.t().contiguous())
 
 
-@pytest.mark.parametrize("cfg", [dict(c0=64, c1=0, n=128, stride=1, up=0), dict(c0=32, c1=64, n=64, stride=1, up=0),
-                                 dict(c0=64, c1=0, n=64, stride=2, up=0), dict(c0=32, c1=0, n=128, stride=1, up=1),
-                                 dict(c0=96, c1=32, n=320, stride=1, up=0)])
+@pytest.mark.parametrize("cfg", [dict(c0=64, c1=0, n=128, stride=1, up=0), dict(c0=64, c1=128, n=64, stride=1, up=0),
+                                 dict(c0=64, c1=0, n=64, stride=2, up=0), dict(c0=64, c1=0, n=128, stride=1, up=1),
+                                 dict(c0=192, c1=64, n=320, stride=1, up=0), dict(c0=640, c1=0, n=128, stride=1, up=0)])
 def test_conv3x3_variants(ops, cfg):
     B, H, W = 2, 12, 10
     c0, c1, n = cfg["c0"], cfg["c1"], cfg["n"]
@@ -71,7 +84,7 @@ def test_conv3x3_variants(ops, cfg):
 
 
 def test_conv1x1_two_sources_and_silu(ops):
-    B, H, W, c0, c1, n = 3, 8, 8, 64, 32, 128
+    B, H, W, c0, c1, n = 3, 8, 8, 64, 128, 128
     x0, x1, w, b = rnd(B * H * W, c0, seed=1), rnd(B * H * W, c1, seed=2), rnd(n, 1, c0 + c1, seed=3, scale=0.1), rnd(n, seed=4)
     out = torch.empty(B * H * W, n, dtype=F16, device=DEV)
     ops.conv_gemm(x0.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, in_h=H, in_w=W, c0=c0, n=n, a1=x1.to(DEV), c1=c1,
@@ -175,7 +188,7 @@ def test_cfg_ddim_step_closed_form(ops):
     x = torch.randn(B, hw, 4, generator=torch.Generator().manual_seed(2))
     mask, masked = (torch.rand(B, hw) > 0.5).to(F16), rnd(B, hw, 4, seed=3)
     lat, x0 = x.to(DEV).clone(), torch.empty(B, hw, 4, device=DEV)
-    uin = torch.full((2 * B, hw, 32), 7.0, dtype=F16, device=DEV)
+    uin = torch.full((2 * B, hw, 64), 7.0, dtype=F16, device=DEV)
     a_t, a_p = float(alphas[t]), float(alphas[t - 20])
     ops.cfg_ddim_step(eps.to(DEV), 64, lat, x0, mask.to(DEV), masked.to(DEV), uin, batch=B, hw=hw, guidance=11.0,
                       alpha_t=a_t, alpha_prev=a_p)
@@ -193,11 +206,11 @@ def test_cfg_ddim_step_closed_form(ops):
 def test_layout_conversions_and_u8(ops):
     B, c, hw = 2, 9, 48
     x = torch.randn(B, c, hw, generator=torch.Generator().manual_seed(0))
-    out = torch.empty(B, hw, 32, dtype=F16, device=DEV)
-    ops.nchw_to_nhwc(x.to(DEV), out, batch=B, c=c, hw=hw, cpad=32)
+    out = torch.empty(B, hw, 64, dtype=F16, device=DEV)
+    ops.nchw_to_nhwc(x.to(DEV), out, batch=B, c=c, hw=hw, cpad=64)
     assert torch.equal(out.cpu()[:, :, :c], x.permute(0, 2, 1).to(F16)) and float(out[:, :, c:].abs().max()) == 0
     back = torch.empty(B, c, hw, device=DEV)
-    ops.nhwc_to_nchw(out, back, batch=B, c=c, hw=hw, ld=32)
+    ops.nhwc_to_nchw(out, back, batch=B, c=c, hw=hw, ld=64)
     assert torch.equal(back.cpu(), x.to(F16).float())
     img = (torch.rand(B, hw, 64, generator=torch.Generator().manual_seed(1)) * 2.4 - 1.2).to(F16)
     for mode in (0, 1):
