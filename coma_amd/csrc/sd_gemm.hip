@@ -218,55 +218,123 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
 
   // ---------------------------------------------------------------- epilogue
-  const int col_in_wave = lane & 31;
+  // The MFMAs were issued as D = W_frag . A_frag^T, so a lane owns ONE output row m = (lane & 31) of each 32-row
+  // tile and its 16 registers run along output columns n = 8*(r>>2) + 4*(lane>>5) + (r&3): four consecutive
+  // registers are four consecutive columns.  Each wave stages its 32 x (BN/2) fp32 sub-tile in LDS (16-byte
+  // writes), then re-reads it row-major so that bias / residual / output move as coalesced 16-byte vectors.
+  constexpr int WCOLS = BN / 2;                 // columns per wave
+  constexpr int EP_STRIDE = WCOLS + 4;          // floats; 16-byte aligned rows, conflict-free 16-byte writes
+  __syncthreads();                              // every wave is done with the operand tiles
+  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
+  const int lrow = lane & 31, hh = lane >> 5;
   if (split) {
     float* part = g.partial + (long long)blockIdx.z * g.M * g.N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      const int row = m0 + wr * 64 + i * 32 + lrow;
+      if (row >= g.M) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
+      for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int col = n0 + wc * (BN / 2) + j * 32 + col_in_wave;
-          if (col < g.N) part[(long long)row * g.N + col] = acc[i][j][r];
+        for (int q = 0; q < 4; ++q) {
+          const int col = n0 + wc * WCOLS + j * 32 + 8 * q + 4 * hh;
+          if (col < g.N)   // N % 8 == 0 on this path
+            *reinterpret_cast<float4*>(part + (long long)row * g.N + col) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         }
-      }
+    }
     return;
   }
   _Float16* outp = g.out + z * g.so;
   const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
   const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
+  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    const int mbase = m0 + wr * 64 + i * 32;
+    int ocols;            // valid output columns of this wave's sub-tile, and its first output column
+    int ocol0;
+    if (geglu) {
+      // wave tile = [32 value cols | 32 gate cols] (weight rows interleaved at prep time) -> 32 outputs
+      ocols = 32;
+      ocol0 = (n0 >> 1) + wc * 32;
+      if constexpr (WN == 2) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row >= g.M) continue;
-      if (geglu) {
-        // wave tile = [32 value cols | 32 gate cols]; output column = (n0 + wc*64)/2 + lane
-        if constexpr (WN == 2) {
-          const int ncol = n0 + wc * 64 + col_in_wave;          // permuted value column
-          const int ocol = (n0 >> 1) + wc * 32 + col_in_wave;
-          float v = acc[i][0][r], gt = acc[i][1][r];
-          if (g.bias) { v += (float)g.bias[ncol]; gt += (float)g.bias[ncol + 32]; }
-          outp[(long long)row * g.ldo + ocol] = (_Float16)(v * gelu_erf(gt));
-        }
-      } else {
+        for (int q = 0; q < 4; ++q) {
+          float o[4];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int col = n0 + wc * (BN / 2) + j * 32 + col_in_wave;
-          if (col >= g.N) continue;
-          outp[(long long)row * g.ldo + col] = (_Float16)epilogue_value(g, acc[i][j][r], row, col, resp);
+          for (int e = 0; e < 4; ++e) {
+            const int c = 8 * q + 4 * hh + e;
+            float v = acc[i][0][4 * q + e], gt = acc[i][1][4 * q + e];
+            if (g.bias) { v += (float)g.bias[n0 + wc * 64 + c]; gt += (float)g.bias[n0 + wc * 64 + 32 + c]; }
+            o[e] = v * gelu_erf(gt);
+          }
+          *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
         }
       }
+    } else {
+      ocols = WCOLS;
+      ocol0 = n0 + wc * WCOLS;
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + j * 32 + 8 * q + 4 * hh) =
+              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // row-major read-back: 8 columns per lane
+    const int cpr = ocols / 8;                  // 16-byte output chunks per row (4 or 8)
+    for (int it = lane; it < 32 * cpr; it += 64) {
+      const int rl = it / cpr, cl = (it - rl * cpr) * 8;
+      const int row = mbase + rl, col = ocol0 + cl;
+      if (row >= g.M) continue;
+      const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
+      const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
+      float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+      if (geglu) {
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+        *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
+      } else if (vec_ok && col + 8 <= g.N) {
+        if (g.bias) {
+          const half8 bv = *reinterpret_cast<const half8*>(g.bias + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)bv[e];
+        }
+        if (g.bias_bn) {
+          const _Float16* bp = g.bias_bn + (long long)(row / g.rows_per_batch) * g.ldbb + col;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)bp[e];
+        }
+        if (g.epi & SD_EPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+        }
+        if (resp) {
+          const half8 rv = *reinterpret_cast<const half8*>(resp + (long long)row * g.ldr + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+        *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
+      } else {
+        for (int e = 0; e < 8; ++e)
+          if (col + e < g.N)
+            outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
