@@ -58,9 +58,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   const int ql = lane & 31, hh = lane >> 5;
   const int d = a.d;
 
-  // zero both tiles once: pad columns / pad rows must hold finite values
-  for (int i = tid; i < BKV * K_STRIDE / 8; i += 256) reinterpret_cast<uint4*>(Ks)[i] = make_uint4(0, 0, 0, 0);
-  for (int i = tid; i < DV * VT_STRIDE / 4; i += 256) reinterpret_cast<uint2*>(Vs)[i] = make_uint2(0, 0);
+  // every K slot [64][DQK] and V^T slot [DV][64] is rewritten by each tile's staging pass (zeros beyond d / lk),
+  // so pad columns and pad rows always hold finite values
 
   // Q fragments (B operand): lane (query ql, half hh) holds dd = ks*16 + hh*8 .. +7
   half8 qf[KS];
@@ -91,33 +90,64 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   const int kchunks = d / 8;            // 16-byte chunks per K row
   __syncthreads();
 
-  for (int key0 = 0; key0 < a.lk; key0 += BKV) {
-    // ---- stage K tile [64 keys][d] and V^T tile [d][64 keys]
-    for (int it = tid; it < BKV * kchunks; it += 256) {
-      const int row = it / kchunks, ch = it - row * kchunks;
+  // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is multiplied
+  constexpr int KCH = DQK / 8;                       // 16-byte chunk slots per K row (>= d/8)
+  constexpr int K_ITEMS = (BKV * KCH + 255) / 256;
+  constexpr int V_ITEMS = DV * (BKV / 8) / 256;      // = DVT
+  uint4 rk[K_ITEMS];
+  half8 rv[V_ITEMS];
+  auto load_regs = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < K_ITEMS; ++i) {
+      const int it = tid + i * 256;
+      const int row = it / KCH, ch = it - row * KCH;
       const int key = key0 + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (key < a.lk) v = *reinterpret_cast<const uint4*>(kbase + (long long)key * a.ldk + ch * 8);
-      *reinterpret_cast<uint4*>(&Ks[row * K_STRIDE + ch * 8]) = v;
+      rk[i] = (row < BKV && ch < kchunks && key < a.lk)
+                  ? *reinterpret_cast<const uint4*>(kbase + (long long)key * a.ldk + ch * 8)
+                  : make_uint4(0, 0, 0, 0);
     }
-    for (int it = tid; it < d * (BKV / 8); it += 256) {
+#pragma unroll
+    for (int i = 0; i < V_ITEMS; ++i) {
+      const int it = tid + i * 256;
       const int row = it >> 3, ch = it & 7;
       const int key = key0 + ch * 8;
       half8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
-      if (key + 8 <= a.lk) {
-        v = *reinterpret_cast<const half8*>(vbase + (long long)row * a.ldv + key);
-      } else if (key < a.lk) {
-        const _Float16* p = vbase + (long long)row * a.ldv + key;
-        for (int j = 0; j < a.lk - key; ++j) v[j] = p[j];
+      if (row < d) {
+        if (key + 8 <= a.lk) {
+          v = *reinterpret_cast<const half8*>(vbase + (long long)row * a.ldv + key);
+        } else if (key < a.lk) {
+          const _Float16* p = vbase + (long long)row * a.ldv + key;
+          for (int j = 0; j < a.lk - key; ++j) v[j] = p[j];
+        }
       }
+      rv[i] = v;
+    }
+  };
+  auto store_regs = [&]() {
+#pragma unroll
+    for (int i = 0; i < K_ITEMS; ++i) {
+      const int it = tid + i * 256;
+      const int row = it / KCH, ch = it - row * KCH;
+      if (row < BKV) *reinterpret_cast<uint4*>(&Ks[row * K_STRIDE + ch * 8]) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < V_ITEMS; ++i) {
+      const int it = tid + i * 256;
+      const int row = it >> 3, ch = it & 7;
       // 8 halves = two 8-byte LDS writes (rows are 8-byte aligned, not 16)
-      half4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+      half4 lo = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]}, hi = {rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
       *reinterpret_cast<half4*>(&Vs[row * VT_STRIDE + ch * 8]) = lo;
       *reinterpret_cast<half4*>(&Vs[row * VT_STRIDE + ch * 8 + 4]) = hi;
     }
+  };
+
+  load_regs(0);
+  for (int key0 = 0; key0 < a.lk; key0 += BKV) {
+    store_regs();
     __syncthreads();
+    if (key0 + BKV < a.lk) load_regs(key0 + BKV);
 
     // ---- S^T = K Q^T  (two 32-key tiles)
     float16v s[2];
@@ -131,37 +161,51 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
-    // ---- online softmax (per-lane scalars; the partner lane holds the other 32 keys of this query)
-    float mx = -__builtin_inff();
+    // ---- online softmax (per-lane scalars; the partner lane holds the other 32 keys of this query).
+    // Scores stay RAW in the accumulators; scale*log2(e) rides in the FMA that forms the exp2 argument.  The
+    // running max is only raised when it would grow by more than RESCALE_THR (log2 units): P may then reach
+    // 2^THR (fine in fp16/fp32) and the O / l rescale becomes a rare, wave-uniformly skipped branch.
+    if (key0 + BKV > a.lk) {   // wave-uniform: only the last tile can be ragged
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float v = s[t][r] * a.scale_log2;
-        v = key < a.lk ? v : -__builtin_inff();
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);            // finite: every tile has at least one valid key
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          s[t][r] = key < a.lk ? s[t][r] : -__builtin_inff();
+        }
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;   // scale > 0: max commutes with the scaling
+    constexpr float RESCALE_THR = 6.0f;
+    const bool need = mx > m_run + RESCALE_THR;          // first tile: m_run = -inf -> true
+    if (__any(need)) {
+      const float m_new = need ? mx : m_run;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 1 when unchanged, 0 on the first tile
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 c2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_run, -m_run};
+    f32x2 ps2 = {0.0f, 0.0f};
     half8 pf[4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[t][r] - m_new);
-        psum += p;
-        pf[t * 2 + (r >> 3)][r & 7] = (_Float16)p;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {s[t][r], s[t][r + 1]};
+        const f32x2 e = __builtin_elementwise_fma(sv, c2, nm2);
+        const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+        ps2 += p;
+        pf[t * 2 + (r >> 3)][r & 7] = (_Float16)p.x;
+        pf[t * 2 + (r >> 3)][(r & 7) + 1] = (_Float16)p.y;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int t = 0; t < DVT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    l_run += ps2.x + ps2.y;
     // ---- O^T += V^T P^T, 16 keys per MFMA, keys in accumulator-register order
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
