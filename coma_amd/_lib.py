@@ -44,6 +44,9 @@ SIGNATURES = {
     "sd_nchw_to_nhwc_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sd_nhwc_to_nchw_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sd_image_to_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "sd_vae_sample": (_i, [_vp, _i, _vp, _f, _i64, _vp, _vp, _vp]),
+    "sd_add_noise": (_i, [_vp, _vp, _f, _i64, _vp, _vp]),
+    "sd_mask_adapt": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
 }
 
 

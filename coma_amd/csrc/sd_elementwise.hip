@@ -148,3 +148,92 @@ extern "C" int sd_image_to_u8(const void* x, int batch, int hw, int ld, int roun
                      (const _Float16*)x, npix, ld, round_mode, out);
   return check_launch("image_to_u8_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// VAE latent sampling + scaling, and the mask glue of the adaptive loop
+// ------------------------------------------------------------------------------------------------
+namespace sd {
+
+// moments: NHWC fp16 [B*hw, ld] = [mean(4) | logvar(4) | pad];  latent = (mean + exp(0.5*clamp(logvar,-30,20))*noise)*scale
+// replaces: DiagonalGaussianDistribution.sample (diffusers) * vae.config.scaling_factor,
+//           utils/adaptive_mask_inpainting.py:675-684.
+__global__ void vae_sample_kernel(const _Float16* __restrict__ mom, int ld, const float* __restrict__ noise, float scale,
+                                  long long n, float* __restrict__ lat32, _Float16* __restrict__ lat16) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 4) return;
+  long long p = i >> 2;
+  int c = (int)(i & 3);
+  float mean = (float)mom[p * ld + c];
+  float logvar = fminf(fmaxf((float)mom[p * ld + 4 + c], -30.0f), 20.0f);
+  float v = (mean + __expf(0.5f * logvar) * (noise ? noise[i] : 0.0f)) * scale;
+  if (lat32) lat32[i] = v;
+  if (lat16) lat16[i] = (_Float16)v;
+}
+
+// x = sqrt(a) * x0 + sqrt(1-a) * noise   (DDIMScheduler.add_noise, used when strength < 1)
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise, float sa, float s1ma, long long n,
+                                 float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sa * x0[i] + s1ma * noise[i];
+}
+
+// Mask adaptation on device (K12): given the segmentation mask (u8 [H,W], non-zero = human) and the default box mask,
+//   m = AND( dilate_{3x3, iters}(seg), default )          cv2.dilate with a 3x3 ones kernel, `iters` iterations
+//                                                          == max over a (2*iters+1)^2 window, zero border
+// and the products the pipeline needs from it:
+//   mask_full  u8  [H,W]       (0/1)
+//   mask_lat   f16 [H/8*W/8]   nearest-neighbour down-sample (F.interpolate, mode="nearest": source pixel (8y, 8x))
+//   masked_img f16 NHWC [H*W, cpad]  image * (mask < 0.5), image given as fp32 NCHW in [-1,1]
+// replaces: utils/adaptive_mask_inpainting.py:1136-1137 (dilate, logical_and), :131-245 (binarise, masked image),
+//           :686-694 (mask interpolate).
+__global__ void mask_adapt_kernel(const uint8_t* __restrict__ seg, const uint8_t* __restrict__ dflt, int H, int W, int iters,
+                                  int use_default, const float* __restrict__ image, int cpad, uint8_t* __restrict__ mask_full,
+                                  _Float16* __restrict__ mask_lat, _Float16* __restrict__ masked_img) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  int m;
+  if (use_default) {
+    m = dflt[y * W + x] != 0;
+  } else {
+    m = 0;
+    const int y0 = max(0, y - iters), y1 = min(H - 1, y + iters), x0 = max(0, x - iters), x1 = min(W - 1, x + iters);
+    for (int yy = y0; yy <= y1 && !m; ++yy)
+      for (int xx = x0; xx <= x1; ++xx)
+        if (seg[yy * W + xx]) { m = 1; break; }
+    m = m && (dflt[y * W + x] != 0);
+  }
+  mask_full[y * W + x] = (uint8_t)m;
+  if ((y & 7) == 0 && (x & 7) == 0) mask_lat[(y >> 3) * (W >> 3) + (x >> 3)] = (_Float16)(float)m;
+  const long long p = (long long)y * W + x;
+  for (int c = 0; c < cpad; ++c)
+    masked_img[p * cpad + c] = c < 3 ? (_Float16)(m ? 0.0f : image[(long long)c * H * W + p]) : (_Float16)0.0f;
+}
+
+}  // namespace sd
+
+extern "C" int sd_vae_sample(const void* moments, int ld, const float* noise, float scale, int64_t npix, float* latents_f32,
+                             void* latents_f16, void* stream) {
+  if (!moments || npix <= 0 || ld < 8 || (!latents_f32 && !latents_f16)) return sd::fail(COMA_E_INVALID, "sd_vae_sample: bad args");
+  hipLaunchKernelGGL(sd::vae_sample_kernel, dim3((unsigned)((npix * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)moments, ld, noise, scale, (long long)npix, latents_f32, (_Float16*)latents_f16);
+  return sd::check_launch("vae_sample_kernel");
+}
+
+extern "C" int sd_add_noise(const float* x0, const float* noise, float alpha, int64_t n, float* out, void* stream) {
+  if (!x0 || !noise || !out || n <= 0 || !(alpha > 0.f) || alpha > 1.f) return sd::fail(COMA_E_INVALID, "sd_add_noise: bad args");
+  hipLaunchKernelGGL(sd::add_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x0, noise,
+                     sqrtf(alpha), sqrtf(1.0f - alpha), (long long)n, out);
+  return sd::check_launch("add_noise_kernel");
+}
+
+extern "C" int sd_mask_adapt(const uint8_t* seg, const uint8_t* default_mask, int H, int W, int dilate_iters, int use_default,
+                             const float* image_nchw, int cpad, uint8_t* mask_full, void* mask_latent, void* masked_image,
+                             void* stream) {
+  if (!default_mask || !image_nchw || !mask_full || !mask_latent || !masked_image || (!use_default && !seg))
+    return sd::fail(COMA_E_INVALID, "sd_mask_adapt: null pointer");
+  if (H <= 0 || W <= 0 || (H & 7) || (W & 7) || dilate_iters < 0 || cpad < 3)
+    return sd::fail(COMA_E_INVALID, "sd_mask_adapt: bad sizes");
+  hipLaunchKernelGGL(sd::mask_adapt_kernel, dim3((W + 127) / 128, H), dim3(128), 0, (hipStream_t)stream, seg, default_mask, H, W,
+                     dilate_iters, use_default, image_nchw, cpad, mask_full, (_Float16*)mask_latent, (_Float16*)masked_image);
+  return sd::check_launch("mask_adapt_kernel");
+}

@@ -115,3 +115,24 @@ def image_to_u8(x, out, *, batch, hw, ld, round_mode=0):
     _lib.check(_lib.lib().sd_image_to_u8(_p(x), batch, hw, ld, round_mode, _p(out, "out", torch.uint8), _stream(out)),
                "sd_image_to_u8")
     return out
+
+
+def vae_sample(moments, ld, noise, scale, npix, lat32=None, lat16=None):
+    rc = _lib.lib().sd_vae_sample(_p(moments), ld, _p(noise, "noise", torch.float32), scale, npix, _p(lat32, "lat32", torch.float32),
+                                  _p(lat16), _stream(moments))
+    _lib.check(rc, "sd_vae_sample")
+
+
+def add_noise(x0, noise, alpha, out):
+    f32 = torch.float32
+    _lib.check(_lib.lib().sd_add_noise(_p(x0, "x0", f32), _p(noise, "noise", f32), alpha, x0.numel(), _p(out, "out", f32),
+                                       _stream(out)), "sd_add_noise")
+    return out
+
+
+def mask_adapt(seg, default_mask, image_nchw, mask_full, mask_latent, masked_image, *, H, W, dilate_iters, use_default, cpad):
+    u8 = torch.uint8
+    rc = _lib.lib().sd_mask_adapt(_p(seg, "seg", u8), _p(default_mask, "default", u8), H, W, dilate_iters, 1 if use_default else 0,
+                                  _p(image_nchw, "image", torch.float32), cpad, _p(mask_full, "mask_full", u8), _p(mask_latent),
+                                  _p(masked_image), _stream(mask_full))
+    _lib.check(rc, "sd_mask_adapt")

@@ -1,0 +1,206 @@
+"""AutoencoderKL (SD-1.5 VAE) on MI355X as two static launch graphs (decoder, encoder) over NHWC fp16 buffers.
+
+The reference pipeline uses exactly: ``vae.decode(z / scaling_factor, return_dict=False)[0]``
+(utils/adaptive_mask_inpainting.py:1086, :1112), ``vae.encode(img).latent_dist.sample(generator)`` (:677-680) and
+``vae.config.{scaling_factor, latent_channels, block_out_channels}`` (:371, :682, :927).  Architecture: public
+SD-1.5 VAE (diffusers is third party).  GroupNorm eps 1e-6, no time embedding, single-head
+attention over 4096 tokens at C = 512 in the mid block (un-fused here: it runs once per image, d = 512).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .graph import F16, LaunchGraph
+from .weights import VAE_CFG, conv_weight, pad_vec
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class _VaeBase:
+    def __init__(self, state, batch, device, cfg):
+        self.cfgd = cfg
+        self.device = torch.device(device)
+        self.batch = batch
+        self.s = {k: v.to(self.device, F16) for k, v in state.items()}
+        self.g = LaunchGraph(self.device)
+        self._captured = False
+
+    def _resnet(self, p, x, cin, cout, H, W):
+        g, s, B = self.g, self.s, self.batch
+        M = B * H * W
+        n1 = g.buf(M, cin)
+        g.groupnorm(x, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=cin, eps=1e-6, silu=True)
+        h = g.buf(M, cout)
+        g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9, bias=s[p + ".conv1.bias"])
+        n2 = g.buf(M, cout)
+        g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-6, silu=True)
+        if p + ".conv_shortcut.weight" in s:
+            sc = g.buf(M, cout)
+            g.conv(x, conv_weight(s[p + ".conv_shortcut.weight"]), sc, batch=B, in_h=H, in_w=W, c0=cin, n=cout,
+                   bias=s[p + ".conv_shortcut.bias"])
+        else:
+            sc = x
+        out = g.buf(M, cout)
+        g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
+               bias=s[p + ".conv2.bias"], res=sc)
+        return out
+
+    def _attention(self, p, x, C, H, W):
+        """Single-head attention with q/k/v/out biases and a residual, un-fused: S = QK^T, row softmax, O = P V."""
+        g, s, B = self.g, self.s, self.batch
+        L, M = H * W, B * H * W
+        gn = g.buf(M, C)
+        g.groupnorm(x, s[p + ".group_norm.weight"], s[p + ".group_norm.bias"], gn, batch=B, hw=L, c0=C, eps=1e-6, silu=False)
+        q, k = g.buf(M, C), g.buf(M, C)
+        g.conv(gn, s[p + ".to_q.weight"], q, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_q.bias"])
+        g.conv(gn, s[p + ".to_k.weight"], k, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_k.bias"])
+        vt = g.buf(B, C, L)                                  # V^T[b] = Wv . X_b^T + bv (bias per row)
+        g.conv(s[p + ".to_v.weight"], gn, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, bias=s[p + ".to_v.bias"],
+               epi=ops.EPI_BIAS_ROWS, nbatch_z=B, stride_w=L * C, stride_out=C * L)
+        sc = g.buf(B, L, L)
+        g.conv(q, k, sc, batch=L, in_h=1, in_w=1, c0=C, n=L, nbatch_z=B, stride_a=L * C, stride_w=L * C, stride_out=L * L)
+        g.add(lambda: ops.softmax_(sc, rows=B * L, n=L, ld=L, scale=C ** -0.5), tag=f"softmax rows={B * L} n={L}")
+        a = g.buf(M, C)
+        g.conv(sc, vt, a, batch=L, in_h=1, in_w=1, c0=L, n=C, nbatch_z=B, stride_a=L * L, stride_w=C * L, stride_out=L * C)
+        out = g.buf(M, C)
+        g.conv(a, s[p + ".to_out.0.weight"], out, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_out.0.bias"], res=x)
+        return out
+
+    def _replay(self):
+        if not self._captured:
+            self.g.capture()
+            self._captured = True
+        self.g.replay()
+
+
+class HipVaeDecoder(_VaeBase):
+    """z (fp16 NHWC [B, h*w, 64], 4 valid channels, ALREADY divided by scaling_factor) -> image NHWC [B, 64*h*w, 64]."""
+
+    def __init__(self, state, batch, latent_h=64, latent_w=64, device="cuda", cfg=VAE_CFG):
+        super().__init__(state, batch, device, cfg)
+        g, s, B = self.g, self.s, batch
+        ch = cfg["block_out_channels"]
+        H, W = latent_h, latent_w
+        self.h, self.w = H, W
+        self.z = g.buf(B, H * W, 64, zero=True)
+        pq = g.buf(B * H * W, 64, zero=True)
+        g.conv(self.z, conv_weight(s["post_quant_conv.weight"], cin_pad=64, cout_pad=64), pq, batch=B * H * W, in_h=1, in_w=1,
+               c0=64, n=64, bias=pad_vec(s["post_quant_conv.bias"], 64))
+        x = g.buf(B * H * W, ch[-1])
+        g.conv(pq, conv_weight(s["decoder.conv_in.weight"], cin_pad=64), x, batch=B, in_h=H, in_w=W, c0=64, n=ch[-1], taps=9,
+               bias=s["decoder.conv_in.bias"])
+        x = self._resnet("decoder.mid_block.resnets.0", x, ch[-1], ch[-1], H, W)
+        x = self._attention("decoder.mid_block.attentions.0", x, ch[-1], H, W)
+        x = self._resnet("decoder.mid_block.resnets.1", x, ch[-1], ch[-1], H, W)
+        cin = ch[-1]
+        for i, cout in enumerate(reversed(ch)):
+            for j in range(cfg["layers_per_block"] + 1):
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, cin, cout, H, W)
+                cin = cout
+            if i < len(ch) - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                o = g.buf(B * 4 * H * W, cout)
+                g.conv(x, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout, n=cout,
+                       taps=9, upsample=1, bias=s[p + ".bias"])
+                x, H, W = o, 2 * H, 2 * W
+        gn = g.buf(B * H * W, cin)
+        g.groupnorm(x, s["decoder.conv_norm_out.weight"], s["decoder.conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin,
+                    eps=1e-6, silu=True)
+        self.image = g.buf(B * H * W, 64, zero=True)          # 3 valid channels
+        g.conv(gn, conv_weight(s["decoder.conv_out.weight"], cout_pad=64), self.image, batch=B, in_h=H, in_w=W, c0=cin, n=64,
+               taps=9, bias=pad_vec(s["decoder.conv_out.bias"], 64))
+        self.out_h, self.out_w = H, W
+
+    def decode_static(self):
+        self._replay()
+        return self.image
+
+
+class HipVaeEncoder(_VaeBase):
+    """image (fp16 NHWC [B, H*W, 64], 3 valid channels in [-1,1]) -> moments NHWC [B, H/8*W/8, 64] (mean 4 | logvar 4)."""
+
+    def __init__(self, state, batch, height=512, width=512, device="cuda", cfg=VAE_CFG):
+        super().__init__(state, batch, device, cfg)
+        g, s, B = self.g, self.s, batch
+        ch = cfg["block_out_channels"]
+        H, W = height, width
+        self.x = g.buf(B, H * W, 64, zero=True)
+        x = g.buf(B * H * W, ch[0])
+        g.conv(self.x, conv_weight(s["encoder.conv_in.weight"], cin_pad=64), x, batch=B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9,
+               bias=s["encoder.conv_in.bias"])
+        cin = ch[0]
+        for i, cout in enumerate(ch):
+            for j in range(cfg["layers_per_block"]):
+                x = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", x, cin, cout, H, W)
+                cin = cout
+            if i < len(ch) - 1:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                o = g.buf(B * (H // 2) * (W // 2), cout)
+                # F.pad(x, (0,1,0,1)) + conv stride 2 padding 0  ==  low-side pad 0, high side bounds-checked
+                g.conv(x, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=H // 2, out_w=W // 2, c0=cout, n=cout,
+                       taps=9, stride=2, pad=0, bias=s[p + ".bias"])
+                x, H, W = o, H // 2, W // 2
+        x = self._resnet("encoder.mid_block.resnets.0", x, cin, cin, H, W)
+        x = self._attention("encoder.mid_block.attentions.0", x, cin, H, W)
+        x = self._resnet("encoder.mid_block.resnets.1", x, cin, cin, H, W)
+        gn = g.buf(B * H * W, cin)
+        g.groupnorm(x, s["encoder.conv_norm_out.weight"], s["encoder.conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin,
+                    eps=1e-6, silu=True)
+        mo = g.buf(B * H * W, 64, zero=True)
+        g.conv(gn, conv_weight(s["encoder.conv_out.weight"], cout_pad=64), mo, batch=B, in_h=H, in_w=W, c0=cin, n=64, taps=9,
+               bias=pad_vec(s["encoder.conv_out.bias"], 64))
+        self.moments = g.buf(B * H * W, 64, zero=True)
+        g.conv(mo, conv_weight(s["quant_conv.weight"], cin_pad=64, cout_pad=64), self.moments, batch=B * H * W, in_h=1, in_w=1,
+               c0=64, n=64, bias=pad_vec(s["quant_conv.bias"], 64))
+        self.lat_h, self.lat_w = H, W
+
+    def encode_static(self):
+        self._replay()
+        return self.moments
+
+
+class _LatentDist:
+    def __init__(self, vae, moments, npix):
+        self.vae, self.moments, self.npix = vae, moments, npix
+
+    def sample(self, generator=None):
+        B, h, w = self.vae.batch, self.vae.enc.lat_h, self.vae.enc.lat_w
+        noise = torch.randn(B, h * w, 4, generator=generator, device=self.vae.device, dtype=torch.float32)
+        return self._to_nchw(noise)
+
+    def mode(self):
+        return self._to_nchw(None)
+
+    def _to_nchw(self, noise):
+        B, h, w = self.vae.batch, self.vae.enc.lat_h, self.vae.enc.lat_w
+        lat = torch.empty(B, h * w, 4, dtype=torch.float32, device=self.vae.device)
+        ops.vae_sample(self.moments, 64, noise, 1.0, self.npix, lat32=lat)
+        return lat.reshape(B, h, w, 4).permute(0, 3, 1, 2).contiguous()
+
+
+class HipAutoencoderKL:
+    """diffusers-shaped facade over the two graphs (NCHW tensors at the boundary, as the reference pipeline passes)."""
+
+    def __init__(self, state, batch, height=512, width=512, device="cuda", cfg=VAE_CFG, with_encoder=True):
+        self.config = _Cfg(scaling_factor=cfg["scaling_factor"], latent_channels=cfg["latent_channels"],
+                           block_out_channels=list(cfg["block_out_channels"]))
+        self.device, self.batch, self.dtype = torch.device(device), batch, F16
+        self.dec = HipVaeDecoder(state, batch, height // 8, width // 8, device, cfg)
+        self.enc = HipVaeEncoder(state, batch, height, width, device, cfg) if with_encoder else None
+
+    def decode(self, z, return_dict=False, **kw):
+        B, hw = self.batch, self.dec.h * self.dec.w
+        ops.nchw_to_nhwc(z.to(self.device, torch.float32).contiguous(), self.dec.z, batch=B, c=4, hw=hw, cpad=64)
+        img = self.dec.decode_static()
+        out = torch.empty(B, 3, self.dec.out_h, self.dec.out_w, dtype=torch.float32, device=self.device)
+        ops.nhwc_to_nchw(img, out, batch=B, c=3, hw=self.dec.out_h * self.dec.out_w, ld=64)
+        return _Cfg(sample=out) if return_dict else (out,)
+
+    def encode(self, image):
+        B, H, W = self.batch, image.shape[-2], image.shape[-1]
+        ops.nchw_to_nhwc(image.to(self.device, torch.float32).contiguous(), self.enc.x, batch=B, c=3, hw=H * W, cpad=64)
+        mom = self.enc.encode_static()
+        return _Cfg(latent_dist=_LatentDist(self, mom, B * self.enc.lat_h * self.enc.lat_w))

@@ -109,6 +109,24 @@ int sd_nhwc_to_nchw_f32(const void* x, int batch, int c, int hw, int ld, float* 
  * or rounded half-to-even (round_mode 1: diffusers' numpy_to_pil used for the final image, :1097). */
 int sd_image_to_u8(const void* x, int batch, int hw, int ld, int round_mode, uint8_t* out, void* stream);
 
+/* VAE posterior sample: moments NHWC fp16 [npix, ld] = [mean(4) | logvar(4) | pad] ->
+ * (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale as fp32 [npix,4] and/or fp16 [npix,4] (noise NULL = mode).
+ * replaces: `self.vae.encode(img).latent_dist.sample(generator)` * scaling_factor, utils/adaptive_mask_inpainting.py:675-684. */
+int sd_vae_sample(const void* moments, int ld, const float* noise, float scale, int64_t npix, float* latents_f32,
+                  void* latents_f16, void* stream);
+
+/* out = sqrt(alpha) x0 + sqrt(1-alpha) noise  (scheduler.add_noise, utils/adaptive_mask_inpainting.py:658). */
+int sd_add_noise(const float* x0, const float* noise, float alpha, int64_t n, float* out, void* stream);
+
+/* Mask adaptation glue of the adaptive loop, on device:
+ *   mask = use_default ? default : AND(dilate_{3x3 ones, dilate_iters}(seg), default)     (u8 [H,W], 0/1)
+ *   mask_latent  fp16 [H/8, W/8]        nearest down-sample (source pixel (8y, 8x))
+ *   masked_image fp16 NHWC [H*W, cpad]  image * (mask < 0.5), image = fp32 NCHW [3,H,W] in [-1,1]
+ * replaces: utils/adaptive_mask_inpainting.py:1130-1141 (cv2.dilate / logical_and / prepare_mask_and_masked_image)
+ *           and the mask interpolation of :686-694. */
+int sd_mask_adapt(const uint8_t* seg, const uint8_t* default_mask, int H, int W, int dilate_iters, int use_default,
+                  const float* image_nchw, int cpad, uint8_t* mask_full, void* mask_latent, void* masked_image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

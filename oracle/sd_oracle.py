@@ -178,3 +178,44 @@ def unet_ref(state, sample, timesteps, ctx, cfg):
         if i < len(ch) - 1:
             h = _conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), s, f"up_blocks.{i}.upsamplers.0.conv")
     return _conv(F.silu(_gn(h, s, "conv_norm_out", 1e-5)), s, "conv_out")
+
+
+# ------------------------------------------------------------------ AutoencoderKL (fp32, NCHW, diffusers semantics)
+def _vae_attn_ref(x, s, p):
+    B, C, H, W = x.shape
+    h = _gn(x, s, p + ".group_norm", 1e-6).reshape(B, C, H * W).transpose(1, 2)
+    q, k, v = _lin(h, s, p + ".to_q"), _lin(h, s, p + ".to_k"), _lin(h, s, p + ".to_v")
+    a = torch.softmax(q @ k.transpose(1, 2) * C**-0.5, dim=-1) @ v
+    a = _lin(a, s, p + ".to_out.0").transpose(1, 2).reshape(B, C, H, W)
+    return a + x
+
+
+def vae_decode_ref(state, z, cfg):
+    s, ch = state, cfg["block_out_channels"]
+    x = _conv(z.float(), s, "post_quant_conv", padding=0)
+    x = _conv(x, s, "decoder.conv_in")
+    x = resnet_ref(x, None, s, "decoder.mid_block.resnets.0", eps=1e-6)
+    x = _vae_attn_ref(x, s, "decoder.mid_block.attentions.0")
+    x = resnet_ref(x, None, s, "decoder.mid_block.resnets.1", eps=1e-6)
+    for i in range(len(ch)):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = resnet_ref(x, None, s, f"decoder.up_blocks.{i}.resnets.{j}", eps=1e-6)
+        if i < len(ch) - 1:
+            x = _conv(F.interpolate(x, scale_factor=2.0, mode="nearest"), s, f"decoder.up_blocks.{i}.upsamplers.0.conv")
+    return _conv(F.silu(_gn(x, s, "decoder.conv_norm_out", 1e-6)), s, "decoder.conv_out")
+
+
+def vae_encode_ref(state, img, cfg):
+    """-> moments [B, 8, H/8, W/8] = (mean | logvar)."""
+    s, ch = state, cfg["block_out_channels"]
+    x = _conv(img.float(), s, "encoder.conv_in")
+    for i in range(len(ch)):
+        for j in range(cfg["layers_per_block"]):
+            x = resnet_ref(x, None, s, f"encoder.down_blocks.{i}.resnets.{j}", eps=1e-6)
+        if i < len(ch) - 1:
+            x = _conv(F.pad(x, (0, 1, 0, 1)), s, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, padding=0)
+    x = resnet_ref(x, None, s, "encoder.mid_block.resnets.0", eps=1e-6)
+    x = _vae_attn_ref(x, s, "encoder.mid_block.attentions.0")
+    x = resnet_ref(x, None, s, "encoder.mid_block.resnets.1", eps=1e-6)
+    x = _conv(F.silu(_gn(x, s, "encoder.conv_norm_out", 1e-6)), s, "encoder.conv_out")
+    return _conv(x, s, "quant_conv", padding=0)

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Golden vectors G13-G16 for the pure-Python glue of the inpainting path, produced by the REAL reference
+(utils/adaptive_mask_inpainting.py imported on CPU with every third-party module auto-stubbed).
+Run from anywhere in the build container:  python tests/golden/make_golden_inpaint.py
+The UNet / VAE / DDIM arithmetic itself lives in diffusers (absent) -> not pinned here ("parity unpinned")."""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import PIL.Image
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Dummy()
+
+    def __getattr__(self, n):
+        return _Dummy()
+
+
+class _Meta(type):
+    def __getattr__(cls, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Dummy()
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Meta(name, (_Dummy,), {})
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    PREFIXES = ("diffusers", "detectron2", "segment_anything", "supervision", "cv2", "open3d", "trimesh", "easydict",
+                "transformers", "packaging")
+
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in self.PREFIXES:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        m = _Stub(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, m):
+        pass
+
+
+def main():
+    sys.meta_path.insert(0, _Finder())
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path = [p for p in sys.path if os.path.abspath(p or ".") != root]
+    sys.path.insert(0, REF)
+    os.chdir(REF)                                 # constants/segmentation.py opens a relative json
+    import utils.adaptive_mask_inpainting as r
+    assert r.__file__.startswith(REF)
+    out = {}
+    # G13 / G14: the schedules of src/generation/inpaint.py:112-132 (values typed here, classes from the reference)
+    n, step = 50, 5
+    sched = [20] * step + [10] * step + [5] * step + [4] * step + [3] * step + [2] * step + [1] * step + [0] * (n - 7 * step)
+    d = r.MaskDilateScheduler(max_dilate_num=20, num_inference_steps=n, schedule=sched)
+    out["g13_dilate"] = np.array([d(i) for i in range(n)])
+    d2 = r.MaskDilateScheduler(max_dilate_num=15, num_inference_steps=n)
+    out["g13_dilate_default"] = np.array([d2(i) for i in range(n)])
+    p = r.ProvokeScheduler(num_inference_steps=n, schedule=list(range(2, 11, 2)) + list(range(12, 41, 2)) + [45], is_zero_indexing=False)
+    out["g14_provoke"] = np.array([i for i in range(n) if p(i)])
+    pz = r.ProvokeScheduler(num_inference_steps=n, schedule=[0, 3, 49], is_zero_indexing=True)
+    out["g14_provoke_zero"] = np.array([i for i in range(n) if pz(i)])
+    # G15: boxes
+    rng = np.random.default_rng(15)
+    segs = []
+    for k in range(3):
+        s = np.zeros((20, 30), np.uint8)
+        y0, x0 = rng.integers(0, 10), rng.integers(0, 15)
+        s[y0:y0 + rng.integers(1, 9), x0:x0 + rng.integers(1, 14)] = 1
+        segs.append(s)
+    out["g15_segs"] = np.stack(segs)
+    boxes = [r.seg2bbox(s) for s in segs]
+    out["g15_boxes"] = np.stack(boxes)
+    out["g15_merged"] = r.merge_bbox(boxes)
+    # G16: prepare_mask_and_masked_image on PIL, numpy and tensor inputs
+    img = rng.integers(0, 256, size=(24, 32, 3)).astype(np.uint8)
+    m = (rng.random((24, 32)) > 0.6)
+    out["g16_img_u8"], out["g16_mask_bool"] = img, m
+    mk, ms, im = r.prepare_mask_and_masked_image(PIL.Image.fromarray(img), PIL.Image.fromarray((m * 255).astype(np.uint8)), 24, 32,
+                                                 return_image=True)
+    out["g16_pil_mask"], out["g16_pil_masked"], out["g16_pil_image"] = mk.numpy(), ms.numpy(), im.numpy()
+    mk, ms = r.prepare_mask_and_masked_image(img, m.astype(np.float32) * 0.7 + 0.1, 24, 32)     # soft mask -> binarised at 0.5
+    out["g16_np_mask"], out["g16_np_masked"] = mk.numpy(), ms.numpy()
+    ti = torch.tensor(img.transpose(2, 0, 1)[None].astype(np.float32) / 127.5 - 1.0)
+    tm = torch.tensor(m.astype(np.float32))[None, None]
+    mk, ms = r.prepare_mask_and_masked_image(ti.clone(), tm.clone(), 24, 32)
+    out["g16_pt_mask"], out["g16_pt_masked"] = mk.numpy(), ms.numpy()
+    errs = []
+    for bad in (lambda: r.prepare_mask_and_masked_image(ti * 2, tm, 24, 32), lambda: r.prepare_mask_and_masked_image(ti, tm * 2, 24, 32),
+                lambda: r.prepare_mask_and_masked_image(ti, m, 24, 32), lambda: r.prepare_mask_and_masked_image(None, tm, 24, 32)):
+        try:
+            bad()
+            errs.append("none")
+        except Exception as e:   # noqa: BLE001
+            errs.append(type(e).__name__)
+    out["g16_errors"] = np.array(errs)
+    np.savez_compressed(os.path.join(HERE, "inpaint_golden.npz"), **out)
+    print("wrote inpaint_golden.npz", {k: getattr(v, "shape", None) for k, v in out.items()}, errs)
+
+
+if __name__ == "__main__":
+    main()

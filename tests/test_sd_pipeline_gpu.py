@@ -1,0 +1,102 @@
+"""GPU: the inpainting loop end to end.
+(1) fixed-mask loop at a small latent (16x16) against a torch fp32 restatement of the SAME loop (UNet oracle +
+    closed-form CFG/DDIM), 3 steps, batch 2 -> latents within 5e-2 relative L2 (fp16 UNet errors compound per step);
+(2) the device mask glue against a NumPy restatement (cv2.dilate 3x3 x k == (2k+1)^2 box max), bit-exact;
+(3) the adaptive loop at full 512x512 / 64x64 latents with a deterministic synthetic mask plug-in: shapes, dtype,
+    determinism under a seeded generator, and the adapted mask is a subset of the default mask."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sd_oracle as so
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_mask_adapt_matches_numpy_box_dilation(hip_lib):
+    from coma_amd.sd import ops
+    H = W = 64
+    rng = np.random.default_rng(0)
+    seg = (rng.random((H, W)) > 0.97).astype(np.uint8)
+    dflt = np.zeros((H, W), np.uint8)
+    dflt[8:56, 16:60] = 1
+    img = rng.uniform(-1, 1, size=(3, H, W)).astype(np.float32)
+    for k, use_default in ((0, False), (3, False), (20, False), (5, True)):
+        mask_full = torch.empty(H, W, dtype=torch.uint8, device=DEV)
+        mask_lat = torch.empty(H // 8 * W // 8, dtype=torch.float16, device=DEV)
+        masked = torch.empty(H * W, 64, dtype=torch.float16, device=DEV)
+        ops.mask_adapt(torch.from_numpy(seg).to(DEV), torch.from_numpy(dflt).to(DEV), torch.from_numpy(img).to(DEV), mask_full,
+                       mask_lat, masked, H=H, W=W, dilate_iters=k, use_default=use_default, cpad=64)
+        if use_default:
+            ref = dflt.copy()
+        else:
+            pad = np.pad(seg, k)
+            dil = np.zeros_like(seg)
+            for dy in range(2 * k + 1):
+                for dx in range(2 * k + 1):
+                    dil |= pad[dy:dy + H, dx:dx + W]
+            ref = (dil & dflt).astype(np.uint8)
+        assert np.array_equal(mask_full.cpu().numpy(), ref)
+        assert np.array_equal(mask_lat.float().cpu().numpy().reshape(H // 8, W // 8), ref[::8, ::8].astype(np.float32))
+        m = masked.float().cpu().numpy().reshape(H, W, 64)
+        exp = np.where(ref[None] > 0, 0.0, img).transpose(1, 2, 0)
+        assert np.array_equal(m[:, :, :3], exp.astype(np.float16).astype(np.float32)) and float(np.abs(m[:, :, 3:]).max()) == 0.0
+
+
+def test_fixed_mask_loop_matches_fp32_restatement(hip_lib):
+    from coma_amd.sd import weights
+    from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline
+    B, HW = 2, 128                                   # 128x128 image, 16x16 latent
+    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=B, height=HW, width=HW, device=DEV, seed=0)
+    g = torch.Generator().manual_seed(5)
+    image = (torch.rand(B, 3, HW, HW, generator=g) * 2 - 1)
+    mask = torch.zeros(B, 1, HW, HW)
+    mask[:, :, 32:96, 32:96] = 1
+    pe, ne = torch.randn(B, 77, 768, generator=g).half().float(), torch.randn(B, 77, 768, generator=g).half().float()
+    lat0 = torch.randn(B, 4, 16, 16, generator=g)
+    steps, guidance = 3, 11.0
+    out = pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps,
+               guidance_scale=guidance, latents=lat0, output_type="latent", use_adaptive_mask=False).images
+    # fp32 restatement of the same loop with the pipeline's own masked-image latents (VAE parity is tested separately)
+    ustate = weights.random_state(weights.unet_shapes(), seed=0)
+    masked_lat = pipe._last_masked_lat.float().cpu().reshape(B, 16, 16, 4).permute(0, 3, 1, 2) if hasattr(pipe, "_last_masked_lat") else None
+    if masked_lat is None:
+        pytest.skip("pipeline does not expose masked latents")
+    mask_lat = mask[:, :, ::8, ::8]
+    alphas = so.ddim_alphas()
+    x = lat0.clone().double()
+    ctx = torch.cat([ne, pe])
+    for t in so.ddim_timesteps(steps):
+        inp = torch.cat([x.float(), mask_lat, masked_lat], dim=1)
+        eps = so.unet_ref(ustate, torch.cat([inp, inp]), torch.full((2 * B,), float(t)), ctx, weights.UNET_CFG)
+        e = eps[:B] + guidance * (eps[B:] - eps[:B])
+        x, _ = so.ddim_step_ref(e, t, x, alphas, num_inference_steps=steps)
+    rel = float((out.cpu().double() - x).norm() / x.norm())
+    assert rel <= 5e-2, rel
+
+
+def test_adaptive_loop_full_resolution(hip_lib):
+    from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
+    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=1, height=512, width=512, device=DEV, seed=0)
+    pipe.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
+    pipe.register_adaptive_mask_settings(default_adaptive_mask_settings(50, "p"))
+    rng = np.random.default_rng(0)
+    image = torch.tensor(rng.uniform(-1, 1, size=(1, 3, 512, 512)).astype(np.float32))
+    mask = torch.zeros(1, 1, 512, 512)
+    mask[:, :, 100:420, 150:400] = 1
+    pe, ne = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(1)), torch.zeros(1, 77, 768)
+
+    def run():
+        g = torch.Generator(device=DEV).manual_seed(3)
+        # 6 of the 50 timesteps: strength trick keeps the schedule of the last steps
+        return pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=50,
+                    strength=0.12, guidance_scale=11.0, generator=g, output_type="u8", use_adaptive_mask=True,
+                    enforce_full_mask_ratio=0.0, human_detection_thres=0.0).images
+    a = run()
+    assert tuple(a.shape) == (1, 512, 512, 3) and a.dtype == torch.uint8
+    m = pipe.last_mask_image_np
+    assert m is not None and m.shape == (512, 512) and set(np.unique(m)) <= {0.0, 1.0}
+    assert (m <= mask[0, 0].numpy()).all(), "adapted mask must stay inside the default mask"
+    b = run()
+    assert torch.equal(a, b), "same generator seed -> identical image"

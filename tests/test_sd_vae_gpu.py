@@ -1,0 +1,50 @@
+"""GPU: VAE decoder / encoder launch graphs against the torch fp32 reference of the same architecture and weights
+(oracle/sd_oracle.py), full SD-1.5 widths (128/256/512/512) at a 64x64 image (8x8 latent) so the host reference is
+quick.  Tolerance: relative L2 <= 2e-2, cosine >= 0.999 (fp16 activations through ~30 layers)."""
+import pytest
+import torch
+
+from oracle import sd_oracle as so
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def vae_setup(hip_lib):
+    from coma_amd.sd import weights
+    from coma_amd.sd.vae import HipAutoencoderKL
+    state = weights.random_state(weights.vae_shapes(), seed=3)
+    return state, weights.VAE_CFG, HipAutoencoderKL(state, batch=2, height=64, width=64, device=DEV)
+
+
+def _metrics(out, ref):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    return float((out - ref).norm() / ref.norm()), float(torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0))
+
+
+def test_decoder(vae_setup):
+    state, cfg, vae = vae_setup
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0)).half().float()
+    out = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert tuple(out.shape) == (2, 3, 64, 64)
+    rel, cos = _metrics(out, so.vae_decode_ref(state, z, cfg))
+    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+
+
+def test_encoder_moments_and_sampling(vae_setup):
+    state, cfg, vae = vae_setup
+    from coma_amd.sd import ops
+    img = (torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1).half().float()
+    dist = vae.encode(img.to(DEV)).latent_dist
+    ref = so.vae_encode_ref(state, img, cfg)                       # [2, 8, 8, 8]
+    mode = dist.mode()
+    rel, cos = _metrics(mode, ref[:, :4])
+    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    # sampling formula on the kernel's own moments: (mean + exp(0.5*clamp(logvar)) * noise) * scale
+    mom = vae.enc.moments.float().reshape(2, 64, 64)[:, :, :8]
+    noise = torch.randn(2, 64, 4, generator=torch.Generator().manual_seed(2))
+    lat = torch.empty(2, 64, 4, device=DEV)
+    ops.vae_sample(vae.enc.moments, 64, noise.to(DEV), 0.18215, 128, lat32=lat)
+    exp = (mom[:, :, :4].cpu() + torch.exp(0.5 * mom[:, :, 4:].cpu().clamp(-30, 20)) * noise) * 0.18215
+    assert float((lat.cpu() - exp).abs().max()) <= 1e-5 * float(exp.abs().max()) + 1e-6
