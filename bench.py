@@ -56,17 +56,179 @@ def cpu_baseline(seconds_budget=25.0):
                       f"intermediates as in the reference), {dt:.1f} s; host has {os.cpu_count()} logical cores"}
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+
+
+def cpu_baseline_inpaint():
+    """torch fp32 CPU restatement of the UNet (oracle/sd_oracle.py) on the host cores: ONE forward at batch 2
+    (cond + uncond of one image, 64x64 latents), extrapolated to 50 steps; VAE encode/decode (~4 % of the flops) ignored."""
+    from coma_amd.sd import weights
+    from oracle import sd_oracle as so
+    state = weights.random_state(weights.unet_shapes(), seed=0)
+    g = torch.Generator().manual_seed(0)
+    x, ctx, t = torch.randn(2, 9, 64, 64, generator=g), torch.randn(2, 77, 768, generator=g), torch.tensor([961.0, 961.0])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        so.unet_ref(state, x, t, ctx, weights.UNET_CFG)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / (50 * dt), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 UNet forward at batch 2 (one image, cond+uncond, 64x64 latents) through oracle/sd_oracle.py (torch fp32 "
+                      f"CPU, {torch.get_num_threads()} threads): {dt:.2f} s, EXTRAPOLATED x50 steps; VAE ignored"}
+
+
+def bench_inpaint(args, dev, world, rank):
+    """BASELINE.json config 2: SD-1.5 inpaint 512x512, 50 DDIM steps, batch 8, fixed mask, CFG 11 (UNet batch 16),
+    seeded random fp16 weights of the SD-1.5-inpainting shapes, synthetic prompt embeddings / image / mask.  One step =
+    one whole batch: masked-image VAE encode, 50 x (UNet graph + CFG/DDIM kernel), VAE decode to uint8."""
+    from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline
+    B = args.images
+    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=B, height=512, width=512, device=dev, seed=0)
+    g = torch.Generator().manual_seed(100 + rank)
+    image = torch.rand(B, 3, 512, 512, generator=g) * 2 - 1
+    mask = torch.zeros(B, 1, 512, 512)
+    mask[:, :, 128:384, 128:384] = 1                       # centred 256^2 box (SURVEY.md 8d, cfg 2)
+    pe, ne = torch.randn(B, 77, 768, generator=g), torch.randn(B, 77, 768, generator=g)
+    gens = torch.Generator(device=dev)
+
+    def step(seed):
+        gens.manual_seed(seed)
+        return pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=50,
+                    strength=1.0, guidance_scale=11.0, generator=gens, output_type="u8", use_adaptive_mask=False).images
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(1000 + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert out.shape == (B, 512, 512, 3) and out.dtype == torch.uint8
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    res = None
+    if rank == 0:
+        # roofline of the dominant kernel (the implicit-GEMM conv/linear kernel): per-launch HIP-event timing of the
+        # UNet launch list, outside the timed region, same process
+        prof = pipe.unet.g.profile(reps=2)
+        gemm = [(fl, ms) for tag, fl, ms in prof if tag.startswith("gemm")]
+        attn = [(fl, ms) for tag, fl, ms in prof if tag.startswith("attention")]
+        tot_ms = sum(ms for _, _, ms in prof)
+        g_fl, g_ms = sum(f for f, _ in gemm), sum(m for _, m in gemm)
+        flops_img = (pipe.unet.g.flops * 50 + pipe.vae.dec.g.flops + pipe.vae.enc.g.flops) / B
+        value = world * B * args.steps / dt
+        res = {
+            "metric": "HOI images/sec (50-step SD-1.5 inpaint, 512x512, fixed mask, CFG; BASELINE metric part 1)",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SD-1.5-inpaint 512x512, 50 DDIM steps, batch {B} images per GPU per step (UNet batch {2 * B}), "
+                                   "fixed centred 256^2 mask, guidance 11, 1 VAE encode + 1 VAE decode per image "
+                                   "(BASELINE.json config 2); random-init weights of the SD-1.5-inpainting architecture",
+                       "parallelism": f"independent image batches on {world} GPU(s), no collective"},
+            "tflop_per_image": flops_img / 1e12, "achieved_tflops_whole_loop": value / world * flops_img / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "sd::conv_gemm_kernel<128> (all conv3x3/1x1/linear launches of one UNet forward)",
+                         "achieved": g_fl / g_ms / 1e9, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, "launches": len(gemm),
+                         "avg_launch_ms": g_ms / len(gemm), "flops_per_forward": g_fl, "traffic": None,
+                         "unet_forward_ms_eager_sum": tot_ms,
+                         "attention": {"achieved": sum(f for f, _ in attn) / sum(m for _, m in attn) / 1e9, "unit": "TFLOP/s"}},
+        }
+    del pipe
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_contact(args, dev, world, rank):
+    from utils.coma import ComA
+    H, O, N, S = args.human_res, args.obj_res, args.normal_res, args.samples
+    coma = ComA(H, O, N, 0, proximity_settings=dict(spatial_grid_size=0.07, spatial_grid_thres=0.03),
+                normal_gaussian_sigma=0.25, eps=1e-10, device=dev)
+    # synthetic inputs of config 4's shape, generated on the device (resident in HBM before the timed region)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    lo = torch.tensor([-0.3, -0.15, -0.85], device=dev)
+    hi = torch.tensor([0.3, 0.15, 0.85], device=dev)
+    hv = lo + (hi - lo) * torch.rand([S, H, 3], generator=g, device=dev)
+    hn = torch.nn.functional.normalize(torch.randn([S, H, 3], generator=g, device=dev), dim=-1)
+    g0 = torch.Generator(device=dev).manual_seed(99)           # the object is the same on every rank
+    on = torch.nn.functional.normalize(torch.randn([O, 3], generator=g0, device=dev), dim=-1)
+    ov = on * 0.2 + torch.tensor([0.0, -0.15, 0.3], device=dev)
+    steps, warmup = args.contact_steps, 2
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        coma.accumulate_device(hv, hn, ov, on)
+        if world > 1:
+            coma.all_reduce()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        coma.accumulate_device(hv, hn, ov, on)      # same stream as the events (torch current stream)
+        ev[i][1].record()
+        if world > 1:
+            coma.all_reduce()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank != 0:
+        return None
+    flops = S * H * O * flop_per_pair(N)
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    alg_bytes = 24 * (S * H + O) + (16 * N + 24) * H * O
+    return {
+        "metric": "vertex-pair contacts/sec (ComA K1-K3 accumulation; BASELINE metric part 2)",
+        "value": world * S * H * O * steps / dt, "unit": "vertex-pair contacts/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ComA contact+orientation accumulation, H={H} SMPL-X verts x O={O} object points x "
+                               f"N={N} bins, {S} samples per GPU per step (BASELINE.json config 4 per-GPU slice)"
+                               + (", + RCCL all-reduce(SUM) of the ComA state every step" if world > 1 else ""),
+                   "parallelism": f"samples sharded over {world} GPU(s)"},
+        "roofline": {"bound": "fp32_valu", "kernel": "coma::contact_accumulate_kernel", "achieved": achieved,
+                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
+                     "kernel_ms": kern_ms, "flop_per_pair": flop_per_pair(N), "algorithmic_hbm_bytes": alg_bytes,
+                     "traffic": CONTACT_PMC_TRAFFIC_BYTES if (S, H, O, N) == (64, 10475, 180, 250) else None,
+                     "traffic_source": "profiles/r01_contact_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
+    }
+
+
+# HBM bytes per contact_accumulate_kernel launch from the committed rocprofv3 PMC pass (profiles/r01_contact_pmc.txt):
+# FETCH_SIZE 1.91553e6 KiB (x2: gfx950 reports half of a coalesced stream) + WRITE_SIZE 3.71135e6 KiB
+CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91553e6 + 3.71135e6) * 1024)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="contact", choices=["contact"])
-    ap.add_argument("--samples", type=int, default=64, help="samples per GPU per step")
+    ap.add_argument("--steps", type=int, default=3, help="timed steps of the primary workload (one step = one image batch)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="inpaint", choices=["inpaint", "contact"],
+                    help="primary workload (the JSON line's metric/value); the other one is reported under 'secondary'")
+    ap.add_argument("--images", type=int, default=8, help="images per GPU per step (inpaint)")
+    ap.add_argument("--samples", type=int, default=64, help="samples per GPU per step (contact)")
+    ap.add_argument("--contact-steps", type=int, default=10)
     ap.add_argument("--human-res", type=int, default=10475)
     ap.add_argument("--obj-res", type=int, default=180)
     ap.add_argument("--normal-res", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -80,73 +242,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from utils.coma import ComA
-    H, O, N, S = args.human_res, args.obj_res, args.normal_res, args.samples
-    coma = ComA(H, O, N, 0, proximity_settings=dict(spatial_grid_size=0.07, spatial_grid_thres=0.03),
-                normal_gaussian_sigma=0.25, eps=1e-10, device=dev)
-
-    # synthetic inputs of config 4's shape, generated on the device (resident in HBM before the timed region)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    lo = torch.tensor([-0.3, -0.15, -0.85], device=dev)
-    hi = torch.tensor([0.3, 0.15, 0.85], device=dev)
-    hv = lo + (hi - lo) * torch.rand([S, H, 3], generator=g, device=dev)
-    hn = torch.nn.functional.normalize(torch.randn([S, H, 3], generator=g, device=dev), dim=-1)
-    g0 = torch.Generator(device=dev).manual_seed(99)           # the object is the same on every rank
-    on = torch.nn.functional.normalize(torch.randn([O, 3], generator=g0, device=dev), dim=-1)
-    ov = on * 0.2 + torch.tensor([0.0, -0.15, 0.3], device=dev)
-
-    def step():
-        coma.accumulate_device(hv, hn, ov, on)
-        if world > 1:
-            coma.all_reduce()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        coma.accumulate_device(hv, hn, ov, on)      # same stream as the events (torch current stream)
-        ev[i][1].record()
-        if world > 1:
-            coma.all_reduce()
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
-
+    if args.workload == "contact":
+        args.contact_steps = args.steps
+    inp = None if (args.workload == "contact" and args.no_secondary) else bench_inpaint(args, dev, world, rank)
+    con = None if (args.workload == "inpaint" and args.no_secondary) else bench_contact(args, dev, world, rank)
     if rank == 0:
-        pairs_per_step = world * S * H * O
-        value = pairs_per_step * args.steps / dt
-        flops = S * H * O * flop_per_pair(N)
-        achieved = flops / (kern_ms * 1e-3) / 1e12
-        out = {
-            "metric": "vertex-pair contacts/sec (ComA K1-K3 accumulation; BASELINE metric part 2)",
-            "value": value, "unit": "vertex-pair contacts/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ComA contact+orientation accumulation, H={H} SMPL-X verts x O={O} object points x "
-                                   f"N={N} bins, {S} samples per GPU per step (BASELINE.json config 4 per-GPU slice)"
-                                   + (", + RCCL all-reduce(SUM) of the ComA state every step" if world > 1 else ""),
-                       "parallelism": f"samples sharded over {world} GPU(s)"},
-            "roofline": {"bound": "fp32_valu", "kernel": "contact_accumulate_kernel", "achieved": achieved,
-                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
-                         "kernel_ms": kern_ms, "flop_per_pair": flop_per_pair(N),
-                         "algorithmic_hbm_bytes": 24 * (S * H + O) + (16 * N + 24) * H * O,
-                         "traffic": None},
-        }
+        primary, secondary = (inp, con) if args.workload == "inpaint" else (con, inp)
+        out = dict(primary)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline_inpaint() if args.workload == "inpaint" else cpu_baseline()
+        if secondary is not None:
+            sec = dict(secondary)
+            if world == 1 and not args.no_cpu_baseline:
+                sec["cpu_baseline"] = cpu_baseline() if args.workload == "inpaint" else cpu_baseline_inpaint()
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
