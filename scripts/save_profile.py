@@ -3,9 +3,8 @@
 usage: python scripts/save_profile.py <tag> [round]"""
 import csv
 import glob
-import io
 import os
-import subprocess
+import shutil
 import sys
 
 tag = sys.argv[1]
@@ -18,10 +17,14 @@ for f in glob.glob(os.path.join(root, "trace", "*kernel_stats.csv")):
         for row in csv.reader(fh):
             row[0] = row[0][:120]
             w.writerow(row)
-txt = subprocess.run([sys.executable, "scripts/summarize_pmc.py", root], capture_output=True, text=True).stdout
-keep = [l for l in txt.splitlines() if l.startswith("==") or "coma::" in l or "sd::" in l]
-open(os.path.join("profiles", f"{rnd}_{tag}_pmc.txt"), "w").write(
-    "# rocprofv3 --pmc passes (one counter group per pass), mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB.\n"
-    "# gfx950: FETCH_SIZE reads 1/2 of the bytes of a coalesced stream (MI355X_MICROARCH.md, HBM) -> double it.\n"
-    + "\n".join(keep) + "\n")
-print("\n".join(keep))
+src = os.path.join(root, "pmc_summary.txt")
+if os.path.exists(src):
+    keep = [l for l in open(src).read().splitlines() if l.startswith("==") or "coma::" in l or "sd::" in l or "_ZN2sd" in l]
+    open(os.path.join("profiles", f"{rnd}_{tag}_pmc.txt"), "w").write(
+        "# rocprofv3 --pmc passes (one counter group per pass), mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB.\n"
+        "# gfx950: FETCH_SIZE reads 1/2 of the bytes of a coalesced stream (MI355X_MICROARCH.md, HBM) -> double it.\n"
+        + "\n".join(keep) + "\n")
+j = os.path.join(root, "bench_line_under_profiler.json")
+if os.path.exists(j):
+    shutil.copy(j, os.path.join("profiles", f"{rnd}_{tag}_bench_line_under_profiler.json"))
+print(open(os.path.join("profiles", f"{rnd}_{tag}_kernel_stats.csv")).read()[:1500])
