@@ -258,6 +258,18 @@ def main():
     refos.export(os.path.join(HERE, "ref_occupancy_small.pickle"))
     out["g7b_occ_grid"] = copy.deepcopy(refos).return_aggregated_spatial_grids().numpy()
 
+    # ---------------- presets: the reference's hyper-parameter tables as data ----------------
+    import importlib.util, json
+    def _load(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    rq = _load(os.path.join(REF, "constants/coma/qual.py"), "_ref_qual").QUAL_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT
+    rn = _load(os.path.join(REF, "constants/coma/quant.py"), "_ref_quant").QUANT_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT
+    with open(os.path.join(HERE, "presets.json"), "w") as fh:
+        json.dump({"qual": rq, "quant": rn}, fh, indent=1, sort_keys=True)
+
     # ---------------- G11 nearest vertex ----------------
     rng = np.random.default_rng(11)
     verts = rng.normal(size=(500, 3))

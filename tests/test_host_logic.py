@@ -162,3 +162,27 @@ def test_two_rank_all_reduce_over_gloo(tmp_path):
     for r, p in enumerate(procs):
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0 and f"RANK_OK {r}" in out, out
+
+
+def test_presets_match_reference_tables():
+    import json
+    from constants.coma.qual import QUAL_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT as Q
+    from constants.coma.quant import QUANT_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT as N
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "presets.json")))
+    norm = lambda d: json.loads(json.dumps(d))            # tuples -> lists, as stored
+    for k, v in ref["qual"].items():
+        assert norm(Q[k]) == v, k
+    assert norm(N) == ref["quant"]
+    # aliases for the keys scripts/learn_coma.sh passes
+    assert Q["qual:backpack_human"] == Q["qual:backpack_human_contact"]
+
+
+def test_inference_cli_flags_match_reference():
+    """Same argparse surface as the reference's src/coma/inference.py:150-161."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "src", "coma", "inference.py"), "--help"], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--supercategory", "--category", "--coma_path", "--visualize_type", "--smplx_downsample_pth",
+                 "--asset_downsample_pth", "--hyperparams_key", "--output_dir", "--seed"):
+        assert flag in out.stdout
