@@ -115,6 +115,14 @@ int coma_occupancy_reduce(float* counts, const uint8_t* select, int H, int64_t R
 int coma_nearest_vertex_i64(const double* points, const double* verts, int P, int V, int64_t* idx,
                             void* stream);
 
+/* Sample ingestion: area-weighted vertex normals of S posed meshes with one shared topology.
+ * replaces: open3d TriangleMesh.compute_vertex_normals() + normalize_vectors_np in
+ *           prepare_affordance_extraction_inputs (utils/coma.py:672-686).
+ * verts f64 [S,V,3]; faces i32 [F,3]; vf_offsets i32 [V+1] / vf_faces i32 [3F]: vertex -> incident faces (CSR, ascending
+ * face index: the order in which open3d accumulates); eps >= 0 applies the reference's second v/(|v|+eps); normals f64 [S,V,3]. */
+int coma_vertex_normals_f64(const double* verts, const int32_t* faces, const int32_t* vf_offsets, const int32_t* vf_faces,
+                            int S, int V, int F, double eps, double* normals, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

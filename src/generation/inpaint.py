@@ -1,0 +1,226 @@
+"""Inpaint a human into every rendered view with the adaptive-mask SD loop on MI355X.
+
+CLI surface and host behaviour of the reference's ``src/generation/inpaint.py``:
+  * flags and module-level defaults (:356-411) -- the shell wrapper reads the constants by importing this module;
+  * work list = render x valid mask x prompt x viewpoint augmentation x inpaint_id (:187-269), per-category /
+    per-view override chain for ddim_steps / cfg_scale / strength / enforce_full_mask_ratio / human_detection_thres
+    (:253-267), sorted by result path, per-process slice ``sub = len // n + 1`` (:271-278);
+  * per item: device generator seeded with ``inpaint_id`` (:308-309), skip-if-exists (:294-297), PNG output (:352).
+The pipeline is :class:`coma_amd.sd.pipeline.AdaptiveMaskInpaintPipeline` (HIP kernels).  Model weights, the CLIP text
+encoder and PointRend are third-party assets that cannot be provisioned offline: ``--weights_dir`` points at a
+diffusers-format checkpoint directory when one exists, otherwise seeded random weights are used (pipeline smoke /
+throughput runs) and prompts are embedded by a deterministic hash encoder; ``--mask_model synthetic`` selects the
+built-in stand-in for PointRend.
+"""
+import argparse
+import hashlib
+import os
+import pickle
+import sys
+from glob import glob
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from constants.generation.inpaint_config import (ALLOWED_VIEWPOINT_AUGMENTATIONS, CATEGORY2ASSET, HF_MODEL_KEYS,  # noqa: E402
+                                                 SC2DIFFUSERCONFIG, SCV2DIFFUSERCONFIG)
+from constants.metadata import DEFAULT_SEED  # noqa: E402
+
+""" HYPERPARAMS (read by scripts/generation/inpaint.sh through `python -c`) """
+NUM_IMG_PER_COMBINATION = 10
+ASSET_RENDER_DIR = "results/generation/asset_renders"
+ASSET_MASK_DIR = "results/generation/asset_masks"
+ASSET_SEG_DIR = "results/generation/asset_segs"
+PROMPTS_DIR = "results/generation/prompts"
+SAVE_DIR = "results/generation/inpaintings"
+LDM_MODEL_KEY = "realisticvision"
+ADAPTIVE_MASK_MODEL_TYPE = "p"
+DEFAULT_CFG_SCALE = 11.0
+DEFAULT_STRENGTH = 0.98
+DEFAULT_DDIM_STEPS = 50
+DEFAULT_POINTREND_THRESHOLD = 0.2
+DEFAULT_ENFORCE_FULL_MASK_RATIO = 0.0
+DEFAULT_HUMAN_DETECTION_THRES = 0.015
+NEGATIVE_PROMPT = "worst quality, normal quality, low quality, bad anatomy, artifacts, blurry, cropped, watermark, greyscale, nsfw"
+SKIP_DONE = True
+
+
+def prepare_asset_render_pths(asset_render_dir, supercategories, categories):
+    """Render paths {dir}/{SC}/{C}/{asset}/{view}.png of registered assets, optionally filtered (utils/prepare_renders.py:6-32)."""
+    out = []
+    for pth in sorted(glob(f"{asset_render_dir}/*/*/*/*.png")):
+        sc_str, c_str, asset_id, _ = pth.split("/")[-4:]
+        sc, c = sc_str.replace(":", "/"), c_str.replace(":", "/")
+        if asset_id not in CATEGORY2ASSET.get(sc, {}).get(c, []):
+            continue
+        if supercategories is not None and sc_str.lower() not in supercategories:
+            continue
+        if categories is not None and c_str.lower() not in categories:
+            continue
+        out.append(pth)
+    return out
+
+
+def resolve_setting(supercategory, category, view_id, key, default):
+    """view override -> category override -> CLI default."""
+    cat_cfg = SC2DIFFUSERCONFIG[supercategory][category]
+    view_cfg = SCV2DIFFUSERCONFIG[supercategory][category].get(view_id, cat_cfg)
+    return view_cfg.get(key, cat_cfg.get(key, default))
+
+
+def build_work_list(asset_render_pths, asset_mask_dir, asset_seg_dir, prompts_dir, save_dir, num_img_per_combination, negative_prompt,
+                    defaults, use_visualizer=False, debug=False):
+    items = []
+    for render in asset_render_pths:
+        sc_str, c_str, asset_id, view_ext = render.split("/")[-4:]
+        sc, c = sc_str.replace(":", "/"), c_str.replace(":", "/")
+        view_id, ext = view_ext.split(".")
+        assert ext == "png", "Rendering must have '.png' extension"
+        meta = f"{asset_mask_dir}/{sc_str}/{c_str}/{asset_id}/{view_id}.pickle"
+        if os.path.exists(meta):
+            with open(meta, "rb") as fh:
+                mask_ids = pickle.load(fh)["valid_mask_ids"]
+        else:
+            assert debug, "THIS SHOULD BE ONLY ALLOWED IN DEBUGGING MODE. RUN STEP2 PRIOR"
+            mask_ids = [p.split("/")[-1].split(".")[0] for p in sorted(glob(f"{asset_mask_dir}/{sc_str}/{c_str}/{asset_id}/{view_id}/*"))]
+        with open(f"{prompts_dir}/{sc}/{c}/{asset_id}/prompts.pickle", "rb") as fh:
+            prompts = pickle.load(fh)["prompts"]
+        augs = SCV2DIFFUSERCONFIG[sc][c].get(view_id, SC2DIFFUSERCONFIG[sc][c]).get("view_text", ["original"])
+        assert type(augs) == list
+        for mask_id in mask_ids:
+            for prompt in prompts:
+                for aug in augs:
+                    assert aug in ALLOWED_VIEWPOINT_AUGMENTATIONS, f"viewpoint augmentation: '{aug}' not allowed"
+                    if aug == "original":
+                        text = prompt
+                    elif aug == ", full body":
+                        text = prompt + aug
+                    else:
+                        continue
+                    rdir = f"{save_dir}/{sc_str}/{c_str}/{asset_id}/{view_id}/{mask_id}/{text}"
+                    for inpaint_id in range(num_img_per_combination):
+                        item = dict(asset_render_pth=render, asset_mask_pth=f"{asset_mask_dir}/{sc_str}/{c_str}/{asset_id}/{view_id}/{mask_id}.png",
+                                    asset_seg_pth=f"{asset_seg_dir}/{sc_str}/{c_str}/{asset_id}/{view_id}.png", result_save_dir=rdir,
+                                    result_save_pth=f"{rdir}/{inpaint_id:06}.png",
+                                    visualization_save_dir=f"{rdir}/{inpaint_id:06}" if use_visualizer else None,
+                                    inpaint_id=inpaint_id, input_prompt=text, input_negprompt=negative_prompt)
+                        for key, default in defaults.items():
+                            item[key] = resolve_setting(sc, c, view_id, key, default)
+                        items.append(item)
+    return sorted(items, key=lambda x: x["result_save_pth"])
+
+
+def slice_for_process(items, parallel_idx, parallel_num):
+    sub = len(items) // parallel_num + 1          # the reference's (unbalanced) rule
+    return items[parallel_idx * sub:(parallel_idx + 1) * sub]
+
+
+class HashTextEncoder:
+    """Deterministic stand-in for CLIP's text tower (weights unreachable offline): prompt -> [1,77,768] unit-variance noise."""
+
+    def __call__(self, prompt):
+        import torch
+        seed = int.from_bytes(hashlib.sha256(prompt.encode()).digest()[:8], "little") % (2**63)
+        return torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(seed))
+
+
+def set_pipeline(ldm_model_key, adaptive_mask_model_type, default_ddim_steps, weights_dir=None, mask_model="synthetic", device="cuda"):
+    from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
+    assert ldm_model_key in HF_MODEL_KEYS
+    if weights_dir:
+        from coma_amd.sd.scheduler import DDIMScheduler
+        from coma_amd.sd.unet import HipUNet2DConditionModel
+        from coma_amd.sd.vae import HipAutoencoderKL
+        from coma_amd.sd.weights import load_safetensors
+        unet = HipUNet2DConditionModel(load_safetensors(f"{weights_dir}/unet/diffusion_pytorch_model.safetensors"), batch=2, device=device)
+        vae = HipAutoencoderKL(load_safetensors(f"{weights_dir}/vae/diffusion_pytorch_model.safetensors"), batch=1, device=device)
+        sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
+        pipeline = AdaptiveMaskInpaintPipeline(vae, unet, sch, device=device)
+    else:
+        pipeline = AdaptiveMaskInpaintPipeline.from_random(batch_size=1, device=device)
+    pipeline.scheduler.set_timesteps(default_ddim_steps)
+    if mask_model != "synthetic":
+        raise NotImplementedError("PointRend / SAM weights cannot be provisioned offline; register your own callable instead")
+    pipeline.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
+    pipeline.register_adaptive_mask_settings(default_adaptive_mask_settings(default_ddim_steps, adaptive_mask_model_type))
+    return pipeline
+
+
+def inpaint_human(args):
+    import torch
+    from PIL import Image
+    renders = prepare_asset_render_pths(args.asset_render_dir, args.supercategories, args.categories)
+    defaults = dict(ddim_steps=args.default_ddim_steps, cfg_scale=args.default_cfg_scale, strength=args.default_strength,
+                    enforce_full_mask_ratio=args.default_enforce_full_mask_ratio, human_detection_thres=args.default_human_detection_thres)
+    items = build_work_list(renders, args.asset_mask_dir, args.asset_seg_dir, args.prompts_dir, args.save_dir, args.num_img_per_combination,
+                            args.negative_prompt, defaults, use_visualizer=args.use_visualizer)
+    items = slice_for_process(items, args.parallel_idx, args.parallel_num)
+    pipeline = set_pipeline(args.ldm_model_key, args.adaptive_mask_model_type, args.default_ddim_steps, args.weights_dir, args.mask_model)
+    encode = HashTextEncoder()
+    for it in items:
+        os.makedirs(it["result_save_dir"], exist_ok=True)
+        if os.path.exists(it["result_save_pth"]) and args.skip_done:
+            if args.verbose:
+                print(f"Continueing {it['result_save_pth']} Since Already Done!")
+            continue
+        init_image = Image.open(it["asset_render_pth"]).convert("RGB")
+        default_mask = Image.open(it["asset_mask_pth"]).convert("L")
+        generator = torch.Generator(device="cuda")
+        generator.manual_seed(it["inpaint_id"])
+        result = pipeline(prompt_embeds=encode(it["input_prompt"]), negative_prompt_embeds=encode(it["input_negprompt"]),
+                          image=init_image, default_mask_image=default_mask, guidance_scale=it["cfg_scale"], strength=it["strength"],
+                          use_adaptive_mask=args.adaptive_mask_model_type != "baseline", generator=generator,
+                          num_inference_steps=it["ddim_steps"], enforce_full_mask_ratio=it["enforce_full_mask_ratio"],
+                          visualization_save_dir=it["visualization_save_dir"], human_detection_thres=it["human_detection_thres"]).images[0]
+        result.save(it["result_save_pth"])
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--num_img_per_combination", type=int, default=NUM_IMG_PER_COMBINATION)
+    p.add_argument("--supercategories", type=str, nargs="+")
+    p.add_argument("--categories", type=str, nargs="+")
+    p.add_argument("--asset_render_dir", type=str, default=ASSET_RENDER_DIR)
+    p.add_argument("--asset_mask_dir", type=str, default=ASSET_MASK_DIR)
+    p.add_argument("--asset_seg_dir", type=str, default=ASSET_SEG_DIR)
+    p.add_argument("--prompts_dir", type=str, default=PROMPTS_DIR)
+    p.add_argument("--save_dir", type=str, default=SAVE_DIR)
+    p.add_argument("--ldm_model_key", type=str, default=LDM_MODEL_KEY, choices=HF_MODEL_KEYS.keys())
+    p.add_argument("--adaptive_mask_model_type", type=str, choices=["baseline", "p", "ps", "ps_ae", "s_pdb_ae", "s_db_ae", "s_ab_ae"],
+                   default=ADAPTIVE_MASK_MODEL_TYPE)
+    p.add_argument("--default_cfg_scale", type=float, default=DEFAULT_CFG_SCALE)
+    p.add_argument("--default_strength", type=float, default=DEFAULT_STRENGTH)
+    p.add_argument("--default_ddim_steps", type=int, default=DEFAULT_DDIM_STEPS)
+    p.add_argument("--default_pointrend_threshold", type=float, default=DEFAULT_POINTREND_THRESHOLD)
+    p.add_argument("--default_enforce_full_mask_ratio", type=float, default=DEFAULT_ENFORCE_FULL_MASK_RATIO)
+    p.add_argument("--default_human_detection_thres", type=float, default=DEFAULT_HUMAN_DETECTION_THRES)
+    p.add_argument("--enable_sam_multitask_output", action="store_true")
+    p.add_argument("--negative_prompt", type=str, default=NEGATIVE_PROMPT)
+    p.add_argument("--enable_safety_checker", action="store_true")
+    p.add_argument("--use_visualizer", action="store_true")
+    p.add_argument("--skip_done", action="store_true", default=SKIP_DONE)
+    p.add_argument("--verbose", action="store_true")
+    p.add_argument("--seed", type=int, default=DEFAULT_SEED)
+    p.add_argument("--parallel_num", type=int, default=1)
+    p.add_argument("--parallel_idx", type=int, default=0)
+    # additions (not in the reference): offline asset provisioning
+    p.add_argument("--weights_dir", type=str, default=None, help="diffusers-format checkpoint dir; default: seeded random weights")
+    p.add_argument("--mask_model", type=str, default="synthetic")
+    return p
+
+
+if __name__ == "__main__":
+    args = build_parser().parse_args()
+    if args.supercategories is not None:
+        args.supercategories = [s.lower() for s in args.supercategories]
+    if args.categories is not None:
+        args.categories = [c.lower() for c in args.categories]
+    if args.adaptive_mask_model_type == "baseline":
+        print("\n\n############################# RUNNING BASELINE MODE!! #############################\n\n")
+        args.save_dir = f"{args.save_dir}_noadaptivemask"
+    from utils.reproducibility import seed_everything
+    seed_everything(args.seed)
+    inpaint_human(args)

@@ -82,3 +82,80 @@ def test_occupancy_output(tmp_path, hip_lib):
     field = ref.aggregated_grid()
     assert np.array_equal(d["prob_field"], 0.7 * (field / field.max()))
     assert d["spatial_grid_metadata"]["N_x"] == 10 and abs(d["spatial_grid_metadata"]["voxel_size"] - 0.24) < 1e-12
+
+
+def _mesh(rng, V=80):
+    """Random closed-ish triangle soup over V vertices on a bumpy sphere (every vertex used)."""
+    pts = rng.normal(size=(V, 3))
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    from scipy.spatial import ConvexHull
+    hull = ConvexHull(pts)
+    return pts * 0.4, hull.simplices.astype(np.int64)
+
+
+def test_vertex_normals_kernel_vs_oracle(hip_lib):
+    from coma_amd.ingest import vertex_normals_batch
+    rng = np.random.default_rng(0)
+    base, faces = _mesh(rng)
+    verts = np.stack([base + rng.normal(scale=0.01, size=base.shape) for _ in range(3)])
+    got = vertex_normals_batch(verts, faces, device=DEV)
+    for s in range(3):
+        ref = orc.vertex_normals(verts[s], faces)
+        assert np.abs(got[s] - ref).max() <= 1e-14
+    assert np.allclose(np.linalg.norm(got, axis=-1), 1.0)
+
+
+def test_extract_coma_cli_end_to_end(tmp_path, hip_lib):
+    """results/ tree in the reference's formats -> extract_coma -> pickle + human_contact.npy, checked against the oracle
+    fed with oracle vertex normals; a sentinel sample and a post-filtered sample must be ignored."""
+    import json
+    from constants.coma.qual import QUAL_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT as Q
+    from src.coma.extract_coma import run_affordance_extraction
+    rng = np.random.default_rng(5)
+    key = "qual:backpack_human_contact"
+    hp = dict(Q[key], human_res="20", enable_postfilter=True)
+    base, faces = _mesh(rng)
+    V, H, O = len(base), 20, 6
+    hidx = list(rng.choice(V, size=H, replace=False))
+    opts = base[hidx[:O]] / 0.4                                    # object points hugging six of the sampled body vertices
+    obj_meta = dict(N=O, N_raw=O, downsample_indices=list(range(O)), downsampled_pcd_points_raw=opts * 0.41,
+                    downsampled_pcd_normal_raw=-opts.copy(), obj_vertices_original=opts * 0.41, obj_faces_original=np.zeros((1, 3), int),
+                    obj_vertex_normals_original=-opts.copy())
+    (tmp_path / "mesh").mkdir()
+    pickle.dump(dict(N=H, N_raw=H, downsample_indices=hidx), open(tmp_path / "mesh" / "smplx_star_downsampled_20.pickle", "wb"))
+    ad = tmp_path / "asset_ds" / "BEHAVE" / "backpack"
+    ad.mkdir(parents=True)
+    pickle.dump(obj_meta, open(ad / "behave_asset_180.pickle", "wb"))
+    prompt = "1 person wears the backpack"
+    sd = tmp_path / "hs" / "BEHAVE" / "backpack" / "behave_asset" / "view:00000" / "00001" / prompt
+    sd.mkdir(parents=True)
+    ref = orc.ComAOracle(H, O, hp["normal_res"], hp["spatial_grid_size"], hp["spatial_grid_thres"], sigma=hp["normal_gaussian_sigma"], eps=hp["eps"])
+    listed = []
+    for i in range(5):
+        verts = base + rng.normal(scale=0.004, size=base.shape)
+        payload = "TOO LITTLE INLIERS" if i == 3 else dict(verts=verts, faces=faces, IoU=0.9, num_inliers=5)
+        pickle.dump(payload, open(sd / f"{i:06}.pickle", "wb"))
+        if i in (0, 1, 2):                      # sample 4 is valid but not listed by the post-filter, sample 3 is a sentinel
+            listed.append(["view:00000", "00001", prompt, f"{i:06}"])
+            n = orc.vertex_normals(verts, faces)
+            n = n / (np.sqrt((n**2).sum(-1, keepdims=True)) + hp["eps"])
+            ref.aggregate_sample(verts[hidx], n[hidx], obj_meta["downsampled_pcd_points_raw"], obj_meta["downsampled_pcd_normal_raw"])
+    pf = tmp_path / "pf" / "BEHAVE" / "backpack" / "behave_asset"
+    pf.mkdir(parents=True)
+    json.dump(listed, open(pf / f"{prompt}.json", "w"))
+    done = run_affordance_extraction(None, None, None, str(tmp_path / "cam"), str(tmp_path / "params"), str(tmp_path / "asset_ds"),
+                                     str(tmp_path / "pf"), str(tmp_path / "hs"), str(tmp_path / "coma"), str(tmp_path / "aff"),
+                                     str(tmp_path / "mesh"), hp, key, 3.0, False, device=DEV)
+    assert len(done) == 1
+    _, save_pth, out = done[0]
+    state = pickle.load(open(save_pth, "rb"))
+    assert state["used_count"] == 3
+    assert np.array_equal(state["significant_contact_count"], ref.cnt)
+    assert orc.max_rel_err(state["prob_grid_canon_human_wrt_obj"], ref.P_h_wrt_o) <= 1e-3       # exported BEFORE normalisation
+    agg, _, _ = ref.aggregated_contact("human", hp["significant_contact_ratio"])
+    got = np.load(os.path.join(out, "human_contact.npy"))
+    exp = agg / agg.max() if agg.max() > 0 else agg
+    assert agg.max() > 0 and ref.cnt.sum() > 0
+    assert np.allclose(got, exp, atol=2e-3)
+    meta = json.load(open(save_pth.replace(".pickle", ".json")))
+    assert meta["H"] == H and meta["O"] == O and len(meta["input_human_pths"]) == 3

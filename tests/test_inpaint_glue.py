@@ -91,3 +91,53 @@ def test_strength_drops_the_first_step():
     assert n == 49 and int(ts[0]) == 961 and len(ts) == 49
     ts, n = p.get_timesteps(50, 1.0)
     assert n == 50 and int(ts[0]) == 981
+
+
+def test_work_list_enumeration_sorting_overrides_and_slicing(tmp_path):
+    """Hand-computable case of the reference's work-list rules (src/generation/inpaint.py:187-278)."""
+    import pickle
+    from PIL import Image
+    from src.generation import inpaint as gi
+    base = tmp_path
+    sc, c, asset = "BEHAVE", "backpack", "behave_asset"
+    for v in (0, 1):
+        d = base / "renders" / sc / c / asset
+        d.mkdir(parents=True, exist_ok=True)
+        Image.new("RGB", (8, 8)).save(d / f"view:{v:05}.png")
+        m = base / "masks" / sc / c / asset
+        m.mkdir(parents=True, exist_ok=True)
+        pickle.dump({"valid_mask_ids": ["00000", "00003"] if v == 0 else ["00001"]}, open(m / f"view:{v:05}.pickle", "wb"))
+    (base / "renders" / sc / c / "unregistered_asset").mkdir()
+    Image.new("RGB", (8, 8)).save(base / "renders" / sc / c / "unregistered_asset" / "view:00000.png")
+    pd = base / "prompts" / sc / c / asset
+    pd.mkdir(parents=True)
+    pickle.dump({"prompts": ["1 person wears the backpack", "1 person holds the backpack"], "use_vlm": False}, open(pd / "prompts.pickle", "wb"))
+    renders = gi.prepare_asset_render_pths(str(base / "renders"), None, ["backpack"])
+    assert len(renders) == 2 and all("unregistered" not in r for r in renders)
+    defaults = dict(ddim_steps=50, cfg_scale=11.0, strength=0.5, enforce_full_mask_ratio=0.0, human_detection_thres=0.015)
+    items = gi.build_work_list(renders, str(base / "masks"), str(base / "segs"), str(base / "prompts"), str(base / "out"), 10,
+                               "neg", defaults)
+    # (2 + 1 masks) x 2 prompts x 2 augmentations x 10 seeds
+    assert len(items) == 3 * 2 * 2 * 10
+    assert [i["result_save_pth"] for i in items] == sorted(i["result_save_pth"] for i in items)
+    assert all(i["strength"] == 0.98 for i in items)              # category override beats the CLI default
+    assert all(i["cfg_scale"] == 11.0 and i["ddim_steps"] == 50 for i in items)
+    assert {i["input_prompt"] for i in items} == {"1 person wears the backpack", "1 person wears the backpack, full body",
+                                                  "1 person holds the backpack", "1 person holds the backpack, full body"}
+    assert items[0]["result_save_pth"].endswith("/000000.png") and items[0]["inpaint_id"] == 0
+    sizes = [len(gi.slice_for_process(items, r, 8)) for r in range(8)]
+    assert sizes == [16] * 7 + [8] and sum(sizes) == 120          # sub = 120 // 8 + 1 = 16
+    assert gi.resolve_setting("motorcycle,bike", "motorcycle,bike", "view:00099", "strength", 0.5) == 0.9
+
+
+def test_inpaint_cli_flags_match_reference():
+    from src.generation.inpaint import build_parser
+    flags = {a.option_strings[0] for a in build_parser()._actions if a.option_strings}
+    for f in ("--num_img_per_combination", "--supercategories", "--categories", "--asset_render_dir", "--asset_mask_dir",
+              "--asset_seg_dir", "--prompts_dir", "--save_dir", "--ldm_model_key", "--adaptive_mask_model_type", "--default_cfg_scale",
+              "--default_strength", "--default_ddim_steps", "--default_pointrend_threshold", "--default_enforce_full_mask_ratio",
+              "--default_human_detection_thres", "--enable_sam_multitask_output", "--negative_prompt", "--enable_safety_checker",
+              "--use_visualizer", "--skip_done", "--verbose", "--seed", "--parallel_num", "--parallel_idx"):
+        assert f in flags, f
+    d = build_parser().parse_args([])
+    assert (d.default_cfg_scale, d.default_strength, d.default_ddim_steps, d.num_img_per_combination) == (11.0, 0.98, 50, 10)

@@ -9,3 +9,4 @@ from coma_amd.coma import (  # noqa: F401
     negative_exp,
     simplify_mesh_and_get_indices,
 )
+from coma_amd.ingest import prepare_affordance_extraction_inputs  # noqa: F401,E402
