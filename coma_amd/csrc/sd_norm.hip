@@ -32,34 +32,56 @@ __device__ __forceinline__ half8 load8(const _Float16* x0, const _Float16* x1, i
   return *reinterpret_cast<const half8*>(p);
 }
 
-// partial[b][chunk][g][2] = (sum, sumsq) over GN_PIX pixels x (C/G) channels
+// partial[b][chunk][g][2] = (sum, sumsq) over GN_PIX pixels x (C/G) channels.
+// Thread mapping: tx = 8-channel chunk, ty = pixel lane; all 256 threads stay busy for every C (a C=320 tensor has only
+// 40 channel chunks, so 6 pixel lanes share them) and each thread walks GN_PIX/ny pixels.  The per-(pixel lane, channel)
+// sums are folded in LDS in a fixed order -> bitwise reproducible statistics, no atomics.
 constexpr int GN_MAX_C = 2560;
 __global__ __launch_bounds__(256) void gn_partial_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
                                                          int c0, int c1, int hw, int groups, float* __restrict__ partial) {
   __shared__ float chs[GN_MAX_C], chq[GN_MAX_C];   // per-channel sums of this pixel chunk
-  const int C = c0 + c1, cg = C / groups;
+  __shared__ float red[256 * 16];                  // [thread][8 sums | 8 sumsq]
+  const int C = c0 + c1, cg = C / groups, c8 = C / 8;
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int p0 = chunk * GN_PIX, p1 = min(hw, p0 + GN_PIX);
-  for (int c = threadIdx.x * 8; c < C; c += 256 * 8) {
+  const int nx = min(c8, 256), ny = 256 / nx;      // nx channel chunks per pass, ny pixel lanes
+  const int tx = threadIdx.x % nx, ty = threadIdx.x / nx;
+  for (int cb = 0; cb < c8; cb += nx) {            // passes over channel chunks (1 unless C > 2048)
+    const int ch = cb + tx;
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0f;
-    for (int p = p0; p < p1; ++p) {
-      half8 v = load8(x0, x1, c0, c1, (long long)b * hw + p, c);
+    if (ty < ny && ch < c8) {
+      for (int p = p0 + ty; p < p1; p += ny) {
+        half8 v = load8(x0, x1, c0, c1, (long long)b * hw + p, ch * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float f = (float)v[j];
-        s[j] += f;
-        q[j] += f * f;
+        for (int j = 0; j < 8; ++j) {
+          float f = (float)v[j];
+          s[j] += f;
+          q[j] += f * f;
+        }
       }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      chs[c + j] = s[j];
-      chq[c + j] = q[j];
+      red[threadIdx.x * 16 + j] = s[j];
+      red[threadIdx.x * 16 + 8 + j] = q[j];
     }
+    __syncthreads();
+    if (ty == 0 && ch < c8) {                      // fold the pixel lanes in a fixed order
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float ss = 0.0f, qq = 0.0f;
+        for (int y = 0; y < ny; ++y) {
+          ss += red[(y * nx + tx) * 16 + j];
+          qq += red[(y * nx + tx) * 16 + 8 + j];
+        }
+        chs[ch * 8 + j] = ss;
+        chq[ch * 8 + j] = qq;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x < groups) {   // fixed summation order -> bitwise reproducible statistics
     float s = 0.0f, q = 0.0f;
     for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) {
@@ -72,22 +94,27 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const _Float16* __restr
   }
 }
 
-// stats[b][g] = (mean, rstd)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int groups, float count, float eps,
-                                   float* __restrict__ stats, int total) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;   // (b, g)
+// stats[b][g] = (mean, rstd): one wave per (b, g), lanes over pixel chunks, fixed-order butterfly
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int groups, float count,
+                                                          float eps, float* __restrict__ stats, int total) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, g)
+  const int lane = threadIdx.x & 63;
   if (i >= total) return;
-  int b = i / groups, g = i - b * groups;
+  const int b = i / groups, g = i - b * groups;
   float s = 0.0f, q = 0.0f;
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = lane; c < nchunk; c += 64) {
     const float* p = partial + ((long long)b * nchunk + c) * groups * 2 + g * 2;
     s += p[0];
     q += p[1];
   }
-  float mean = s / count;
-  float var = fmaxf(q / count - mean * mean, 0.0f);
-  stats[2 * i] = mean;
-  stats[2 * i + 1] = rsqrtf(var + eps);
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (lane == 0) {
+    float mean = s / count;
+    float var = fmaxf(q / count - mean * mean, 0.0f);
+    stats[2 * i] = mean;
+    stats[2 * i + 1] = rsqrtf(var + eps);
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
@@ -201,7 +228,7 @@ extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, 
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, s, (const _Float16*)x0, (const _Float16*)x1, c0, c1,
                      hw, groups, partial);
   const int total = batch * groups;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 63) / 64), dim3(64), 0, s, partial, nchunk, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s, partial, nchunk, groups,
                      (float)hw * (float)(C / groups), eps, stats, total);
   const long long total8 = (long long)batch * hw * (C / 8);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const _Float16*)x0,
