@@ -33,7 +33,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-constexpr int BK = 64;
+constexpr int BKMIN = 32;   // source channel counts must be multiples of this (and of 64 for the deep-K variant)
 
 struct GemmArgs {
   const _Float16* a0;
@@ -75,30 +75,62 @@ __device__ __attribute__((aligned(128))) uint4 g_zero_page[8];
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// LDS tile image: [rows][64 halves = 8 x 16 B], unpadded 128-byte rows filled by LDS-DMA (global_load_lds), so a
-// wave instruction writes 8 rows x 128 B lane-linearly.  Bank conflicts are removed by an XOR swizzle applied on the
-// SOURCE side: 16-byte slot p of row r holds K-chunk p ^ ((r >> 1) & 7).  A 256-byte bank row spans two tile rows,
-// so (r & 1, (r >> 1) & 7) enumerates the 16 slots and the 16 rows read by one ds_read_b128 lane group land on 16
-// distinct slots (conflict-free), for both the A and the W fragments.
-__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+// LDS tile image: [rows][BK halves], unpadded rows filled by LDS-DMA (global_load_lds, 16 B per lane), so one wave
+// instruction writes 1 KiB lane-linearly (8 rows of 128 B at BK = 64, 16 rows of 64 B at BK = 32).  Bank conflicts of
+// the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE side: the 16-byte slot p of row r
+// holds K-chunk p ^ f(r).  A 256-byte bank row spans 2 (BK=64) or 4 (BK=32) tile rows, so with
+//   BK = 64: f(r) = (r >> 1) & 7        BK = 32: f(r) = (r >> 2) & 3
+// (r mod rows-per-bank-row, slot) enumerates the 16 slots of a bank row and the 16 rows read by one lane group of a
+// ds_read_b128 land on 16 distinct slots -> conflict-free, for both the A and the W fragments.
+template <int BK>
+__device__ __forceinline__ int swz(int row, int chunk) {
+  return BK == 64 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+}
 
-template <int BN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// STAGES-deep LDS-DMA pipeline: tiles kt+1 .. kt+STAGES-1 are in flight while tile kt is multiplied.
+//   <BN=128, BK=64, STAGES=2>  64 KiB, 2 blocks/CU : deep-K convolutions (compute-bound, fewer barriers per flop)
+//   <BN=128, BK=32, STAGES=4>  64 KiB, 2 blocks/CU : short-K linears (latency-bound: 3 tiles in flight per block)
+template <int BN, int BK, int STAGES>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
-  constexpr int WN = BN / 64;                  // MFMA n-tiles per wave
-  constexpr int A_LD = BM / 32;                // glds instructions per wave for the A tile (8 rows each) = 4
-  constexpr int B_LD = BN / 32;
-  __shared__ __attribute__((aligned(1024))) _Float16 lds[2 * (BM + BN) * BK];
+  constexpr int WN = BN / 64;                       // MFMA n-tiles per wave
+  constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
+  constexpr int RPI = 64 / CPR;                     // tile rows written by one wave-wide DMA instruction
+  constexpr int A_LD = BM / RPI / 4;                // DMA instructions per wave for the A tile
+  constexpr int B_LD = BN / RPI / 4;
+  constexpr int LPT = A_LD + B_LD;                  // DMA instructions per wave per K tile
+  constexpr int EPI_BYTES = 4 * 32 * (BN / 2 + 4) * 4;
+  constexpr int TILE_BYTES = STAGES * (BM + BN) * BK * 2;
+  __shared__ __attribute__((aligned(1024))) _Float16 lds[(TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES) / 2];
   _Float16* const As0 = lds;
-  _Float16* const Bs0 = lds + 2 * BM * BK;
+  _Float16* const Bs0 = lds + STAGES * BM * BK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private
+  // L2.  With enough M tiles every XCD gets a contiguous band of them and walks the N tiles of one M tile back to back,
+  // so the A rows are fetched once per XCD and re-read from its L2; small grids keep the plain order.
+  const int n_tiles = (g.N + BN - 1) / BN;
+  const int m_tiles = (g.M + BM - 1) / BM;
+  int m_tile, n_tile;
+  if (m_tiles >= 16) {
+    const int mq = (m_tiles + 7) >> 3;               // M tiles per XCD band (grid is padded to 8 * mq * n_tiles)
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    m_tile = xcd * mq + seq / n_tiles;
+    n_tile = seq % n_tiles;
+  } else {
+    m_tile = blockIdx.x % m_tiles;
+    n_tile = blockIdx.x / m_tiles;
+  }
+  if (m_tile >= m_tiles || n_tile >= n_tiles) return;   // padding block (exits before any barrier)
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
   const bool split = g.ksplit > 1;
-  const long long z = split ? 0 : blockIdx.z;
+  const long long z = split ? 0 : blockIdx.y;
   const _Float16* a0 = g.a0 + z * g.sa;
   const _Float16* wp = g.w + z * g.sw;
   const int ctot = g.c0 + g.c1;
@@ -107,22 +139,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
   // K range of this block (split-K) in units of BK tiles
   const int nk_all = g.K / BK;
   int kt0 = 0, nk = nk_all;
+  if (g.epi & (1 << 17)) nk = 0;          // tuning knob: skip the K loop
   if (split) {
     const int per = (nk_all + g.ksplit - 1) / g.ksplit;
-    kt0 = blockIdx.z * per;
+    kt0 = blockIdx.y * per;
     nk = min(per, nk_all - kt0);
     if (nk < 0) nk = 0;
   }
 
-  // DMA role of this lane: instruction j of this wave covers tile rows (wave*A_LD + j)*8 .. +7; lane -> row +lane/8,
-  // LDS slot lane%8, which must receive K-chunk slot ^ swizzle(row)
-  const int l_row = lane >> 3, l_slot = lane & 7;
+  // DMA role of this lane: instruction j of this wave covers tile rows (wave*A_LD + j)*RPI .. +RPI-1; lane -> row
+  // +lane/CPR, LDS slot lane%CPR, which must receive K-chunk slot ^ swizzle(row)
+  const int l_row = lane / CPR, l_slot = lane % CPR;
   int a_n[A_LD], a_y[A_LD], a_x[A_LD], a_koff[A_LD];
   bool a_ok[A_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    const int r = (wave * A_LD + j) * 8 + l_row;
-    a_koff[j] = swz(r, l_slot) * 8;
+    const int r = (wave * A_LD + j) * RPI + l_row;
+    a_koff[j] = swz<BK>(r, l_slot) * 8;
     const int m = m0 + r;
     a_ok[j] = m < g.M;
     const int mm = a_ok[j] ? m : 0;
@@ -132,12 +165,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
     a_y[j] = oy * g.stride - g.pad;
     a_x[j] = (rem - oy * g.out_w) * g.stride - g.pad;
   }
-  const _Float16* b_ptr[B_LD];     // row pointer + swizzled chunk offset (or the zero page)
+  const _Float16* b_ptr[B_LD];     // row pointer + swizzled chunk offset (or null -> zero page)
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
-    const int r = (wave * B_LD + j) * 8 + l_row;
+    const int r = (wave * B_LD + j) * RPI + l_row;
     const int n = n0 + r;
-    b_ptr[j] = n < g.N ? wp + (long long)n * g.K + swz(r, l_slot) * 8 : nullptr;
+    b_ptr[j] = n < g.N ? wp + (long long)n * g.K + swz<BK>(r, l_slot) * 8 : nullptr;
   }
   const int lim_h = g.upsample ? 2 * g.in_h : g.in_h;
   const int lim_w = g.upsample ? 2 * g.in_w : g.in_w;
@@ -159,22 +192,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
   };
   retap();
 
-  auto issue_tile = [&](int buf) {          // LDS-DMA of the tile at (ld_tap, ld_ci) into buffer `buf`; advances
+  auto issue_tile = [&](int buf) {          // LDS-DMA of the tile at (ld_tap, ld_ci) into stage `buf`; advances
     const _Float16* src = a0;
     int csrc = g.c0, ci = ld_ci;
     if (ci >= g.c0) { src = g.a1; csrc = g.c1; ci -= g.c0; }
-    _Float16* ad = As0 + buf * (BM * BK) + wave * A_LD * 8 * BK;
+    _Float16* ad = As0 + buf * (BM * BK) + wave * A_LD * RPI * BK;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       const _Float16* p = a_off[j] >= 0 ? src + a_off[j] * csrc + ci + a_koff[j] : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(ad + j * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(ad + j * RPI * BK), 16, 0, 0);
     }
     const int k0 = ld_tap * ctot + ld_ci;
-    _Float16* bd = Bs0 + buf * (BN * BK) + wave * B_LD * 8 * BK;
+    _Float16* bd = Bs0 + buf * (BN * BK) + wave * B_LD * RPI * BK;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       const _Float16* p = b_ptr[j] ? b_ptr[j] + k0 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(bd + j * 8 * BK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(bd + j * RPI * BK), 16, 0, 0);
     }
     ld_ci += BK;
     if (ld_ci >= ctot) { ld_ci = 0; ++ld_tap; retap(); }
@@ -196,24 +229,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
 #pragma unroll
   for (int j = 0; j < WN; ++j) b_fr[j] = wc * (BN / 2) + j * 32 + frow;
 
-  if (nk > 0) issue_tile(0);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue_tile(s);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    // the barrier's release carries vmcnt(0): tile kt has landed for every wave, and every wave is done reading
-    // the other buffer (it was consumed in iteration kt-1), so it can be refilled while tile kt is multiplied
-    __syncthreads();
-    if (kt + 1 < nk) issue_tile(cur ^ 1);
-    const _Float16* Ab = As0 + cur * (BM * BK);
-    const _Float16* Bb = Bs0 + cur * (BN * BK);
+    // wait for tile kt only: the (up to STAGES-2) younger tiles stay in flight across the barrier.  A raw s_barrier is
+    // used on purpose -- __syncthreads() would drain the DMA queue (its release carries vmcnt(0)).
+    const int younger = min(nk - 1, kt + STAGES - 2) - kt;
+    if constexpr (STAGES == 2) {
+      wait_vmcnt<0>();
+    } else if constexpr (STAGES == 3) {
+      if (younger >= 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    } else {
+      if (younger >= 2) wait_vmcnt<2 * LPT>(); else if (younger == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    // every wave has finished reading the stage that tile kt+STAGES-1 overwrites (it held tile kt-1)
+    if (kt + STAGES - 1 < nk) issue_tile((kt + STAGES - 1) % STAGES);
+    const _Float16* Ab = As0 + (kt % STAGES) * (BM * BK);
+    const _Float16* Bb = Bs0 + (kt % STAGES) * (BN * BK);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       half8 af[2], bf[WN];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const half8*>(Ab + a_fr[i] * BK + swz(a_fr[i], 2 * ks + fhalf) * 8);
+        af[i] = *reinterpret_cast<const half8*>(Ab + a_fr[i] * BK + swz<BK>(a_fr[i], 2 * ks + fhalf) * 8);
 #pragma unroll
       for (int j = 0; j < WN; ++j)
-        bf[j] = *reinterpret_cast<const half8*>(Bb + b_fr[j] * BK + swz(b_fr[j], 2 * ks + fhalf) * 8);
+        bf[j] = *reinterpret_cast<const half8*>(Bb + b_fr[j] * BK + swz<BK>(b_fr[j], 2 * ks + fhalf) * 8);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -229,11 +272,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
   // writes), then re-reads it row-major so that bias / residual / output move as coalesced 16-byte vectors.
   constexpr int WCOLS = BN / 2;                 // columns per wave
   constexpr int EP_STRIDE = WCOLS + 4;          // floats; 16-byte aligned rows, conflict-free 16-byte writes
-  __syncthreads();                              // every wave is done with the operand tiles
+  __syncthreads();                              // every wave is done with the operand tiles (all DMA drained)
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
   const int lrow = lane & 31, hh = lane >> 5;
   if (split) {
-    float* part = g.partial + (long long)blockIdx.z * g.M * g.N;
+    float* part = g.partial + (long long)blockIdx.y * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = m0 + wr * 64 + i * 32 + lrow;
@@ -250,78 +293,114 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
     }
     return;
   }
+  if (g.epi & (1 << 16)) return;          // tuning knob: skip the write-back
   _Float16* outp = g.out + z * g.so;
   const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
   const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
-  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS);
+  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS) &&
+                      (!g.bias_bn || (g.rows_per_batch % 32 == 0 && g.ldbb % 8 == 0));
+  if (geglu) {
+    if constexpr (WN == 2) {
+      // wave tile = [32 value cols | 32 gate cols] (weight rows interleaved at prep time) -> 32 outputs per row
+      const int ocol0 = (n0 >> 1) + wc * 32;
+      float bv[4][4], bg[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int mbase = m0 + wr * 64 + i * 32;
-    int ocols;            // valid output columns of this wave's sub-tile, and its first output column
-    int ocol0;
-    if (geglu) {
-      // wave tile = [32 value cols | 32 gate cols] (weight rows interleaved at prep time) -> 32 outputs
-      ocols = 32;
-      ocol0 = (n0 >> 1) + wc * 32;
-      if constexpr (WN == 2) {
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = n0 + wc * 64 + 8 * q + 4 * hh + e;
+          bv[q][e] = g.bias ? (float)g.bias[c] : 0.0f;
+          bg[q][e] = g.bias ? (float)g.bias[c + 32] : 0.0f;
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int mbase = m0 + wr * 64 + i * 32;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float o[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = 8 * q + 4 * hh + e;
-            float v = acc[i][0][4 * q + e], gt = acc[i][1][4 * q + e];
-            if (g.bias) { v += (float)g.bias[n0 + wc * 64 + c]; gt += (float)g.bias[n0 + wc * 64 + 32 + c]; }
-            o[e] = v * gelu_erf(gt);
-          }
+          for (int e = 0; e < 4; ++e) o[e] = (acc[i][0][4 * q + e] + bv[q][e]) * gelu_erf(acc[i][1][4 * q + e] + bg[q][e]);
           *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
         }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                 // 32 rows x 4 chunks = 128 items
+          const int it = lane + 64 * k, rl = it >> 2, cl = (it & 3) * 8;
+          const int row = mbase + rl;
+          const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
+          const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
+          half8 o = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w, (_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
+          if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocol0 + cl) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-    } else {
-      ocols = WCOLS;
-      ocol0 = n0 + wc * WCOLS;
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + j * 32 + 8 * q + 4 * hh) =
-              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     }
+    return;
+  }
+  constexpr int CPRW = WCOLS / 8;               // 16-byte output chunks per row of the wave tile (8 or 4)
+  constexpr int ITERS = 32 * CPRW / 64;         // read-back items per lane per 32-row half (4 or 2)
+  const int cl = (lane % CPRW) * 8;             // this lane's column chunk is the same for every item
+  const int col = n0 + wc * WCOLS + cl;
+  const bool col_ok = col + 8 <= g.N;
+  float bcol[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bcol[e] = 0.0f;
+  if (vec_ok && col_ok && g.bias) {
+    const half8 bvv = *reinterpret_cast<const half8*>(g.bias + col);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bcol[e] = (float)bvv[e];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mbase = m0 + wr * 64 + i * 32;
+    // issue the residual / per-sample-bias loads of this half first: they fly while the tile goes through LDS
+    half8 rv[ITERS], tb;
+    bool have_tb = false;
+    if (vec_ok && col_ok) {
+      if (g.bias_bn && mbase < g.M) {
+        tb = *reinterpret_cast<const half8*>(g.bias_bn + (long long)(mbase / g.rows_per_batch) * g.ldbb + col);
+        have_tb = true;
+      }
+      if (resp) {
+#pragma unroll
+        for (int k = 0; k < ITERS; ++k) {
+          const int row = mbase + (lane + 64 * k) / CPRW;
+          if (row < g.M) rv[k] = *reinterpret_cast<const half8*>(resp + (long long)row * g.ldr + col);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + j * 32 + 8 * q + 4 * hh) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // row-major read-back: 8 columns per lane
-    const int cpr = ocols / 8;                  // 16-byte output chunks per row (4 or 8)
-    for (int it = lane; it < 32 * cpr; it += 64) {
-      const int rl = it / cpr, cl = (it - rl * cpr) * 8;
-      const int row = mbase + rl, col = ocol0 + cl;
-      if (row >= g.M) continue;
+#pragma unroll
+    for (int k = 0; k < ITERS; ++k) {
+      const int rl = (lane + 64 * k) / CPRW;
+      const int row = mbase + rl;
       const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
       const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
       float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-      if (geglu) {
-        half8 o;
+      if (row >= g.M) continue;
+      if (vec_ok && col_ok) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-        *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
-      } else if (vec_ok && col + 8 <= g.N) {
-        if (g.bias) {
-          const half8 bv = *reinterpret_cast<const half8*>(g.bias + col);
+        for (int e = 0; e < 8; ++e) v[e] += bcol[e];
+        if (have_tb) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)bv[e];
-        }
-        if (g.bias_bn) {
-          const _Float16* bp = g.bias_bn + (long long)(row / g.rows_per_batch) * g.ldbb + col;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)bp[e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)tb[e];
         }
         if (g.epi & SD_EPI_SILU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
         }
         if (resp) {
-          const half8 rv = *reinterpret_cast<const half8*>(resp + (long long)row * g.ldr + col);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[k][e];
         }
         half8 o;
 #pragma unroll
@@ -370,8 +449,8 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (!d->a0 || !d->w || !d->out) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null pointer");
   if (d->taps != 1 && d->taps != 9) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: taps must be 1 or 9");
   if (d->stride != 1 && d->stride != 2) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: stride must be 1 or 2");
-  if (d->c0 <= 0 || d->c0 % BK || d->c1 < 0 || d->c1 % BK || (d->c1 > 0 && !d->a1))
-    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: source channels must be multiples of %d (c0=%d c1=%d)", BK, d->c0, d->c1);
+  if (d->c0 <= 0 || d->c0 % BKMIN || d->c1 < 0 || d->c1 % BKMIN || (d->c1 > 0 && !d->a1))
+    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: source channels must be multiples of %d (c0=%d c1=%d)", BKMIN, d->c0, d->c1);
   if (d->batch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->n <= 0)
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: bad sizes");
   if (d->pad < 0 || d->pad > 1) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: pad must be 0 or 1");
@@ -397,23 +476,31 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: GEGLU needs N %% 128 == 0 and no residual / batch bias");
   const bool wide = d->n % 128 == 0 || d->n > 256;
   const int bn = wide ? 128 : 64;
+  // short K -> BK = 32 with a 4-stage pipeline (latency-bound regime); deep K -> BK = 64, 2 stages
+  const bool deep = g.K >= 2048 && d->c0 % 64 == 0 && d->c1 % 64 == 0;
+  const int bk = deep ? 64 : 32;
   const unsigned gx = (unsigned)((g.M + BM - 1) / BM), gy = (unsigned)((d->n + bn - 1) / bn);
-  // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 4 K tiles per split
+  // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 256 of K per split
   g.ksplit = 1;
   g.partial = (float*)d->workspace;
   const long long blocks = (long long)gx * gy;
-  const int nk = g.K / BK;
-  if (nz == 1 && !geglu && d->workspace && blocks < 384 && nk >= 8 && d->n % 8 == 0 && g.ldo % 8 == 0) {
+  const int nk = g.K / bk;
+  const int min_tiles = 256 / bk;
+  if (nz == 1 && !geglu && d->workspace && blocks < 384 && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((512 + blocks - 1) / blocks);
-    if (s > nk / 4) s = nk / 4;
+    if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;
     while (s > 1 && (size_t)s * g.M * g.N * sizeof(float) > d->workspace_bytes) --s;
     if (s > 1) g.ksplit = s;
   }
-  dim3 grid(gx, gy, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
+  const long long lin_blocks = gx >= 16 ? 8LL * ((gx + 7) / 8) * gy : (long long)gx * gy;   // XCD-banded order (see kernel)
+  if (lin_blocks > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: grid too large");
+  dim3 grid((unsigned)lin_blocks, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
   hipStream_t st = (hipStream_t)stream;
-  if (wide) hipLaunchKernelGGL(conv_gemm_kernel<128>, grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL(conv_gemm_kernel<64>, grid, dim3(256), 0, st, g);
+  if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 2>), grid, dim3(256), 0, st, g);
+  else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<128, 32, 4>), grid, dim3(256), 0, st, g);
+  else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 2>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((conv_gemm_kernel<64, 32, 4>), grid, dim3(256), 0, st, g);
   if (g.ksplit > 1) {
     const long long n8 = (long long)g.M * (g.N / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, g);

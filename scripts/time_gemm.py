@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Time single conv_gemm shapes (tuning aid)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from coma_amd.sd import ops
+dev = "cuda:0"
+def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
+    C = K // taps
+    if taps == 9:
+        B, H = M // hw, int(hw ** 0.5)
+        x = torch.randn(M, C, device=dev).half()
+        kw = dict(batch=B, in_h=H, in_w=H, c0=C, n=N, taps=9)
+    else:
+        x = torch.randn(M, K, device=dev).half()
+        kw = dict(batch=M, in_h=1, in_w=1, c0=K, n=N)
+    w = torch.randn(N, K, device=dev).half() * K ** -0.5
+    b = torch.randn(N, device=dev).half()
+    r = torch.randn(M, N, device=dev).half() if res else None
+    out = torch.empty(M, N if not (epi & 1) else N // 2, device=dev, dtype=torch.float16)
+    for _ in range(3):
+        ops.conv_gemm(x, w, out, bias=b, res=r, epi=epi, **kw)
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        ops.conv_gemm(x, w, out, bias=b, res=r, epi=epi, **kw)
+    e.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(e) / reps
+    return ms, 2 * M * N * K / ms / 1e9
+for (M, N, K) in [(65536, 320, 320), (4096, 1280, 1280), (16384, 640, 640), (65536, 2560, 320)]:
+    for name, epi, res in [("full+res", 0, True), ("full", 0, False), ("no-store", 1 << 16, False), ("no-kloop", 1 << 17, False),
+                           ("nothing", (1 << 16) | (1 << 17), False)]:
+        ms, tf = bench(M, N, K, epi=epi, res=res)
+        print(f"M={M} N={N} K={K} {name:9s} {ms*1e3:8.1f} us  {tf:7.1f} TF/s")
