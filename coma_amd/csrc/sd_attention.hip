@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   constexpr int DQK = KS * 16;
   constexpr int K_STRIDE = DQK + 8;     // halves
   constexpr int DV = DVT * 32;
-  __shared__ __attribute__((aligned(16))) _Float16 Ks[BKV * K_STRIDE];
-  __shared__ __attribute__((aligned(16))) _Float16 Vs[DV * VT_STRIDE];
+  // double-buffered tiles: one barrier per key tile (stage t+1 is written while stage t is still being read)
+  __shared__ __attribute__((aligned(16))) _Float16 Kbuf[2][BKV * K_STRIDE];
+  __shared__ __attribute__((aligned(16))) _Float16 Vbuf[2][DV * VT_STRIDE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -125,7 +126,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       rv[i] = v;
     }
   };
-  auto store_regs = [&]() {
+  auto store_regs = [&](int buf) {
+    _Float16* Ks = Kbuf[buf];
+    _Float16* Vs = Vbuf[buf];
 #pragma unroll
     for (int i = 0; i < K_ITEMS; ++i) {
       const int it = tid + i * 256;
@@ -144,10 +147,13 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   };
 
   load_regs(0);
-  for (int key0 = 0; key0 < a.lk; key0 += BKV) {
-    store_regs();
-    __syncthreads();
+  int stage = 0;
+  for (int key0 = 0; key0 < a.lk; key0 += BKV, stage ^= 1) {
+    store_regs(stage);
+    __syncthreads();            // stage `stage` is complete; every wave finished reading stage^1 one iteration ago
     if (key0 + BKV < a.lk) load_regs(key0 + BKV);
+    const _Float16* Ks = Kbuf[stage];
+    const _Float16* Vs = Vbuf[stage];
 
     // ---- S^T = K Q^T  (two 32-key tiles)
     float16v s[2];
@@ -219,7 +225,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[t], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
 
   // ---- normalise and store: lane (query, half) owns dd = t*32 + 8*(r>>2) + 4*hh + (r&3)
