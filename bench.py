@@ -82,7 +82,8 @@ def bench_inpaint(args, dev, world, rank):
     one whole batch: masked-image VAE encode, 50 x (UNet graph + CFG/DDIM kernel), VAE decode to uint8."""
     from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline
     B = args.images
-    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=B, height=512, width=512, device=dev, seed=0)
+    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=B, height=512, width=512, device=dev, seed=0,
+                                                   use_graph=not args.eager)
     g = torch.Generator().manual_seed(100 + rank)
     image = torch.rand(B, 3, 512, 512, generator=g) * 2 - 1
     mask = torch.zeros(B, 1, 512, 512)
@@ -92,7 +93,7 @@ def bench_inpaint(args, dev, world, rank):
 
     def step(seed):
         gens.manual_seed(seed)
-        return pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=50,
+        return pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=args.ddim_steps,
                     strength=1.0, guidance_scale=11.0, generator=gens, output_type="u8", use_adaptive_mask=False).images
 
     def barrier():
@@ -229,6 +230,9 @@ def main():
     ap.add_argument("--normal-res", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph "
+                    "(profiling aid: rocprofv3 --pmc segfaults under graph replay on this image)")
+    ap.add_argument("--ddim-steps", type=int, default=50, help="only for profiling runs; the metric is defined at 50")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))

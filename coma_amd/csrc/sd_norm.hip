@@ -40,7 +40,7 @@ constexpr int GN_MAX_C = 2560;
 __global__ __launch_bounds__(256) void gn_partial_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
                                                          int c0, int c1, int hw, int groups, float* __restrict__ partial) {
   __shared__ float chs[GN_MAX_C], chq[GN_MAX_C];   // per-channel sums of this pixel chunk
-  __shared__ float red[256 * 16];                  // [thread][8 sums | 8 sumsq]
+  __shared__ float red[16 * 256];                  // [8 sums | 8 sumsq][thread]: consecutive threads -> consecutive banks
   const int C = c0 + c1, cg = C / groups, c8 = C / 8;
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
   const int p0 = chunk * GN_PIX, p1 = min(hw, p0 + GN_PIX);
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const _Float16* __restr
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      red[threadIdx.x * 16 + j] = s[j];
-      red[threadIdx.x * 16 + 8 + j] = q[j];
+      red[j * 256 + threadIdx.x] = s[j];
+      red[(8 + j) * 256 + threadIdx.x] = q[j];
     }
     __syncthreads();
     if (ty == 0 && ch < c8) {                      // fold the pixel lanes in a fixed order
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const _Float16* __restr
       for (int j = 0; j < 8; ++j) {
         float ss = 0.0f, qq = 0.0f;
         for (int y = 0; y < ny; ++y) {
-          ss += red[(y * nx + tx) * 16 + j];
-          qq += red[(y * nx + tx) * 16 + 8 + j];
+          ss += red[j * 256 + y * nx + tx];
+          qq += red[(8 + j) * 256 + y * nx + tx];
         }
         chs[ch * 8 + j] = ss;
         chq[ch * 8 + j] = qq;

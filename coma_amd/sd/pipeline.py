@@ -175,7 +175,7 @@ class AdaptiveMaskInpaintPipeline:
         unet = HipUNet2DConditionModel(random_state(unet_shapes(), seed=seed), batch=2 * batch_size, height=height // 8,
                                        width=width // 8, device=dev, use_graph=use_graph)
         vae = HipAutoencoderKL(random_state(vae_shapes(), seed=seed + 1), batch=batch_size, height=height, width=width, device=dev,
-                               with_encoder=with_encoder)
+                               with_encoder=with_encoder, use_graph=use_graph)
         sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                             set_alpha_to_one=False)
         return cls(vae, unet, sch, device=dev)

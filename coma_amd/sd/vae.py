@@ -20,7 +20,8 @@ class _Cfg(dict):
 
 
 class _VaeBase:
-    def __init__(self, state, batch, device, cfg):
+    def __init__(self, state, batch, device, cfg, use_graph=True):
+        self.use_graph = use_graph
         self.cfgd = cfg
         self.device = torch.device(device)
         self.batch = batch
@@ -70,6 +71,8 @@ class _VaeBase:
         return out
 
     def _replay(self):
+        if not self.use_graph:
+            return self.g.run()
         if not self._captured:
             self.g.capture()
             self._captured = True
@@ -184,12 +187,15 @@ class _LatentDist:
 class HipAutoencoderKL:
     """diffusers-shaped facade over the two graphs (NCHW tensors at the boundary, as the reference pipeline passes)."""
 
-    def __init__(self, state, batch, height=512, width=512, device="cuda", cfg=VAE_CFG, with_encoder=True):
+    def __init__(self, state, batch, height=512, width=512, device="cuda", cfg=VAE_CFG, with_encoder=True, use_graph=True):
         self.config = _Cfg(scaling_factor=cfg["scaling_factor"], latent_channels=cfg["latent_channels"],
                            block_out_channels=list(cfg["block_out_channels"]))
         self.device, self.batch, self.dtype = torch.device(device), batch, F16
         self.dec = HipVaeDecoder(state, batch, height // 8, width // 8, device, cfg)
         self.enc = HipVaeEncoder(state, batch, height, width, device, cfg) if with_encoder else None
+        self.dec.use_graph = use_graph
+        if self.enc is not None:
+            self.enc.use_graph = use_graph
 
     def decode(self, z, return_dict=False, **kw):
         B, hw = self.batch, self.dec.h * self.dec.w
