@@ -91,31 +91,41 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // STAGES-deep LDS-DMA pipeline: tiles kt+1 .. kt+STAGES-1 are in flight while tile kt is multiplied.
-//   <BN=128, BK=64, STAGES=2>  64 KiB, 2 blocks/CU : deep-K convolutions (compute-bound, fewer barriers per flop)
-//   <BN=128, BK=32, STAGES=4>  64 KiB, 2 blocks/CU : short-K linears (latency-bound: 3 tiles in flight per block)
-template <int BN, int BK, int STAGES>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
-  constexpr int WN = BN / 64;                       // MFMA n-tiles per wave
+// Block = WM x WN waves; a wave owns 64 rows x (TN * 32) columns = 2 x TN MFMA tiles.  Instantiations:
+//   <WM=2, WN=2, TN=2, BK=64, ST=2>  128 x 128, 64 KiB, 2 blocks/CU : generic deep-K (and GEGLU, which needs TN even)
+//   <WM=2, WN=2, TN=2, BK=32, ST=4>  128 x 128, 64 KiB, 2 blocks/CU : generic short-K (3 tiles in flight per block)
+//   <WM=4, WN=2, TN=5, BK=64, ST=2>  256 x 320, 144 KiB, 1 block/CU (8 waves): every N of this UNet is a multiple of
+//        320, so activations are read ONCE per 320 output columns and the LDS-DMA issue cost -- measured at 66-114
+//        cycles per wave instruction and NOT overlapped with MFMA issue, the limiter of the 128 x 128 tile (0.5 DMA per
+//        MFMA) -- drops to 0.225 DMA per MFMA.
+//   <WM=2, WN=1/2, ...> 64-wide fallbacks for small N.
+template <int WM, int WN, int TN, int BK, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm_kernel(GemmArgs g) {
+  constexpr int NW = WM * WN;                       // waves per block
+  constexpr int NT = NW * 64;
+  constexpr int BM_ = WM * 64, BN = WN * TN * 32;
   constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
   constexpr int RPI = 64 / CPR;                     // tile rows written by one wave-wide DMA instruction
-  constexpr int A_LD = BM / RPI / 4;                // DMA instructions per wave for the A tile
-  constexpr int B_LD = BN / RPI / 4;
+  static_assert((BM_ / RPI) % NW == 0 && (BN / RPI) % NW == 0, "DMA instructions must divide evenly over the waves");
+  constexpr int A_LD = BM_ / RPI / NW;              // DMA instructions per wave for the A tile
+  constexpr int B_LD = BN / RPI / NW;
   constexpr int LPT = A_LD + B_LD;                  // DMA instructions per wave per K tile
-  constexpr int EPI_BYTES = 4 * 32 * (BN / 2 + 4) * 4;
-  constexpr int TILE_BYTES = STAGES * (BM + BN) * BK * 2;
+  constexpr int EP_STRIDE = 32 + 4;                 // floats per staged row (one 32x32 MFMA tile per wave at a time)
+  constexpr int EPI_BYTES = NW * 32 * EP_STRIDE * 4;
+  constexpr int TILE_BYTES = STAGES * (BM_ + BN) * BK * 2;
   __shared__ __attribute__((aligned(1024))) _Float16 lds[(TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES) / 2];
   _Float16* const As0 = lds;
-  _Float16* const Bs0 = lds + STAGES * BM * BK;
+  _Float16* const Bs0 = lds + STAGES * BM_ * BK;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with a private
   // L2.  With enough M tiles every XCD gets a contiguous band of them and walks the N tiles of one M tile back to back,
   // so the A rows are fetched once per XCD and re-read from its L2; small grids keep the plain order.
   const int n_tiles = (g.N + BN - 1) / BN;
-  const int m_tiles = (g.M + BM - 1) / BM;
+  const int m_tiles = (g.M + BM_ - 1) / BM_;
   int m_tile, n_tile;
   if (m_tiles >= 16) {
     const int mq = (m_tiles + 7) >> 3;               // M tiles per XCD band (grid is padded to 8 * mq * n_tiles)
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
     n_tile = blockIdx.x / m_tiles;
   }
   if (m_tile >= m_tiles || n_tile >= n_tiles) return;   // padding block (exits before any barrier)
-  const int m0 = m_tile * BM;
+  const int m0 = m_tile * BM_;
   const int n0 = n_tile * BN;
   const bool split = g.ksplit > 1;
   const long long z = split ? 0 : blockIdx.y;
@@ -175,59 +185,66 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
   const int lim_h = g.upsample ? 2 * g.in_h : g.in_h;
   const int lim_w = g.upsample ? 2 * g.in_w : g.in_w;
 
-  // running position of the NEXT tile to load: tap index and channel offset inside the concatenation
+  // running position of the NEXT tile to load: tap index and channel offset inside the concatenation.  Per row the
+  // element pointer of (pixel of the current tap, channel 0 of the current source) is kept ready so that a tile's DMA
+  // address is one 64-bit add; it is rebuilt only when the tap or the source tensor changes.
   int ld_tap = (kt0 * BK) / ctot;
   int ld_ci = kt0 * BK - ld_tap * ctot;
-  long long a_off[A_LD];      // pixel index (n, iy, ix) of this lane's row for the current tap, or -1
-  auto retap = [&]() {
+  int ld_src = -1;                    // 0: a0, 1: a1
+  const _Float16* a_ptr[A_LD];        // pixel base pointer (+ swizzled chunk offset) or null -> zero page
+  auto repoint = [&]() {
     const int ky = g.taps == 9 ? ld_tap / 3 : 0;
     const int kx = g.taps == 9 ? ld_tap - ky * 3 : 0;
+    ld_src = ld_ci >= g.c0 ? 1 : 0;
+    const _Float16* src = ld_src ? g.a1 : a0;
+    const int csrc = ld_src ? g.c1 : g.c0;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       int iy = a_y[j] + ky, ix = a_x[j] + kx;
       const bool ok = a_ok[j] && iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w;
       if (g.upsample) { iy >>= 1; ix >>= 1; }
-      a_off[j] = ok ? ((long long)a_n[j] * g.in_h + iy) * g.in_w + ix : -1;
+      a_ptr[j] = ok ? src + (((long long)a_n[j] * g.in_h + iy) * g.in_w + ix) * csrc + a_koff[j] : nullptr;
     }
   };
-  retap();
+  repoint();
 
   auto issue_tile = [&](int buf) {          // LDS-DMA of the tile at (ld_tap, ld_ci) into stage `buf`; advances
-    const _Float16* src = a0;
-    int csrc = g.c0, ci = ld_ci;
-    if (ci >= g.c0) { src = g.a1; csrc = g.c1; ci -= g.c0; }
-    _Float16* ad = As0 + buf * (BM * BK) + wave * A_LD * RPI * BK;
+    const int ci = ld_src ? ld_ci - g.c0 : ld_ci;
+    _Float16* ad = As0 + buf * (BM_ * BK) + wave * A_LD * RPI * BK;
+    if (!(g.epi & (1 << 19)))      // tuning knob: skip the A-tile DMA
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-      const _Float16* p = a_off[j] >= 0 ? src + a_off[j] * csrc + ci + a_koff[j] : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(ad + j * RPI * BK), 16, 0, 0);
-    }
+      for (int j = 0; j < A_LD; ++j) {
+        const _Float16* p = a_ptr[j] ? a_ptr[j] + ci : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(ad + j * RPI * BK), 16, 0, 0);
+      }
     const int k0 = ld_tap * ctot + ld_ci;
     _Float16* bd = Bs0 + buf * (BN * BK) + wave * B_LD * RPI * BK;
+    if (!(g.epi & (1 << 18)))      // tuning knob: skip the W-tile DMA
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      const _Float16* p = b_ptr[j] ? b_ptr[j] + k0 : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(bd + j * RPI * BK), 16, 0, 0);
-    }
+      for (int j = 0; j < B_LD; ++j) {
+        const _Float16* p = b_ptr[j] ? b_ptr[j] + k0 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(bd + j * RPI * BK), 16, 0, 0);
+      }
     ld_ci += BK;
-    if (ld_ci >= ctot) { ld_ci = 0; ++ld_tap; retap(); }
+    if (ld_ci >= ctot) { ld_ci = 0; ++ld_tap; repoint(); }
+    else if ((ld_ci >= g.c0) != (ld_src == 1)) repoint();
   };
 
-  float16v acc[2][WN];
+  float16v acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   // fragment addressing: row = base + (lane & 31), K-chunk = 2*ks + (lane >> 5), slot = chunk ^ swizzle(row)
   const int frow = lane & 31, fhalf = lane >> 5;
-  int a_fr[2], b_fr[WN];
+  int a_fr[2], b_fr[TN];
 #pragma unroll
   for (int i = 0; i < 2; ++i) a_fr[i] = wr * 64 + i * 32 + frow;
 #pragma unroll
-  for (int j = 0; j < WN; ++j) b_fr[j] = wc * (BN / 2) + j * 32 + frow;
+  for (int j = 0; j < TN; ++j) b_fr[j] = wc * (TN * 32) + j * 32 + frow;
 
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -246,21 +263,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     // every wave has finished reading the stage that tile kt+STAGES-1 overwrites (it held tile kt-1)
     if (kt + STAGES - 1 < nk) issue_tile((kt + STAGES - 1) % STAGES);
-    const _Float16* Ab = As0 + (kt % STAGES) * (BM * BK);
+    const _Float16* Ab = As0 + (kt % STAGES) * (BM_ * BK);
     const _Float16* Bb = Bs0 + (kt % STAGES) * (BN * BK);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      half8 af[2], bf[WN];
+      half8 af[2], bf[TN];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         af[i] = *reinterpret_cast<const half8*>(Ab + a_fr[i] * BK + swz<BK>(a_fr[i], 2 * ks + fhalf) * 8);
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+      for (int j = 0; j < TN; ++j)
         bf[j] = *reinterpret_cast<const half8*>(Bb + b_fr[j] * BK + swz<BK>(b_fr[j], 2 * ks + fhalf) * 8);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
@@ -268,10 +285,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
   // ---------------------------------------------------------------- epilogue
   // The MFMAs were issued as D = W_frag . A_frag^T, so a lane owns ONE output row m = (lane & 31) of each 32-row
   // tile and its 16 registers run along output columns n = 8*(r>>2) + 4*(lane>>5) + (r&3): four consecutive
-  // registers are four consecutive columns.  Each wave stages its 32 x (BN/2) fp32 sub-tile in LDS (16-byte
-  // writes), then re-reads it row-major so that bias / residual / output move as coalesced 16-byte vectors.
-  constexpr int WCOLS = BN / 2;                 // columns per wave
-  constexpr int EP_STRIDE = WCOLS + 4;          // floats; 16-byte aligned rows, conflict-free 16-byte writes
+  // registers are four consecutive columns.  Each wave stages one 32 x 32 fp32 MFMA tile at a time in LDS (16-byte
+  // writes) and re-reads it row-major so that bias / residual / output move as coalesced 16-byte vectors.
+  wait_vmcnt<0>();
   __syncthreads();                              // every wave is done with the operand tiles (all DMA drained)
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
   const int lrow = lane & 31, hh = lane >> 5;
@@ -282,10 +298,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
       const int row = m0 + wr * 64 + i * 32 + lrow;
       if (row >= g.M) continue;
 #pragma unroll
-      for (int j = 0; j < WN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int col = n0 + wc * WCOLS + j * 32 + 8 * q + 4 * hh;
+          const int col = n0 + wc * (TN * 32) + j * 32 + 8 * q + 4 * hh;
           if (col < g.N)   // N % 8 == 0 on this path
             *reinterpret_cast<float4*>(part + (long long)row * g.N + col) =
                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
@@ -299,121 +315,126 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(GemmArgs g) {
   const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
   const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS) &&
                       (!g.bias_bn || (g.rows_per_batch % 32 == 0 && g.ldbb % 8 == 0));
+  // read-back role: 32 rows x 4 chunks of 8 columns = 128 items, two per lane; the column chunk is fixed per lane
+  const int cl = (lane & 3) * 8;
   if (geglu) {
-    if constexpr (WN == 2) {
-      // wave tile = [32 value cols | 32 gate cols] (weight rows interleaved at prep time) -> 32 outputs per row
-      const int ocol0 = (n0 >> 1) + wc * 32;
-      float bv[4][4], bg[4][4];
+    if constexpr (TN % 2 == 0) {
+      // tile pairs (2p, 2p+1) = (32 value columns, their 32 gate columns): weight rows interleaved at prep time
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int p = 0; p < TN / 2; ++p) {
+        const int ncol0 = n0 + wc * (TN * 32) + p * 64;        // permuted value columns [ncol0, +32), gates [+32, +64)
+        const int ocol0 = (ncol0 >> 1);
+        float bv[4][4], bg[4][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int c = n0 + wc * 64 + 8 * q + 4 * hh + e;
-          bv[q][e] = g.bias ? (float)g.bias[c] : 0.0f;
-          bg[q][e] = g.bias ? (float)g.bias[c + 32] : 0.0f;
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = ncol0 + 8 * q + 4 * hh + e;
+            bv[q][e] = g.bias ? (float)g.bias[c] : 0.0f;
+            bg[q][e] = g.bias ? (float)g.bias[c + 32] : 0.0f;
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int mbase = m0 + wr * 64 + i * 32;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              o[e] = (acc[i][2 * p][4 * q + e] + bv[q][e]) * gelu_erf(acc[i][2 * p + 1][4 * q + e] + bg[q][e]);
+            *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int rl = (lane + 64 * k) >> 2;
+            const int row = mbase + rl;
+            const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
+            const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
+            half8 o = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w, (_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
+            if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocol0 + cl) = o;
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int mbase = m0 + wr * 64 + i * 32;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (acc[i][0][4 * q + e] + bv[q][e]) * gelu_erf(acc[i][1][4 * q + e] + bg[q][e]);
-          *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {                 // 32 rows x 4 chunks = 128 items
-          const int it = lane + 64 * k, rl = it >> 2, cl = (it & 3) * 8;
-          const int row = mbase + rl;
-          const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
-          const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
-          half8 o = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w, (_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
-          if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocol0 + cl) = o;
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
     return;
   }
-  constexpr int CPRW = WCOLS / 8;               // 16-byte output chunks per row of the wave tile (8 or 4)
-  constexpr int ITERS = 32 * CPRW / 64;         // read-back items per lane per 32-row half (4 or 2)
-  const int cl = (lane % CPRW) * 8;             // this lane's column chunk is the same for every item
-  const int col = n0 + wc * WCOLS + cl;
-  const bool col_ok = col + 8 <= g.N;
-  float bcol[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bcol[e] = 0.0f;
-  if (vec_ok && col_ok && g.bias) {
-    const half8 bvv = *reinterpret_cast<const half8*>(g.bias + col);
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wc * (TN * 32) + j * 32 + cl;
+    const bool col_ok = col + 8 <= g.N;
+    float bcol[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bcol[e] = (float)bvv[e];
-  }
+    for (int e = 0; e < 8; ++e) bcol[e] = 0.0f;
+    if (vec_ok && col_ok && g.bias) {
+      const half8 bvv = *reinterpret_cast<const half8*>(g.bias + col);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int mbase = m0 + wr * 64 + i * 32;
-    // issue the residual / per-sample-bias loads of this half first: they fly while the tile goes through LDS
-    half8 rv[ITERS], tb;
-    bool have_tb = false;
-    if (vec_ok && col_ok) {
-      if (g.bias_bn && mbase < g.M) {
-        tb = *reinterpret_cast<const half8*>(g.bias_bn + (long long)(mbase / g.rows_per_batch) * g.ldbb + col);
-        have_tb = true;
-      }
-      if (resp) {
-#pragma unroll
-        for (int k = 0; k < ITERS; ++k) {
-          const int row = mbase + (lane + 64 * k) / CPRW;
-          if (row < g.M) rv[k] = *reinterpret_cast<const half8*>(resp + (long long)row * g.ldr + col);
-        }
-      }
+      for (int e = 0; e < 8; ++e) bcol[e] = (float)bvv[e];
     }
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + j * 32 + 8 * q + 4 * hh) =
-            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < ITERS; ++k) {
-      const int rl = (lane + 64 * k) / CPRW;
-      const int row = mbase + rl;
-      const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
-      const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
-      float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-      if (row >= g.M) continue;
+    for (int i = 0; i < 2; ++i) {
+      const int mbase = m0 + wr * 64 + i * 32;
+      // issue the residual / per-sample-bias loads of this tile first: they fly while the tile goes through LDS
+      half8 rv[2], tb;
+      bool have_tb = false;
       if (vec_ok && col_ok) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bcol[e];
-        if (have_tb) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)tb[e];
-        }
-        if (g.epi & SD_EPI_SILU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+        if (g.bias_bn && mbase < g.M) {
+          tb = *reinterpret_cast<const half8*>(g.bias_bn + (long long)(mbase / g.rows_per_batch) * g.ldbb + col);
+          have_tb = true;
         }
         if (resp) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rv[k][e];
+          for (int k = 0; k < 2; ++k) {
+            const int row = mbase + ((lane + 64 * k) >> 2);
+            if (row < g.M) rv[k] = *reinterpret_cast<const half8*>(resp + (long long)row * g.ldr + col);
+          }
         }
-        half8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-        *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
-      } else {
-        for (int e = 0; e < 8; ++e)
-          if (col + e < g.N)
-            outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int rl = (lane + 64 * k) >> 2;
+        const int row = mbase + rl;
+        const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
+        const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
+        float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        if (row >= g.M) continue;
+        if (vec_ok && col_ok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bcol[e];
+          if (have_tb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)tb[e];
+          }
+          if (g.epi & SD_EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+          }
+          if (resp) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[k][e];
+          }
+          half8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+          *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
+        } else {
+          for (int e = 0; e < 8; ++e)
+            if (col + e < g.N)
+              outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
@@ -474,19 +495,23 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   g.sa = d->stride_a; g.sw = d->stride_w; g.so = d->stride_out; g.sr = d->stride_res;
   if (geglu && (d->n % 128 != 0 || d->bias_bn || d->res))
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: GEGLU needs N %% 128 == 0 and no residual / batch bias");
+  // ---- tile configuration
+  const bool k64 = d->c0 % 64 == 0 && d->c1 % 64 == 0;
+  const bool deep = g.K >= 2048 && k64;
+  // 256 x 320 tile: N a multiple of 320 (every layer of the SD UNet), enough rows to fill the chip with 1 block / CU
+  const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
   const bool wide = d->n % 128 == 0 || d->n > 256;
-  const int bn = wide ? 128 : 64;
-  // short K -> BK = 32 with a 4-stage pipeline (latency-bound regime); deep K -> BK = 64, 2 stages
-  const bool deep = g.K >= 2048 && d->c0 % 64 == 0 && d->c1 % 64 == 0;
-  const int bk = deep ? 64 : 32;
-  const unsigned gx = (unsigned)((g.M + BM - 1) / BM), gy = (unsigned)((d->n + bn - 1) / bn);
+  const int bm = big ? 256 : 128;
+  const int bn = big ? 320 : (wide ? 128 : 64);
+  const int bk = (big || deep) ? 64 : 32;
+  const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((d->n + bn - 1) / bn);
   // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 256 of K per split
   g.ksplit = 1;
   g.partial = (float*)d->workspace;
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 256 / bk;
-  if (nz == 1 && !geglu && d->workspace && blocks < 384 && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
+  if (!big && nz == 1 && !geglu && d->workspace && blocks < 384 && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((512 + blocks - 1) / blocks);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;
@@ -497,10 +522,11 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (lin_blocks > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: grid too large");
   dim3 grid((unsigned)lin_blocks, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
   hipStream_t st = (hipStream_t)stream;
-  if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<128, 64, 2>), grid, dim3(256), 0, st, g);
-  else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<128, 32, 4>), grid, dim3(256), 0, st, g);
-  else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<64, 64, 2>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((conv_gemm_kernel<64, 32, 4>), grid, dim3(256), 0, st, g);
+  if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
+  else if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2>), grid, dim3(256), 0, st, g);
+  else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 32, 4>), grid, dim3(256), 0, st, g);
+  else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 64, 2>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 32, 4>), grid, dim3(256), 0, st, g);
   if (g.ksplit > 1) {
     const long long n8 = (long long)g.M * (g.N / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, g);
