@@ -500,10 +500,12 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const bool deep = g.K >= 2048 && k64;
   // 256 x 320 tile: N a multiple of 320 (every layer of the SD UNet), enough rows to fill the chip with 1 block / CU
   const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
+  // GEGLU (needs an even number of MFMA column tiles per wave): 256 x 256, 8 waves, wave tile 64 x 128
+  const bool big_geglu = geglu && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 16 && !(d->epi & (1 << 20));
   const bool wide = d->n % 128 == 0 || d->n > 256;
-  const int bm = big ? 256 : 128;
-  const int bn = big ? 320 : (wide ? 128 : 64);
-  const int bk = (big || deep) ? 64 : 32;
+  const int bm = (big || big_geglu) ? 256 : 128;
+  const int bn = big ? 320 : (big_geglu ? 256 : (wide ? 128 : 64));
+  const int bk = (big || big_geglu || deep) ? 64 : 32;
   const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((d->n + bn - 1) / bn);
   // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 256 of K per split
   g.ksplit = 1;
@@ -523,6 +525,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   dim3 grid((unsigned)lin_blocks, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
   hipStream_t st = (hipStream_t)stream;
   if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
+  else if (big_geglu) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
   else if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2>), grid, dim3(256), 0, st, g);
   else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 32, 4>), grid, dim3(256), 0, st, g);
   else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 64, 2>), grid, dim3(256), 0, st, g);
