@@ -210,6 +210,75 @@ def bench_contact(args, dev, world, rank):
     }
 
 
+def bench_adaptive(args, dev, world, rank):
+    """BASELINE.json config 3 shape: the full adaptive-mask loop, one 512x512 image per call (batch must be 1, as in the
+    reference), strength 0.98 -> 49 steps, 21 mask re-estimations (x0 decode + mask plug-in + device mask glue + VAE
+    re-encode).  The mask plug-in is the deterministic synthetic stand-in (PointRend weights are unreachable offline)."""
+    from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
+    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=1, height=512, width=512, device=dev, seed=0)
+    pipe.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
+    pipe.register_adaptive_mask_settings(default_adaptive_mask_settings(50, "p"))
+    g = torch.Generator().manual_seed(5 + rank)
+    image = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, 512, 512)
+    mask[:, :, 100:420, 150:400] = 1
+    pe, ne = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    gen = torch.Generator(device=dev)
+
+    def one(seed):
+        gen.manual_seed(seed)
+        return pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=50,
+                    strength=0.98, guidance_scale=11.0, generator=gen, output_type="u8", use_adaptive_mask=True,
+                    enforce_full_mask_ratio=0.0, human_detection_thres=0.015).images
+    one(0)
+    torch.cuda.synchronize()
+    n = 3
+    t0 = time.perf_counter()
+    for k in range(n):
+        one(1 + k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    del pipe
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {"metric": "adaptive-mask HOI images/s (49 steps, 21 mask re-estimations, batch 1)", "value": world / dt, "unit": "images/s",
+            "s_per_image": dt, "config": {"workload": "config 3 shape: full adaptive loop, synthetic mask plug-in, 512x512, one image per call"}}
+
+
+def bench_occupancy(args, dev, world, rank):
+    """BASELINE.json config 5, one GPU's share: human-vertex rows are sharded over 8 GPUs (1310 of 10475 rows each), every rank
+    splats all S=2000 samples into its [H/8, 128^3] grid (11 GB), reduces its rows and the [R,R,R] result is MAX-all-reduced."""
+    from coma_amd import dist as cdist
+    from utils.coma_occupancy import ComA_Occupancy
+    H, R, S = 1310, 128, 2000
+    occ = ComA_Occupancy(scale_tolerance=3.0, human_res=H, obj_res=1, normal_res=0, spatial_res=R, device=dev)
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    q = (torch.rand([S, H, 3], generator=g, device=dev) * 2.6 - 1.3).contiguous()      # ~21 % of the points fall outside the grid
+    occ.accumulate_device(q[:8])
+    torch.cuda.synchronize()
+    occ.spatial_occupancy_grids.zero_()
+    a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    a.record()
+    occ.accumulate_device(q)
+    b.record()
+    out = occ.return_aggregated_spatial_grids()
+    if world > 1:
+        cdist.all_reduce_max_nan(out)
+    c.record()
+    torch.cuda.synchronize()
+    ms_splat, ms_reduce = a.elapsed_time(b), b.elapsed_time(c)
+    if rank != 0:
+        return None
+    cells = 113.1                                   # 4/3 pi 3^3 voxels inside the threshold sphere
+    alg = S * H * (12 + cells * 8) + 4 * H * R**3   # structure A of SURVEY.md 8d: RMW per lit cell + the grid itself
+    return {"metric": "occupancy splats/s (ComA_Occupancy K5, R=128)", "value": world * S * H / (ms_splat * 1e-3), "unit": "splats/s",
+            "dense_equivalent_voxel_tests_per_s": world * S * H * R**3 / (ms_splat * 1e-3), "splat_ms": ms_splat,
+            "reduce_ms": ms_reduce, "config": {"workload": f"H={H} rows/GPU (10475/8), R={R}, S={S}, scale_tolerance 3 (config 5 per-GPU share)"},
+            "roofline": {"bound": "hbm", "kernel": "coma::occupancy_splat_kernel", "achieved": alg / (ms_splat * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+
+
 # HBM bytes per contact_accumulate_kernel launch from the committed rocprofv3 PMC pass (profiles/r01_contact_pmc.txt):
 # FETCH_SIZE 1.91553e6 KiB (x2: gfx950 reports half of a coalesced stream) + WRITE_SIZE 3.71135e6 KiB
 CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91553e6 + 3.71135e6) * 1024)
@@ -255,6 +324,15 @@ def main():
         out = dict(primary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_inpaint() if args.workload == "inpaint" else cpu_baseline()
+        if not args.no_secondary:
+            try:
+                out["occupancy"] = bench_occupancy(args, dev, world, rank)
+            except Exception as e:   # noqa: BLE001  (never lose the primary line)
+                out["occupancy"] = {"error": repr(e)}
+            try:
+                out["adaptive_loop"] = bench_adaptive(args, dev, world, rank)
+            except Exception as e:   # noqa: BLE001
+                out["adaptive_loop"] = {"error": repr(e)}
         if secondary is not None:
             sec = dict(secondary)
             if world == 1 and not args.no_cpu_baseline:
