@@ -502,13 +502,16 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
   // GEGLU (needs an even number of MFMA column tiles per wave): 256 x 256, 8 waves, wave tile 64 x 128
   const bool big_geglu = geglu && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 16 && !(d->epi & (1 << 20));
+  // VAE widths (128 / 256 / 512 channels at up to 512 x 512 pixels): 256 x 256 and 256 x 128 tiles, 8 waves
+  const bool big256 = !geglu && !big && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
+  const bool big128 = !geglu && !big && !big256 && nz == 1 && k64 && d->n % 128 == 0 && g.M >= 256 * 256 && !(d->epi & (1 << 20));
   // 128 x 320, 4 waves (wave tile 64 x 160): mid-size M where 256-row tiles would leave CUs idle
-  const bool mid = !big && !geglu && nz == 1 && d->n % 320 == 0 && g.M >= 128 * 64 &&
+  const bool mid = !big && !big256 && !big128 && !geglu && nz == 1 && d->n % 320 == 0 && g.M >= 128 * 64 &&
                    (d->n <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20));
   const bool wide = d->n % 128 == 0 || d->n > 256;
-  const int bm = (big || big_geglu) ? 256 : 128;
-  const int bn = (big || mid) ? 320 : (big_geglu ? 256 : (wide ? 128 : 64));
-  const int bk = mid ? 32 : ((big || big_geglu || deep) ? 64 : 32);
+  const int bm = (big || big_geglu || big256 || big128) ? 256 : 128;
+  const int bn = (big || mid) ? 320 : ((big_geglu || big256) ? 256 : ((wide || big128) ? 128 : 64));
+  const int bk = mid ? 32 : ((big || big_geglu || big256 || big128 || deep) ? 64 : 32);
   const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((d->n + bn - 1) / bn);
   // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 256 of K per split
   g.ksplit = 1;
@@ -516,7 +519,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 256 / bk;
-  if (!big && nz == 1 && !geglu && d->workspace && blocks < (mid ? 192 : 384) && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
+  if (!big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < (mid ? 192 : 384) && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((512 + blocks - 1) / blocks);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;
@@ -528,7 +531,8 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   dim3 grid((unsigned)lin_blocks, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
   hipStream_t st = (hipStream_t)stream;
   if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
-  else if (big_geglu) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
+  else if (big_geglu || big256) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
+  else if (big128) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 2, 64, 2>), grid, dim3(512), 0, st, g);
   else if (mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 3>), grid, dim3(256), 0, st, g);
   else if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2>), grid, dim3(256), 0, st, g);
   else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 32, 4>), grid, dim3(256), 0, st, g);

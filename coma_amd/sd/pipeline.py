@@ -219,13 +219,15 @@ class AdaptiveMaskInpaintPipeline:
         ops.vae_sample(mom, 64, noise, float(self.vae.config.scaling_factor), B * n, lat32=lat32, lat16=lat16)
         return lat32, lat16
 
-    def decode_to_npuint8_image(self, latents_nhwc_f32):
-        """latents fp32 [1,hw,4] -> uint8 HWC numpy (truncating cast, as `(x*255).astype(np.uint8)` at :1114)."""
+    def decode_to_npuint8_image(self, latents_nhwc_f32, all_images=False):
+        """latents fp32 [B,hw,4] -> uint8 HWC numpy (truncating cast, as `(x*255).astype(np.uint8)` at :1114);
+        image 0 only (the reference's contract) unless all_images."""
         img = self._decode(latents_nhwc_f32)
         H, W = self.vae.dec.out_h, self.vae.dec.out_w
         u8 = torch.empty(self.vae.batch, H * W, 3, dtype=torch.uint8, device=self.device)
         ops.image_to_u8(img, u8, batch=self.vae.batch, hw=H * W, ld=64, round_mode=0)
-        return u8.reshape(self.vae.batch, H, W, 3)[0].cpu().numpy()
+        arr = u8.reshape(self.vae.batch, H, W, 3).cpu().numpy()
+        return arr if all_images else arr[0]
 
     def _decode(self, latents_nhwc_f32):
         dec = self.vae.dec
@@ -246,7 +248,8 @@ class AdaptiveMaskInpaintPipeline:
         if strength < 0 or strength > 1:
             raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
         if use_adaptive_mask:
-            assert B == 1, "the adaptive-mask loop processes one image per call (reference: squeeze() at :1114)"
+            # the reference handles one image per call (squeeze() at :1114); here a batch of independent images runs the
+            # loop together, each with its own adapted mask (the plug-in is called once per image)
             assert self.adaptive_mask_model is not None and self.adaptive_mask_settings is not None
         if PIL is not None and isinstance(image, PIL.Image.Image):
             width, height = image.size
@@ -289,13 +292,14 @@ class AdaptiveMaskInpaintPipeline:
         mask_full = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
         mask_lat = torch.empty(B, hw, dtype=torch.float16, device=dev)
 
-        def set_mask(seg_u8, dilate_iters, use_default):
+        def set_mask(segs, dilate_iters):
+            """segs[b]: u8 device mask to dilate & intersect with the default mask, or None -> default mask."""
             for b in range(B):
-                ops.mask_adapt(seg_u8, default_mask_u8[b], init_image[b], mask_full[b], mask_lat[b],
-                               self.vae.enc.x[b], H=H, W=W, dilate_iters=dilate_iters, use_default=use_default, cpad=64)
+                ops.mask_adapt(segs[b], default_mask_u8[b], init_image[b], mask_full[b], mask_lat[b], self.vae.enc.x[b], H=H, W=W,
+                               dilate_iters=dilate_iters, use_default=segs[b] is None, cpad=64)
             return self._encode_vae_image(None, generator)[1]
 
-        masked_lat = set_mask(None, 0, True)
+        masked_lat = set_mask([None] * B, 0)
         self._last_masked_lat = masked_lat
         x0 = torch.empty(B, hw, 4, dtype=torch.float32, device=dev)
         # first UNet input (no step yet)
@@ -316,7 +320,7 @@ class AdaptiveMaskInpaintPipeline:
                 # step first (latents + x0), adapt the mask from the decoded x0, then assemble the next input
                 ops.cfg_ddim_step(eps, 64, lat, x0, None, None, None, batch=B, hw=hw, guidance=guidance_scale, alpha_t=a_t,
                                   alpha_prev=a_p)
-                pred_orig_image = self.decode_to_npuint8_image(x0)
+                pred_orig_images = self.decode_to_npuint8_image(x0, all_images=True)
                 if adapt:
                     if enforce_full_mask_ratio > 0.0:
                         use_default = t < self.scheduler.config.num_train_timesteps * enforce_full_mask_ratio
@@ -324,12 +328,12 @@ class AdaptiveMaskInpaintPipeline:
                         use_default = False
                     else:
                         raise NotImplementedError
-                    seg = np.ascontiguousarray(self.adaptive_mask_model(pred_orig_image)["mask"]).astype(np.uint8)
-                    if use_default or seg.sum() < 512 * 512 * human_detection_thres:
-                        masked_lat = set_mask(None, 0, True)
-                    else:
-                        k = self.adaptive_mask_settings.dilate_scheduler(i)
-                        masked_lat = set_mask(torch.from_numpy(seg).to(dev), int(k), False)
+                    segs = []
+                    for b in range(B):
+                        seg = np.ascontiguousarray(self.adaptive_mask_model(pred_orig_images[b])["mask"]).astype(np.uint8)
+                        small = seg.sum() < 512 * 512 * human_detection_thres
+                        segs.append(None if (use_default or small) else torch.from_numpy(seg).to(dev))
+                    masked_lat = set_mask(segs, int(self.adaptive_mask_settings.dilate_scheduler(i)))
                     mask_image_np = mask_full[0].cpu().numpy().astype(np.float32)
                 ops.cfg_ddim_step(None, 0, lat, None, mask_lat, masked_lat, self.unet.x_in, batch=B, hw=hw,
                                   guidance=guidance_scale, alpha_t=1.0, alpha_prev=1.0)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Time the VAE decoder / encoder graphs at batch 8, 512x512 (tuning aid)."""
+import sys, os, time, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from coma_amd.sd import weights
+from coma_amd.sd.vae import HipAutoencoderKL
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = "cuda:0"
+vae = HipAutoencoderKL(weights.random_state(weights.vae_shapes(), seed=1), batch=B, device=dev)
+vae.dec.z.copy_(torch.randn(vae.dec.z.shape, device=dev).half()); vae.dec.z[:, :, 4:] = 0
+vae.enc.x.copy_(torch.randn(vae.enc.x.shape, device=dev).half()); vae.enc.x[:, :, 3:] = 0
+for name, m, run in (("decoder", vae.dec, vae.dec.decode_static), ("encoder", vae.enc, vae.enc.encode_static)):
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print(f"{name} B={B}: {dt*1e3:.2f} ms, {m.g.flops/1e12:.2f} TFLOP -> {m.g.flops/dt/1e12:.1f} TFLOP/s ({len(m.g.launches)} launches)")
+    if "--profile" in sys.argv:
+        acc = collections.defaultdict(lambda: [0.0, 0, 0.0])
+        for tag, fl, ms in m.g.profile(reps=2):
+            acc[tag][0] += ms; acc[tag][1] += 1; acc[tag][2] += fl
+        for tag, (ms, n, fl) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]:
+            print(f"   {ms:8.3f} ms n={n:3d} {fl/ms/1e9 if ms else 0:7.1f} TF/s  {tag}")
