@@ -28,8 +28,8 @@ def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
     e.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(e) / reps
     return ms, 2 * M * N * K / ms / 1e9
-for (M, N, K, taps, hw) in [(16384, 640, 5760, 9, 1024), (16384, 640, 640, 1, None), (16384, 1280, 11520, 9, 1024), (4096, 1280, 11520, 9, 256),
-                            (4096, 1280, 1280, 1, None), (16384, 640, 2560, 1, None)]:
-    for name, epi in [("default", 0), ("128x320", 1 << 21)]:
+for (M, N, K, taps, hw) in [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 1280, 1, None), (16384, 640, 640, 1, None),
+                            (4096, 1280, 1280, 1, None), (65536, 640, 5760, 9, 4096)]:
+    for name, epi in [("staged", 0), ("direct", 1 << 22)]:
         ms, tf = bench(M, N, K, taps=taps, epi=epi, hw=hw, res=True)
         print(f"M={M} N={N} K={K} taps={taps} {name:8s} {ms*1e3:8.1f} us  {tf:7.1f} TF/s")
