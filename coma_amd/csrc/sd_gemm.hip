@@ -52,6 +52,7 @@ struct GemmArgs {
   _Float16* out;
   int ldo;
   int epi;
+  float* colstats;            // optional [M/64][2][N] fp32: per 64-row block column sums / sums of squares of the OUTPUT
   int ksplit;                 // >1: blockIdx.z selects a K range and fp32 partials go to `partial`
   float* partial;             // [ksplit][M][N] fp32
   long long sa, sw, so, sr;   // per-blockIdx.z strides in elements (batched mode, ksplit == 1)
@@ -366,6 +367,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wc * (TN * 32) + j * 32 + cl;
     const bool col_ok = col + 8 <= g.N;
+    float cs[8], cq[8];          // GroupNorm statistics of the consumer: column sums over this wave's 64 rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
     float bcol[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bcol[e] = 0.0f;
@@ -426,6 +430,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
           *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
+          if (g.colstats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)o[e];     // statistics of the stored (fp16-rounded) tensor, as a GroupNorm pass would see it
+              cs[e] += f;
+              cq[e] += f * f;
+            }
+          }
         } else {
           for (int e = 0; e < 8; ++e)
             if (col + e < g.N)
@@ -434,6 +446,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (g.colstats) {
+      // fold the 16 lanes that share a column chunk (lane & 3 fixed): fixed butterfly order -> reproducible
+#pragma unroll
+      for (int mask = 4; mask < 64; mask <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          cs[e] += __shfl_xor(cs[e], mask);
+          cq[e] += __shfl_xor(cq[e], mask);
+        }
+      if (lane < 4 && col_ok) {
+        float* dst = g.colstats + (long long)((m0 >> 6) + wr) * 2 * g.N + col;
+        *reinterpret_cast<float4*>(dst) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+        *reinterpret_cast<float4*>(dst + g.N) = make_float4(cq[0], cq[1], cq[2], cq[3]);
+        *reinterpret_cast<float4*>(dst + g.N + 4) = make_float4(cq[4], cq[5], cq[6], cq[7]);
+      }
     }
   }
 }
@@ -516,10 +545,13 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 256 of K per split
   g.ksplit = 1;
   g.partial = (float*)d->workspace;
+  g.colstats = (float*)d->colstats;
+  if (g.colstats && (geglu || nz != 1 || g.M % 64 || d->n % 8 || (d->epi & SD_EPI_BIAS_ROWS)))
+    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: colstats needs M %% 64 == 0, N %% 8 == 0, no GEGLU / batching");
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 256 / bk;
-  if (!big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < (mid ? 192 : 384) && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
+  if (!g.colstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < (mid ? 192 : 384) && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((512 + blocks - 1) / blocks);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;

@@ -94,9 +94,24 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const _Float16* __restr
   }
 }
 
-// stats[b][g] = (mean, rstd): one wave per (b, g), lanes over pixel chunks, fixed-order butterfly
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int groups, float count,
-                                                          float eps, float* __restrict__ stats, int total) {
+// One wave per (b, g): fold the per-chunk partial sums (fixed order), then write the affine table the apply pass uses:
+//   y = x * scale[b][c] + shift[b][c],  scale = rstd * gamma[c],  shift = beta[c] - mean * rstd * gamma[c]
+__device__ __forceinline__ void gn_write_affine(float s, float q, float count, float eps, int b, int g, int cg, int C,
+                                                const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
+                                                float* __restrict__ affine, int lane) {
+  const float mean = s / count;
+  const float var = fmaxf(q / count - mean * mean, 0.0f);
+  const float rstd = rsqrtf(var + eps);
+  for (int c = g * cg + lane; c < (g + 1) * cg; c += 64) {
+    const float sc = rstd * (float)gamma[c];
+    affine[((long long)b * C + c) * 2] = sc;
+    affine[((long long)b * C + c) * 2 + 1] = (float)beta[c] - mean * sc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int groups, int C,
+                                                          float count, float eps, const _Float16* __restrict__ gamma,
+                                                          const _Float16* __restrict__ beta, float* __restrict__ affine, int total) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, g)
   const int lane = threadIdx.x & 63;
   if (i >= total) return;
@@ -109,37 +124,63 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
   s = wave_sum(s);
   q = wave_sum(q);
-  if (lane == 0) {
-    float mean = s / count;
-    float var = fmaxf(q / count - mean * mean, 0.0f);
-    stats[2 * i] = mean;
-    stats[2 * i + 1] = rsqrtf(var + eps);
-  }
+  gn_write_affine(s, q, count, eps, b, g, C / groups, C, gamma, beta, affine, lane);
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
-                                                       int c0, int c1, int hw, int groups, const float* __restrict__ stats,
-                                                       const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
-                                                       int silu, _Float16* __restrict__ out, long long total8) {
-  const int C = c0 + c1, cg = C / groups, c8 = C / 8;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total8) return;
-  long long pix = i / c8;
-  int c = (int)(i - pix * c8) * 8;
-  int b = (int)(pix / hw);
-  half8 v = load8(x0, x1, c0, c1, pix, c);
-  half8 ga = *reinterpret_cast<const half8*>(gamma + c);
-  half8 be = *reinterpret_cast<const half8*>(beta + c);
-  half8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    int g = (c + j) / cg;
-    float mean = stats[((long long)b * groups + g) * 2], rstd = stats[((long long)b * groups + g) * 2 + 1];
-    float y = ((float)v[j] - mean) * rstd * (float)ga[j] + (float)be[j];
-    if (silu) y = y / (1.0f + __expf(-y));
-    o[j] = (_Float16)y;
+// the same from per-64-row-block column sums [rb][2][C] of one or two producers
+__global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* __restrict__ cs0, const float* __restrict__ cs1,
+                                                                  int c0, int c1, int hw, int groups, float eps,
+                                                                  const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
+                                                                  float* __restrict__ affine, int total) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, g)
+  const int lane = threadIdx.x & 63;
+  if (i >= total) return;
+  const int C = c0 + c1, cg = C / groups, rbs = hw / 64;
+  const int b = i / groups, g = i - b * groups;
+  float s = 0.0f, q = 0.0f;
+  for (int it = lane; it < rbs * cg; it += 64) {
+    const int rb = it / cg, c = g * cg + (it - rb * cg);
+    const float* p = c < c0 ? cs0 + ((long long)(b * rbs + rb) * 2) * c0 + c : cs1 + ((long long)(b * rbs + rb) * 2) * c1 + (c - c0);
+    s += p[0];
+    q += p[c < c0 ? c0 : c1];
   }
-  *reinterpret_cast<half8*>(out + pix * C + c) = o;
+  s = wave_sum(s);
+  q = wave_sum(q);
+  gn_write_affine(s, q, (float)hw * (float)cg, eps, b, g, cg, C, gamma, beta, affine, lane);
+}
+
+// y = silu(x * scale + shift): blockIdx.y = sample, tx = 8-channel chunk, ty = pixel lane -> no integer division
+constexpr int GN_APPLY_PIX = 32;     // pixels per block
+__global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
+                                                       int c0, int c1, int hw, const float* __restrict__ affine, int silu,
+                                                       _Float16* __restrict__ out) {
+  const int C = c0 + c1, c8 = C / 8;
+  const int b = blockIdx.y;
+  const int nx = min(c8, 256), ny = 256 / nx;
+  const int tx = threadIdx.x % nx, ty = threadIdx.x / nx;
+  if (ty >= ny) return;
+  const int p0 = blockIdx.x * GN_APPLY_PIX, p1 = min(hw, p0 + GN_APPLY_PIX);
+  for (int ch = tx; ch < c8; ch += nx) {
+    const float4* ap = reinterpret_cast<const float4*>(affine + ((long long)b * C + ch * 8) * 2);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = ap[k];
+      sc[2 * k] = v.x; sh[2 * k] = v.y; sc[2 * k + 1] = v.z; sh[2 * k + 1] = v.w;
+    }
+    for (int p = p0 + ty; p < p1; p += ny) {
+      const long long pix = (long long)b * hw + p;
+      const half8 v = load8(x0, x1, c0, c1, pix, ch * 8);
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float y = fmaf((float)v[j], sc[j], sh[j]);
+        if (silu) y = y / (1.0f + __expf(-y));
+        o[j] = (_Float16)y;
+      }
+      *reinterpret_cast<half8*>(out + pix * C + ch * 8) = o;
+    }
+  }
 }
 
 // one wave per row; C <= 64*8*4
@@ -214,6 +255,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(_Float16* __restrict__ x, 
 
 using namespace sd;
 
+// scratch layout (floats): [batch*C*2] affine table, then [batch*nchunk*groups*2] partial sums
 extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                                 const void* gamma, const void* beta, int silu, void* out, float* stats, void* stream) {
   if (!x0 || !gamma || !beta || !out || !stats) return fail(COMA_E_INVALID, "sd_groupnorm_f16: null pointer");
@@ -222,18 +264,15 @@ extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, 
   if (batch <= 0 || hw <= 0 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || c1 % 8 || C > GN_MAX_C)
     return fail(COMA_E_INVALID, "sd_groupnorm_f16: bad shape C=%d groups=%d", C, groups);
   const int nchunk = (hw + GN_PIX - 1) / GN_PIX;
-  // scratch layout: [batch*groups*2] final stats, then [batch*nchunk*groups*2] partials
-  float* partial = stats + (size_t)batch * groups * 2;
+  float* partial = stats + (size_t)batch * C * 2;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, s, (const _Float16*)x0, (const _Float16*)x1, c0, c1,
                      hw, groups, partial);
   const int total = batch * groups;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s, partial, nchunk, groups,
-                     (float)hw * (float)(C / groups), eps, stats, total);
-  const long long total8 = (long long)batch * hw * (C / 8);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const _Float16*)x0,
-                     (const _Float16*)x1, c0, c1, hw, groups, stats, (const _Float16*)gamma, (const _Float16*)beta, silu,
-                     (_Float16*)out, total8);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s, partial, nchunk, groups, C,
+                     (float)hw * (float)(C / groups), eps, (const _Float16*)gamma, (const _Float16*)beta, stats, total);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + GN_APPLY_PIX - 1) / GN_APPLY_PIX, batch), dim3(256), 0, s, (const _Float16*)x0,
+                     (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out);
   return check_launch("groupnorm kernels");
 }
 
@@ -251,4 +290,21 @@ extern "C" int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale,
   if (rows <= 0 || n <= 0 || ld < n) return fail(COMA_E_INVALID, "sd_softmax_f16: bad shape");
   hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (_Float16*)x, n, ld, scale);
   return check_launch("softmax_kernel");
+}
+
+extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                                         const void* gamma, const void* beta, int silu, void* out, float* stats,
+                                         const float* colstats0, const float* colstats1, void* stream) {
+  if (!x0 || !gamma || !beta || !out || !stats || !colstats0) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: null pointer");
+  if (c1 > 0 && (!x1 || !colstats1)) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: second source incomplete");
+  const int C = c0 + c1;
+  if (batch <= 0 || hw <= 0 || hw % 64 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || c1 % 8)
+    return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: bad shape C=%d groups=%d hw=%d", C, groups, hw);
+  hipStream_t s = (hipStream_t)stream;
+  const int total = batch * groups;
+  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3((total + 3) / 4), dim3(256), 0, s, colstats0, colstats1, c0, c1, hw, groups,
+                     eps, (const _Float16*)gamma, (const _Float16*)beta, stats, total);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + GN_APPLY_PIX - 1) / GN_APPLY_PIX, batch), dim3(256), 0, s, (const _Float16*)x0,
+                     (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out);
+  return check_launch("groupnorm (colstats) kernels");
 }

@@ -22,6 +22,8 @@ class LaunchGraph:
         self._graph = None
         self._gn_stats = None
         self._ws = None             # split-K workspace shared by every GEMM of the graph (launches are serial)
+        self._colstats = {}         # data_ptr of a GEMM output -> its [M/64][2][N] column-sum buffer (GroupNorm statistics)
+        self.fuse_gn_stats = True
 
     # ---- memory
     def buf(self, *shape, dtype=F16, zero=False):
@@ -46,6 +48,12 @@ class LaunchGraph:
         if self._ws is None:
             self._ws = torch.empty(16 << 20, dtype=torch.float32, device=self.device)   # 64 MiB
         kw.setdefault("workspace", self._ws)
+        # GroupNorm statistics of the consumer come for free from the epilogue of large, never-split GEMMs
+        M = batch * oh * ow
+        if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= 16384 and M % 64 == 0:
+            cs = torch.zeros(M // 64, 2, n, dtype=torch.float32, device=self.device)
+            kw["colstats"] = cs
+            self._colstats[out.data_ptr()] = cs
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
                                        c1=c1, taps=taps, **kw),
                  flops=2 * batch * oh * ow * n * taps * (c0 + c1) * z,
@@ -54,8 +62,15 @@ class LaunchGraph:
 
     def groupnorm(self, x0, gamma, beta, out, *, batch, hw, c0, x1=None, c1=0, eps, silu):
         stats = self.gn_scratch(batch, hw)
-        self.add(lambda: ops.groupnorm(x0, gamma, beta, out, stats, batch=batch, hw=hw, c0=c0, x1=x1, c1=c1, eps=eps, silu=silu),
-                 tag=f"groupnorm B={batch} hw={hw} C={c0 + c1}")
+        cs0 = self._colstats.get(x0.data_ptr())
+        cs1 = self._colstats.get(x1.data_ptr()) if x1 is not None else None
+        if cs0 is not None and (x1 is None or cs1 is not None) and hw % 64 == 0:
+            self.add(lambda: ops.groupnorm_colstats(x0, gamma, beta, out, stats, cs0, batch=batch, hw=hw, c0=c0, x1=x1, c1=c1,
+                                                    colstats1=cs1, eps=eps, silu=silu),
+                     tag=f"groupnorm(colstats) B={batch} hw={hw} C={c0 + c1}")
+        else:
+            self.add(lambda: ops.groupnorm(x0, gamma, beta, out, stats, batch=batch, hw=hw, c0=c0, x1=x1, c1=c1, eps=eps, silu=silu),
+                     tag=f"groupnorm B={batch} hw={hw} C={c0 + c1}")
         return out
 
     def layernorm(self, x, gamma, beta, out, *, rows, c):

@@ -19,7 +19,7 @@ class ConvGemmDesc(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("bias_bn", C.c_void_p), ("ldbb", C.c_int), ("res", C.c_void_p), ("ldr", C.c_int),
                 ("out", C.c_void_p), ("ldo", C.c_int), ("epi", C.c_int), ("nbatch_z", C.c_int),
                 ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colstats", C.c_void_p)]
 
 
 def _p(t, name="tensor", dtype=F16):
@@ -34,7 +34,7 @@ def _stream(t):
 
 def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a1=None, c1=0, taps=1, stride=1, upsample=0,
               pad=1, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, epi=EPI_NONE, nbatch_z=1, stride_a=0, stride_w=0,
-              stride_out=0, stride_res=0, workspace=None):
+              stride_out=0, stride_res=0, workspace=None, colstats=None):
     d = ConvGemmDesc()
     d.a0, d.a1, d.c0, d.c1 = _p(a0, "a0"), _p(a1, "a1"), c0, c1
     d.batch, d.in_h, d.in_w = batch, in_h, in_w
@@ -47,6 +47,8 @@ def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a
     d.stride_a, d.stride_w, d.stride_out, d.stride_res = stride_a, stride_w, stride_out, stride_res
     if workspace is not None:
         d.workspace, d.workspace_bytes = _p(workspace, "workspace", torch.float32), workspace.numel() * 4
+    if colstats is not None:
+        d.colstats = _p(colstats, "colstats", torch.float32)
     _lib.check(_lib.lib().sd_conv_gemm_f16(C.byref(d), _stream(out)), "sd_conv_gemm_f16")
     return out
 
@@ -63,8 +65,18 @@ def groupnorm(x0, gamma, beta, out, stats, *, batch, hw, c0, x1=None, c1=0, grou
     return out
 
 
-def gn_scratch_floats(batch, hw, groups=32):
-    return batch * groups * 2 * (1 + (hw + 63) // 64)
+def groupnorm_colstats(x0, gamma, beta, out, stats, colstats0, *, batch, hw, c0, x1=None, c1=0, colstats1=None, groups=32, eps=1e-5,
+                       silu=True):
+    f32 = torch.float32
+    rc = _lib.lib().sd_groupnorm_colstats_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, hw, groups, eps, _p(gamma), _p(beta),
+                                              1 if silu else 0, _p(out, "out"), _p(stats, "stats", f32),
+                                              _p(colstats0, "colstats0", f32), _p(colstats1, "colstats1", f32), _stream(out))
+    _lib.check(rc, "sd_groupnorm_colstats_f16")
+    return out
+
+
+def gn_scratch_floats(batch, hw, groups=32, channels=2560):
+    return batch * channels * 2 + batch * groups * 2 * ((hw + 63) // 64)
 
 
 def layernorm(x, gamma, beta, out, *, rows, c, eps=1e-5):

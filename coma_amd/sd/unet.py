@@ -79,7 +79,7 @@ class HipUNet2DConditionModel:
         H, W = self.H, self.W
         w_in = conv_weight(s["conv_in.weight"], cin_pad=64)
         h = g.buf(B * H * W, ch[0])
-        g.conv(self.x_in, w_in, h, batch=B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9, bias=s["conv_in.bias"])
+        g.conv(self.x_in, w_in, h, batch=B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9, bias=s["conv_in.bias"], stats=True)
         skips = [(h, ch[0], H, W)]
         cin = ch[0]
         for i, cout in enumerate(ch):
@@ -93,7 +93,7 @@ class HipUNet2DConditionModel:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 o = g.buf(B * (H // 2) * (W // 2), cout)
                 g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=H // 2, out_w=W // 2, c0=cout,
-                       n=cout, taps=9, stride=2, bias=s[p + ".bias"])
+                       n=cout, taps=9, stride=2, bias=s[p + ".bias"], stats=True)
                 h, H, W = o, H // 2, W // 2
                 skips.append((h, cout, H, W))
         h = self._resnet("mid_block.resnets.0", h, cin, None, 0, cin, H, W)
@@ -111,7 +111,7 @@ class HipUNet2DConditionModel:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 o = g.buf(B * 4 * H * W, cout)
                 g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout,
-                       n=cout, taps=9, upsample=1, bias=s[p + ".bias"])
+                       n=cout, taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
                 h, H, W = o, 2 * H, 2 * W
         gn = g.buf(B * H * W, cin)
         g.groupnorm(h, s["conv_norm_out.weight"], s["conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin, eps=1e-5, silu=True)
@@ -128,7 +128,7 @@ class HipUNet2DConditionModel:
         h = g.buf(M, cout)
         off = self._tb_off[p]
         g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
-               bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld)
+               bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
         n2 = g.buf(M, cout)
         g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
         if p + ".conv_shortcut.weight" in s:
@@ -140,7 +140,7 @@ class HipUNet2DConditionModel:
             sc = x0
         out = g.buf(M, cout)
         g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
-               bias=s[p + ".conv2.bias"], res=sc)
+               bias=s[p + ".conv2.bias"], res=sc, stats=True)
         return out
 
     def _transformer(self, p, x, C, H, W):
@@ -193,7 +193,7 @@ class HipUNet2DConditionModel:
         g.conv(f, s[t + ".ff.net.2.weight"], h3, batch=M, in_h=1, in_w=1, c0=4 * C, n=C, bias=s[t + ".ff.net.2.bias"], res=h2)
         out = g.buf(M, C)
         g.conv(h3, conv_weight(s[p + ".proj_out.weight"]), out, batch=M, in_h=1, in_w=1, c0=C, n=C,
-               bias=s[p + ".proj_out.bias"], res=x)
+               bias=s[p + ".proj_out.bias"], res=x, stats=True)
         return out
 
     # ------------------------------------------------------------------ execution

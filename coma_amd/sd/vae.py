@@ -35,7 +35,8 @@ class _VaeBase:
         n1 = g.buf(M, cin)
         g.groupnorm(x, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=cin, eps=1e-6, silu=True)
         h = g.buf(M, cout)
-        g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9, bias=s[p + ".conv1.bias"])
+        g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9, bias=s[p + ".conv1.bias"],
+               stats=True)
         n2 = g.buf(M, cout)
         g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-6, silu=True)
         if p + ".conv_shortcut.weight" in s:
@@ -46,7 +47,7 @@ class _VaeBase:
             sc = x
         out = g.buf(M, cout)
         g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
-               bias=s[p + ".conv2.bias"], res=sc)
+               bias=s[p + ".conv2.bias"], res=sc, stats=True)
         return out
 
     def _attention(self, p, x, C, H, W):
@@ -67,7 +68,7 @@ class _VaeBase:
         a = g.buf(M, C)
         g.conv(sc, vt, a, batch=L, in_h=1, in_w=1, c0=L, n=C, nbatch_z=B, stride_a=L * L, stride_w=C * L, stride_out=L * C)
         out = g.buf(M, C)
-        g.conv(a, s[p + ".to_out.0.weight"], out, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_out.0.bias"], res=x)
+        g.conv(a, s[p + ".to_out.0.weight"], out, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_out.0.bias"], res=x)   # (M tokens as batch: no stats)
         return out
 
     def _replay(self):
@@ -107,7 +108,7 @@ class HipVaeDecoder(_VaeBase):
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 o = g.buf(B * 4 * H * W, cout)
                 g.conv(x, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout, n=cout,
-                       taps=9, upsample=1, bias=s[p + ".bias"])
+                       taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
                 x, H, W = o, 2 * H, 2 * W
         gn = g.buf(B * H * W, cin)
         g.groupnorm(x, s["decoder.conv_norm_out.weight"], s["decoder.conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin,
@@ -144,7 +145,7 @@ class HipVaeEncoder(_VaeBase):
                 o = g.buf(B * (H // 2) * (W // 2), cout)
                 # F.pad(x, (0,1,0,1)) + conv stride 2 padding 0  ==  low-side pad 0, high side bounds-checked
                 g.conv(x, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=H // 2, out_w=W // 2, c0=cout, n=cout,
-                       taps=9, stride=2, pad=0, bias=s[p + ".bias"])
+                       taps=9, stride=2, pad=0, bias=s[p + ".bias"], stats=True)
                 x, H, W = o, H // 2, W // 2
         x = self._resnet("encoder.mid_block.resnets.0", x, cin, cin, H, W)
         x = self._attention("encoder.mid_block.attentions.0", x, cin, H, W)

@@ -57,6 +57,8 @@ typedef struct sd_conv_gemm_desc {
   int64_t stride_a, stride_w, stride_out, stride_res;
   void* workspace;      /* optional fp32 scratch for split-K (small M*N, deep K); NULL disables split-K */
   size_t workspace_bytes;
+  float* colstats;      /* optional fp32 [M/64][2][n]: per 64-row block, column sums and sums of squares of the stored output
+                           (the GroupNorm statistics of the consumer, sd_groupnorm_f16 colstats0/1); needs M % 64 == 0 */
 } sd_conv_gemm_desc;
 
 int sd_conv_gemm_f16(const sd_conv_gemm_desc* desc, void* stream);
@@ -65,9 +67,14 @@ size_t sd_conv_gemm_workspace_bytes(void); /* recommended workspace size */
 /* GroupNorm (+ optional SiLU) over NHWC fp16, reading the channel concatenation of two sources and writing one
  * tensor [batch, hw, c0+c1].  replaces: nn.GroupNorm(groups, C, eps) + nn.SiLU in diffusers ResnetBlock2D /
  * Transformer2DModel / VAE (and the torch.cat feeding the UNet up blocks).
- * stats: fp32 scratch [batch*groups*2]. */
+ * stats: fp32 scratch of batch*(c0+c1)*2 + batch*ceil(hw/64)*groups*2 floats (affine table + partial sums). */
 int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                      const void* gamma, const void* beta, int silu, void* out, float* stats, void* stream);
+/* Same, but the statistics come from the column sums the producing GEMMs left behind (sd_conv_gemm_desc.colstats of x0
+ * and, with two sources, of x1): no statistics pass over the tensor.  hw % 64 == 0. */
+int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
+                              const void* gamma, const void* beta, int silu, void* out, float* stats, const float* colstats0,
+                              const float* colstats1, void* stream);
 
 /* LayerNorm over the last dim of fp16 [rows, c].  replaces: nn.LayerNorm(C) in BasicTransformerBlock. */
 int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* gamma, const void* beta, void* out,

@@ -219,3 +219,32 @@ def test_layout_conversions_and_u8(ops):
         v = (img.float()[:, :, :3] * 0.5 + 0.5).clamp(0, 1) * 255
         ref = (v.round() if mode else v.floor()).to(torch.uint8)
         assert torch.equal(u8.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,c0,c1,n,hw", [(16384, 64, 0, 320, 4096), (32768, 64, 64, 640, 1024)])
+def test_groupnorm_statistics_fused_into_the_gemm_epilogue(ops, M, c0, c1, n, hw):
+    """The producing GEMM leaves per-64-row column sums; GroupNorm built from them must equal GroupNorm of the tensor."""
+    B = M // hw
+    x0 = rnd(M, c0, seed=1)
+    x1 = rnd(M, c1, seed=5) if c1 else None
+    w, b, r = rnd(n, c0 + c1, seed=2, scale=(c0 + c1) ** -0.5), rnd(n, seed=3), rnd(M, n, seed=4)
+    out = torch.empty(M, n, dtype=F16, device=DEV)
+    cs = torch.zeros(M // 64, 2, n, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(x0.to(DEV), w.to(DEV), out, batch=M, in_h=1, in_w=1, c0=c0, n=n, a1=x1.to(DEV) if c1 else None, c1=c1,
+                  bias=b.to(DEV), res=r.to(DEV), colstats=cs)
+    o = out.float().cpu()
+    ref_sum = o.reshape(M // 64, 64, n).sum(1)
+    assert float((cs[:, 0].cpu() - ref_sum).abs().max()) <= 1e-3 * float(ref_sum.abs().max()) + 1e-3
+    ref_sq = (o * o).reshape(M // 64, 64, n).sum(1)
+    assert float((cs[:, 1].cpu() - ref_sq).abs().max()) <= 1e-3 * float(ref_sq.abs().max())
+    ga, be = rnd(n, seed=6) * 0.2 + 1, rnd(n, seed=7) * 0.2
+    y = torch.empty(M, n, dtype=F16, device=DEV)
+    stats = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+    ops.groupnorm_colstats(out, ga.to(DEV), be.to(DEV), y, stats, cs, batch=B, hw=hw, c0=n, eps=1e-5, silu=True)
+    close(y, so.groupnorm_ref(out.cpu(), ga, be, batch=B, hw=hw, eps=1e-5, silu=True))
+    # two-source form: [out | out] with both column-sum buffers
+    y2 = torch.empty(M, 2 * n, dtype=F16, device=DEV)
+    ga2, be2 = torch.cat([ga, ga]), torch.cat([be, be])
+    ops.groupnorm_colstats(out, ga2.to(DEV), be2.to(DEV), y2, stats, cs, batch=B, hw=hw, c0=n, x1=out, c1=n, colstats1=cs, eps=1e-5,
+                           silu=False)
+    close(y2, so.groupnorm_ref(torch.cat([out.cpu(), out.cpu()], -1), ga2, be2, batch=B, hw=hw, eps=1e-5, silu=False))
