@@ -127,26 +127,41 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   gn_write_affine(s, q, count, eps, b, g, C / groups, C, gamma, beta, affine, lane);
 }
 
-// the same from per-64-row-block column sums [rb][2][C] of one or two producers
+// the same from per-64-row-block column sums [rb][2][C] of one or two producers: one 256-thread block per (b, g),
+// thread t owns channel (t % cg) of the group and every (256 / cg)-th row block; LDS fold in a fixed order
 __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* __restrict__ cs0, const float* __restrict__ cs1,
                                                                   int c0, int c1, int hw, int groups, float eps,
                                                                   const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
-                                                                  float* __restrict__ affine, int total) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, g)
-  const int lane = threadIdx.x & 63;
-  if (i >= total) return;
+                                                                  float* __restrict__ affine) {
+  __shared__ float rs[256], rq[256];
   const int C = c0 + c1, cg = C / groups, rbs = hw / 64;
-  const int b = i / groups, g = i - b * groups;
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
+  const int per = 256 / cg;                       // row-block lanes (cg <= 80 in every SD layer)
+  const int tc = threadIdx.x % cg, tr = threadIdx.x / cg;
   float s = 0.0f, q = 0.0f;
-  for (int it = lane; it < rbs * cg; it += 64) {
-    const int rb = it / cg, c = g * cg + (it - rb * cg);
-    const float* p = c < c0 ? cs0 + ((long long)(b * rbs + rb) * 2) * c0 + c : cs1 + ((long long)(b * rbs + rb) * 2) * c1 + (c - c0);
-    s += p[0];
-    q += p[c < c0 ? c0 : c1];
+  if (tr < per) {
+    const int c = g * cg + tc;
+    const float* base = c < c0 ? cs0 + c : cs1 + (c - c0);
+    const int cw = c < c0 ? c0 : c1;
+    for (int rb = tr; rb < rbs; rb += per) {
+      const float* p = base + ((long long)(b * rbs + rb) * 2) * cw;
+      s += p[0];
+      q += p[cw];
+    }
   }
-  s = wave_sum(s);
-  q = wave_sum(q);
-  gn_write_affine(s, q, (float)hw * (float)cg, eps, b, g, cg, C, gamma, beta, affine, lane);
+  rs[threadIdx.x] = s;
+  rq[threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float ss = 0.0f, qq = 0.0f;
+    for (int i = threadIdx.x; i < per * cg; i += 64) {
+      ss += rs[i];
+      qq += rq[i];
+    }
+    ss = wave_sum(ss);
+    qq = wave_sum(qq);
+    gn_write_affine(ss, qq, (float)hw * (float)cg, eps, b, g, cg, C, gamma, beta, affine, threadIdx.x);
+  }
 }
 
 // y = silu(x * scale + shift): blockIdx.y = sample, tx = 8-channel chunk, ty = pixel lane -> no integer division
@@ -302,8 +317,9 @@ extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0,
     return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: bad shape C=%d groups=%d hw=%d", C, groups, hw);
   hipStream_t s = (hipStream_t)stream;
   const int total = batch * groups;
-  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3((total + 3) / 4), dim3(256), 0, s, colstats0, colstats1, c0, c1, hw, groups,
-                     eps, (const _Float16*)gamma, (const _Float16*)beta, stats, total);
+  if (C / groups > 256) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: more than 256 channels per group");
+  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(total), dim3(256), 0, s, colstats0, colstats1, c0, c1, hw, groups, eps,
+                     (const _Float16*)gamma, (const _Float16*)beta, stats);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + GN_APPLY_PIX - 1) / GN_APPLY_PIX, batch), dim3(256), 0, s, (const _Float16*)x0,
                      (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out);
   return check_launch("groupnorm (colstats) kernels");
