@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA results land directly in VGPRs (gfx950 has one unified register file); without it hipcc
 # parks accumulators in AGPRs and pays a v_accvgpr_read/write per element every time VALU code (softmax, epilogues)
 # touches them -- 159 extra instructions per attention key tile.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 

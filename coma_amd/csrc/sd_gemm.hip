@@ -32,7 +32,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128;
 constexpr int BKMIN = 32;   // source channel counts must be multiples of this (and of 64 for the deep-K variant)
 
 struct GemmArgs {
@@ -70,10 +69,6 @@ __device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int 
   return v;
 }
 
-// 128 bytes of zeros: the source of every out-of-image (zero padding) or out-of-range row of a tile
-__device__ __attribute__((aligned(128))) uint4 g_zero_page[8];
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // LDS tile image: [rows][BK halves], unpadded rows filled by LDS-DMA (global_load_lds, 16 B per lane), so one wave
@@ -100,10 +95,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 //        cycles per wave instruction and NOT overlapped with MFMA issue, the limiter of the 128 x 128 tile (0.5 DMA per
 //        MFMA) -- drops to 0.225 DMA per MFMA.
 //   <WM=2, WN=1/2, ...> 64-wide fallbacks for small N.
-template <int WM, int WN, int TN, int BK, int STAGES>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm_kernel(GemmArgs g) {
+template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per block
-  constexpr int NT = NW * 64;
   constexpr int BM_ = WM * 64, BN = WN * TN * 32;
   constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
   constexpr int RPI = 64 / CPR;                     // tile rows written by one wave-wide DMA instruction
@@ -138,97 +132,126 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm
     n_tile = blockIdx.x / m_tiles;
   }
   if (m_tile >= m_tiles || n_tile >= n_tiles) return;   // padding block (exits before any barrier)
-  const int m0 = m_tile * BM_;
-  const int n0 = n_tile * BN;
+  // integer divisions run on the VALU; readfirstlane moves their (wave-uniform) results back to SGPRs so that the
+  // loop control, the tile bookkeeping and the DMA descriptors below stay scalar
+  const int m0 = __builtin_amdgcn_readfirstlane(m_tile * BM_);
+  const int n0 = __builtin_amdgcn_readfirstlane(n_tile * BN);
   const bool split = g.ksplit > 1;
   const long long z = split ? 0 : blockIdx.y;
   const _Float16* a0 = g.a0 + z * g.sa;
   const _Float16* wp = g.w + z * g.sw;
   const int ctot = g.c0 + g.c1;
-  const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
 
   // K range of this block (split-K) in units of BK tiles
   const int nk_all = g.K / BK;
   int kt0 = 0, nk = nk_all;
-  if (g.epi & (1 << 17)) nk = 0;          // tuning knob: skip the K loop
   if (split) {
     const int per = (nk_all + g.ksplit - 1) / g.ksplit;
     kt0 = blockIdx.y * per;
     nk = min(per, nk_all - kt0);
     if (nk < 0) nk = 0;
   }
+  kt0 = __builtin_amdgcn_readfirstlane(kt0);
+  nk = __builtin_amdgcn_readfirstlane(nk);
 
   // DMA role of this lane: instruction j of this wave covers tile rows (wave*A_LD + j)*RPI .. +RPI-1; lane -> row
-  // +lane/CPR, LDS slot lane%CPR, which must receive K-chunk slot ^ swizzle(row)
+  // +lane/CPR, LDS slot lane%CPR, which must receive K-chunk slot ^ swizzle(row).  The transfers are
+  // `buffer_load_dwordx4 ... offen lds`: per row ONE 32-bit byte offset in a VGPR (rebuilt only when the tap or the
+  // source tensor changes), the K position of the tile in the scalar offset, so a tile's DMA issue costs no VALU work.
+  // Rows that are zero padding (or beyond M) carry the offset 0x80000000, which fails the buffer range check: the
+  // hardware then writes zeros into LDS.
+  constexpr unsigned OOB = 0x80000000u;
   const int l_row = lane / CPR, l_slot = lane % CPR;
-  int a_n[A_LD], a_y[A_LD], a_x[A_LD], a_koff[A_LD];
-  bool a_ok[A_LD];
+  int a_n[A_LD], a_yx[A_LD];          // sample index; (y, x) of tap (0,0) packed as two int16 (y = -16384 -> row >= M)
+  unsigned a_koff[A_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
     const int r = (wave * A_LD + j) * RPI + l_row;
-    a_koff[j] = swz<BK>(r, l_slot) * 8;
+    a_koff[j] = swz<BK>(r, l_slot) * 16;
     const int m = m0 + r;
-    a_ok[j] = m < g.M;
-    const int mm = a_ok[j] ? m : 0;
+    const bool ok = m < g.M;
+    const int mm = ok ? m : 0;
     a_n[j] = mm / g.rows_per_batch;
     const int rem = mm - a_n[j] * g.rows_per_batch;
     const int oy = rem / g.out_w;
-    a_y[j] = oy * g.stride - g.pad;
-    a_x[j] = (rem - oy * g.out_w) * g.stride - g.pad;
+    const int y = ok ? oy * g.stride - g.pad : -16384;
+    const int x = (rem - oy * g.out_w) * g.stride - g.pad;
+    a_yx[j] = (y << 16) | (x & 0xffff);
   }
-  const _Float16* b_ptr[B_LD];     // row pointer + swizzled chunk offset (or null -> zero page)
+  unsigned b_off[B_LD];               // byte offset of (weight row, swizzled chunk); rows >= N re-read row N-1 (never stored)
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     const int r = (wave * B_LD + j) * RPI + l_row;
-    const int n = n0 + r;
-    b_ptr[j] = n < g.N ? wp + (long long)n * g.K + swz<BK>(r, l_slot) * 8 : nullptr;
+    const int n = min(n0 + r, g.N - 1);
+    b_off[j] = (unsigned)(n * g.K) * 2u + swz<BK>(r, l_slot) * 16;
   }
+  // buffer resources and scalar offsets must live in SGPRs: pin them with readfirstlane (every input is wave-uniform,
+  // but the compiler's divergence analysis would otherwise wrap each DMA in a waterfall loop)
+  auto make_rsrc = [](const void* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wp);
   const int lim_h = g.upsample ? 2 * g.in_h : g.in_h;
   const int lim_w = g.upsample ? 2 * g.in_w : g.in_w;
 
-  // running position of the NEXT tile to load: tap index and channel offset inside the concatenation.  Per row the
-  // element pointer of (pixel of the current tap, channel 0 of the current source) is kept ready so that a tile's DMA
-  // address is one 64-bit add; it is rebuilt only when the tap or the source tensor changes.
-  int ld_tap = (kt0 * BK) / ctot;
+  // running position of the NEXT tile to load: tap index and channel offset inside the concatenation
+  int ld_tap = __builtin_amdgcn_readfirstlane((kt0 * BK) / ctot);
   int ld_ci = kt0 * BK - ld_tap * ctot;
   int ld_src = -1;                    // 0: a0, 1: a1
-  const _Float16* a_ptr[A_LD];        // pixel base pointer (+ swizzled chunk offset) or null -> zero page
+  unsigned a_off[A_LD];
   auto repoint = [&]() {
     const int ky = g.taps == 9 ? ld_tap / 3 : 0;
     const int kx = g.taps == 9 ? ld_tap - ky * 3 : 0;
-    ld_src = ld_ci >= g.c0 ? 1 : 0;
-    const _Float16* src = ld_src ? g.a1 : a0;
-    const int csrc = ld_src ? g.c1 : g.c0;
+    ld_src = __builtin_amdgcn_readfirstlane(ld_ci >= g.c0 ? 1 : 0);
+    const int csrc2 = (ld_src ? g.c1 : g.c0) * 2;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      int iy = a_y[j] + ky, ix = a_x[j] + kx;
-      const bool ok = a_ok[j] && iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w;
+      int iy = (a_yx[j] >> 16) + ky, ix = (int)(short)(a_yx[j] & 0xffff) + kx;
+      const bool ok = iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w;
       if (g.upsample) { iy >>= 1; ix >>= 1; }
-      a_ptr[j] = ok ? src + (((long long)a_n[j] * g.in_h + iy) * g.in_w + ix) * csrc + a_koff[j] : nullptr;
+      a_off[j] = ok ? (unsigned)((a_n[j] * g.in_h + iy) * g.in_w + ix) * (unsigned)csrc2 + a_koff[j] : OOB;
     }
   };
   repoint();
 
-  auto issue_tile = [&](int buf) {          // LDS-DMA of the tile at (ld_tap, ld_ci) into stage `buf`; advances
-    const int ci = ld_src ? ld_ci - g.c0 : ld_ci;
-    _Float16* ad = As0 + buf * (BM_ * BK) + wave * A_LD * RPI * BK;
-    if (!(g.epi & (1 << 19)))      // tuning knob: skip the A-tile DMA
-#pragma unroll
-      for (int j = 0; j < A_LD; ++j) {
-        const _Float16* p = a_ptr[j] ? a_ptr[j] + ci : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(ad + j * RPI * BK), 16, 0, 0);
-      }
-    const int k0 = ld_tap * ctot + ld_ci;
-    _Float16* bd = Bs0 + buf * (BN * BK) + wave * B_LD * RPI * BK;
-    if (!(g.epi & (1 << 18)))      // tuning knob: skip the W-tile DMA
-#pragma unroll
-      for (int j = 0; j < B_LD; ++j) {
-        const _Float16* p = b_ptr[j] ? b_ptr[j] + k0 : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(bd + j * RPI * BK), 16, 0, 0);
-      }
-    ld_ci += BK;
-    if (ld_ci >= ctot) { ld_ci = 0; ++ld_tap; repoint(); }
+  // LDS-DMA of the tile at (ld_tap, ld_ci) into stage `buf`: instruction `idx` of this wave's LPT (A first, then W)
+  auto issue_one = [&](int buf, auto idx_c) {
+    constexpr int idx = decltype(idx_c)::value;
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (and cannot type the LDS-DMA builtin)
+    if constexpr (idx < A_LD) {
+      const int ci = ld_src ? ld_ci - g.c0 : ld_ci;
+      _Float16* ad = As0 + buf * (BM_ * BK) + wave * A_LD * RPI * BK;
+      const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(ld_src ? g.a1 : a0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(ad + idx * RPI * BK), 16, a_off[idx], __builtin_amdgcn_readfirstlane(ci * 2), 0, 0);
+    } else {
+      constexpr int j = idx - A_LD;
+      const int k0 = ld_tap * ctot + ld_ci;
+      _Float16* bd = Bs0 + buf * (BN * BK) + wave * B_LD * RPI * BK;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(bd + j * RPI * BK), 16, b_off[j], __builtin_amdgcn_readfirstlane(k0 * 2), 0, 0);
+    }
+#endif
+  };
+  auto issue_range = [&](int buf, auto lo_c, auto hi_c) {
+    constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+    if constexpr (lo < hi) {
+      issue_one(buf, std::integral_constant<int, lo>{});
+      if constexpr (lo + 1 < hi) issue_one(buf, std::integral_constant<int, lo + 1>{});
+      if constexpr (lo + 2 < hi) issue_one(buf, std::integral_constant<int, lo + 2>{});
+      if constexpr (lo + 3 < hi) issue_one(buf, std::integral_constant<int, lo + 3>{});
+      static_assert(hi - lo <= 4, "at most four DMA instructions per K step");
+    }
+  };
+  auto advance_tile = [&]() {
+    ld_ci = __builtin_amdgcn_readfirstlane(ld_ci + BK);
+    if (ld_ci >= ctot) { ld_ci = 0; ld_tap = __builtin_amdgcn_readfirstlane(ld_tap + 1); repoint(); }
     else if ((ld_ci >= g.c0) != (ld_src == 1)) repoint();
+  };
+  auto issue_tile = [&](int buf) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (issue_one(buf, std::integral_constant<int, I>{}), ...); }
+    (std::make_integer_sequence<int, LPT>{});
+    advance_tile();
   };
 
   float16v acc[2][TN];
@@ -250,7 +273,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue_tile(s);
-  for (int kt = 0; kt < nk; ++kt) {
+  constexpr int KS = BK / 16;
+  auto k_tile = [&](int kt, auto next_c) {
+    constexpr bool NEXT = decltype(next_c)::value;     // a tile kt+STAGES-1 exists and is issued during this one
     // wait for tile kt only: the (up to STAGES-2) younger tiles stay in flight across the barrier.  A raw s_barrier is
     // used on purpose -- __syncthreads() would drain the DMA queue (its release carries vmcnt(0)).
     const int younger = min(nk - 1, kt + STAGES - 2) - kt;
@@ -263,24 +288,35 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm
     }
     __builtin_amdgcn_s_barrier();
     // every wave has finished reading the stage that tile kt+STAGES-1 overwrites (it held tile kt-1)
-    if (kt + STAGES - 1 < nk) issue_tile((kt + STAGES - 1) % STAGES);
+    const int nbuf = (kt + STAGES - 1) % STAGES;
+    if constexpr (NEXT && !SPREAD) issue_tile(nbuf);
     const _Float16* Ab = As0 + (kt % STAGES) * (BM_ * BK);
     const _Float16* Bb = Bs0 + (kt % STAGES) * (BN * BK);
+    [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
+      ([&] {
+        constexpr int ks = KSI;
+        half8 af[2], bf[TN];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      half8 af[2], bf[TN];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const half8*>(Ab + a_fr[i] * BK + swz<BK>(a_fr[i], 2 * ks + fhalf) * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const half8*>(Bb + b_fr[j] * BK + swz<BK>(b_fr[j], 2 * ks + fhalf) * 8);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const half8*>(Ab + a_fr[i] * BK + swz<BK>(a_fr[i], 2 * ks + fhalf) * 8);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-    }
+          bf[j] = *reinterpret_cast<const half8*>(Bb + b_fr[j] * BK + swz<BK>(b_fr[j], 2 * ks + fhalf) * 8);
+        if constexpr (NEXT && SPREAD)      // this K step's share of the next tile's DMA, between its LDS reads and MFMAs
+          issue_range(nbuf, std::integral_constant<int, ks * LPT / KS>{}, std::integral_constant<int, (ks + 1) * LPT / KS>{});
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }(), ...);
+    }(std::make_integer_sequence<int, KS>{});
+    if constexpr (NEXT && SPREAD) advance_tile();
+  };
+  {
+    int kt = 0;
+    for (; kt + STAGES - 1 < nk; ++kt) k_tile(kt, std::true_type{});
+    for (; kt < nk; ++kt) k_tile(kt, std::false_type{});
   }
 
   // ---------------------------------------------------------------- epilogue
@@ -310,7 +346,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8) ? 2 : 2) void conv_gemm
     }
     return;
   }
-  if (g.epi & (1 << 16)) return;          // tuning knob: skip the write-back
   _Float16* outp = g.out + z * g.so;
   const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
   const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
@@ -562,7 +597,10 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (lin_blocks > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: grid too large");
   dim3 grid((unsigned)lin_blocks, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
   hipStream_t st = (hipStream_t)stream;
-  if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
+  const bool spread = !(d->epi & (1 << 22));   // tuning knob: DMA issued in one burst instead of spread over the K steps
+  if (big && spread) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2, true>), grid, dim3(512), 0, st, g);
+  else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2, true>), grid, dim3(256), 0, st, g);
+  else if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
   else if (big_geglu || big256) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
   else if (big128) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 2, 64, 2>), grid, dim3(512), 0, st, g);
   else if (mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 3>), grid, dim3(256), 0, st, g);

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Time single conv_gemm shapes (tuning aid)."""
-import sys, os, time
+"""Time single conv_gemm shapes (tuning aid): python scripts/time_gemm.py [knob_bits ...]"""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coma_amd.sd import ops
 dev = "cuda:0"
+
+
 def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
     C = K // taps
     if taps == 9:
@@ -28,8 +30,16 @@ def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
     e.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(e) / reps
     return ms, 2 * M * N * K / ms / 1e9
-for (M, N, K, taps, hw) in [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 1280, 1, None), (16384, 640, 640, 1, None),
-                            (4096, 1280, 1280, 1, None), (65536, 640, 5760, 9, 4096)]:
-    for name, epi in [("staged", 0), ("direct", 1 << 22)]:
+
+
+SHAPES = [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 1280, 1, None), (65536, 640, 5760, 9, 4096),
+          (16384, 640, 640, 1, None), (16384, 640, 5760, 9, 1024), (16384, 1280, 11520, 9, 1024),
+          (4096, 1280, 1280, 1, None), (4096, 1280, 5120, 1, None), (4096, 1280, 11520, 9, 256), (4096, 1280, 23040, 9, 256),
+          (1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64)]
+knobs = [0] + [sum(1 << int(b) for b in a.split("+")) for a in sys.argv[1:]]
+for (M, N, K, taps, hw) in SHAPES:
+    row = []
+    for epi in knobs:
         ms, tf = bench(M, N, K, taps=taps, epi=epi, hw=hw, res=True)
-        print(f"M={M} N={N} K={K} taps={taps} {name:8s} {ms*1e3:8.1f} us  {tf:7.1f} TF/s")
+        row.append(f"{ms*1e3:7.1f} us {tf:6.1f} TF")
+    print(f"M={M:6d} N={N:5d} K={K:6d} taps={taps} | " + " | ".join(row))
