@@ -58,7 +58,19 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// x * Phi(x) = 0.5 x erfc(-x / sqrt 2) with erfc from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, relative in the
+// negative tail because erfc is formed directly): erfc(a) = t (a1 + t (a2 + ...)) exp(-a^2), t = 1 / (1 + p a), a >= 0
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float a = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+  const float ex = __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float e = q * t * ex;
+  return 0.5f * x * (x < 0.0f ? e : 2.0f - e);
+}
 
 // Shared epilogue math: v = acc (+bias)(+per-batch bias) -> SiLU -> (+residual)
 __device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int row, int col, const _Float16* resp) {
@@ -586,7 +598,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 256 / bk;
-  if (!g.colstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < (mid ? 192 : 384) && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
+  if (!g.colstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((512 + blocks - 1) / blocks);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;

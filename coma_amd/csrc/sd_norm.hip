@@ -164,6 +164,64 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
   }
 }
 
+// Small feature maps (16 x 16 and 8 x 8 levels of the UNet): one launch, one block per (sample, group).  The group's
+// hw x (C/G) slice (<= GN_SMALL_ITEMS * 256 four-channel chunks) is read ONCE into registers, reduced through LDS in a
+// fixed order, normalised and written -- three launches and two extra passes over L2 become one.
+constexpr int GN_SMALL_ITEMS = 20;
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gn_small_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1, int c0,
+                                                       int c1, int hw, int groups, float eps, const _Float16* __restrict__ gamma,
+                                                       const _Float16* __restrict__ beta, int silu, _Float16* __restrict__ out) {
+  __shared__ float rs[4], rq[4];
+  const int C = c0 + c1, cg = C / groups, q4 = cg / 4;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int items = hw * q4;
+  half4v v[GN_SMALL_ITEMS];
+  float s = 0.0f, q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < GN_SMALL_ITEMS; ++k) {
+    const int it = threadIdx.x + k * 256;
+    if (it < items) {
+      const int p = it / q4, c = g * cg + (it - p * q4) * 4;
+      const long long pix = (long long)b * hw + p;
+      v[k] = *reinterpret_cast<const half4v*>(c < c0 ? x0 + pix * c0 + c : x1 + pix * c1 + (c - c0));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float f = (float)v[k][j];
+        s += f;
+        q += f * f;
+      }
+    }
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rq[threadIdx.x >> 6] = q; }
+  __syncthreads();
+  s = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+  q = (rq[0] + rq[1]) + (rq[2] + rq[3]);
+  const float count = (float)hw * (float)cg;
+  const float mean = s / count;
+  const float var = fmaxf(q / count - mean * mean, 0.0f);
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int k = 0; k < GN_SMALL_ITEMS; ++k) {
+    const int it = threadIdx.x + k * 256;
+    if (it < items) {
+      const int p = it / q4, c = g * cg + (it - p * q4) * 4;
+      const half4v ga = *reinterpret_cast<const half4v*>(gamma + c), be = *reinterpret_cast<const half4v*>(beta + c);
+      half4v o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = rstd * (float)ga[j];
+        float y = fmaf((float)v[k][j], sc, (float)be[j] - mean * sc);
+        if (silu) y = y / (1.0f + __expf(-y));
+        o[j] = (_Float16)y;
+      }
+      *reinterpret_cast<half4v*>(out + ((long long)b * hw + p) * C + c) = o;
+    }
+  }
+}
+
 // y = silu(x * scale + shift): blockIdx.y = sample, tx = 8-channel chunk, ty = pixel lane -> no integer division
 constexpr int GN_APPLY_PIX = 32;     // pixels per block
 __global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
@@ -278,9 +336,15 @@ extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, 
   const int C = c0 + c1;
   if (batch <= 0 || hw <= 0 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || c1 % 8 || C > GN_MAX_C)
     return fail(COMA_E_INVALID, "sd_groupnorm_f16: bad shape C=%d groups=%d", C, groups);
+  hipStream_t s = (hipStream_t)stream;
+  const int cg = C / groups;
+  if (cg % 4 == 0 && c0 % 4 == 0 && (long long)hw * (cg / 4) <= GN_SMALL_ITEMS * 256) {
+    hipLaunchKernelGGL(gn_small_kernel, dim3(groups, batch), dim3(256), 0, s, (const _Float16*)x0, (const _Float16*)x1, c0, c1, hw,
+                       groups, eps, (const _Float16*)gamma, (const _Float16*)beta, silu, (_Float16*)out);
+    return check_launch("gn_small_kernel");
+  }
   const int nchunk = (hw + GN_PIX - 1) / GN_PIX;
   float* partial = stats + (size_t)batch * C * 2;
-  hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, s, (const _Float16*)x0, (const _Float16*)x1, c0, c1,
                      hw, groups, partial);
   const int total = batch * groups;

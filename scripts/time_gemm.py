@@ -36,6 +36,7 @@ SHAPES = [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 
           (16384, 640, 640, 1, None), (16384, 640, 5760, 9, 1024), (16384, 1280, 11520, 9, 1024),
           (4096, 1280, 1280, 1, None), (4096, 1280, 5120, 1, None), (4096, 1280, 11520, 9, 256), (4096, 1280, 23040, 9, 256),
           (1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64)]
+GEGLU = [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)]
 knobs = [0] + [sum(1 << int(b) for b in a.split("+")) for a in sys.argv[1:]]
 for (M, N, K, taps, hw) in SHAPES:
     row = []
@@ -43,3 +44,9 @@ for (M, N, K, taps, hw) in SHAPES:
         ms, tf = bench(M, N, K, taps=taps, epi=epi, hw=hw, res=True)
         row.append(f"{ms*1e3:7.1f} us {tf:6.1f} TF")
     print(f"M={M:6d} N={N:5d} K={K:6d} taps={taps} | " + " | ".join(row))
+for (M, N, K) in GEGLU:
+    row = []
+    for epi in knobs:
+        ms, tf = bench(M, N, K, epi=epi | 1)
+        row.append(f"{ms*1e3:7.1f} us {tf:6.1f} TF")
+    print(f"GEGLU M={M:6d} N={N:5d} K={K:6d} | " + " | ".join(row))

@@ -115,7 +115,8 @@ def test_batched_weight_as_a_operand_gives_v_transposed(ops):
     assert float(out[:, :, L:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 256, True), (640, 320, 64, True), (1280, 640, 100, True), (128, 0, 300, False)])
+@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 256, True), (640, 320, 64, True), (1280, 640, 100, True), (128, 0, 300, False),
+                                           (1280, 1280, 256, True), (1280, 0, 64, True), (1280, 640, 256, False)])
 def test_groupnorm_two_sources(ops, c0, c1, hw, silu):
     B = 2
     x0, x1 = rnd(B * hw, c0, seed=1) + 0.5, (rnd(B * hw, c1, seed=2, scale=2.0) if c1 else None)
