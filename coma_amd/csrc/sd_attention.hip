@@ -15,8 +15,11 @@
 // V must be supplied TRANSPOSED ([heads*d, keys]); the projection GEMM produces that layout directly
 // (sd_conv_gemm_f16 with the weight as the A operand), so no transpose pass exists anywhere.
 //
-// Block = 4 waves x 32 queries = 128 queries of one (batch, head); K / V^T tiles of 64 keys staged in LDS with
-// padded rows (stride/16 B odd for the b128 reads, stride/8 B odd for the b64 reads -> conflict-free).
+// Block = 4 waves x 32 (or 64) queries of one (batch, head); K / V^T tiles of 64 keys reach LDS by LDS-DMA into
+// XOR-swizzled 128-byte rows (conflict-free b128 / b64 fragment reads), two stages.
+// Measured on MI355X (scripts/probes/mfma_valu.hip): MFMA and VALU time of the waves of one SIMD ADD UP rather than
+// overlap, so per 32 x 64 score tile the kernel pays 14 MFMAs (~450 cycles) plus the softmax VALU work (32 exp2 at
+// quarter rate ~510 cycles, ~75 more full-rate instructions); the staging is kept off the VALU entirely.
 #include <hip/hip_fp16.h>
 
 #include "common.h"
@@ -32,7 +35,6 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int BKV = 64;            // keys per tile
-constexpr int VT_STRIDE = BKV + 4; // halves (136 B rows)
 
 struct AttnArgs {
   const _Float16* q;
@@ -44,206 +46,240 @@ struct AttnArgs {
   float scale_log2;   // scale * log2(e)
 };
 
-template <int KS, int DVT>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
-  constexpr int DQK = KS * 16;
-  constexpr int K_STRIDE = DQK + 8;     // halves
-  constexpr int DV = DVT * 32;
-  // double-buffered tiles: one barrier per key tile (stage t+1 is written while stage t is still being read)
-  __shared__ __attribute__((aligned(16))) _Float16 Kbuf[2][BKV * K_STRIDE];
-  __shared__ __attribute__((aligned(16))) _Float16 Vbuf[2][DV * VT_STRIDE];
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// 16-byte chunk slot of K-chunk `chunk` in a 128-byte LDS row (same XOR swizzle as the GEMM's BK = 64 tiles): the rows
+// read by one ds_read lane group land on distinct bank slots for both the b128 K reads and the b64 V^T reads
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// QT = 32-query tiles per wave (QT = 2: each K / V^T fragment read feeds two MFMAs).
+// ONES >= 0: V^T has spare padded rows (d < DVT*32); row ONES (= d) of both LDS stages is written once with ones, so the
+// softmax denominator falls out of the same MFMAs as the numerator (sum of the SAME fp16-rounded weights) and the
+// per-tile VALU row sums disappear.  ONES < 0: the denominator is summed on the VALU.
+//
+// Staging: K / V^T tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`), two stages, tile t+1 in flight
+// while tile t is multiplied.  Per lane the source offset is fixed up to a per-tile increment, zero padding (head dim
+// beyond d, keys beyond lk, V^T rows beyond d) comes from the buffer range check, and the VALU -- the unit that limits
+// this kernel (exp2, max, convert) -- spends nothing on the copy.
+//   K  stage: KP panels of [64 keys][64 halves] (panel p = head dims 64p .. 64p+63), rows of 128 B, swizzled
+//   V^T stage: [DV rows][64 keys], rows of 128 B, swizzled
+template <int KS, int DVT, int QT, int ONES>
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
+  constexpr int KP = (KS * 16 + 63) / 64;
+  constexpr int DV = DVT * 32;
+  constexpr int K_STAGE = KP * BKV * 64, V_STAGE = DV * 64;           // halves
+  __shared__ __attribute__((aligned(1024))) _Float16 Kbuf[2][K_STAGE];
+  __shared__ __attribute__((aligned(1024))) _Float16 Vbuf[2][V_STAGE];
+  constexpr int K_DMA = KP * 8 / 4, V_DMA = DV / 8 / 4;                // DMA instructions per wave per tile
+  static_assert(DV % 32 == 0, "V^T rows come in groups of 32");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QT) + wave * (32 * QT);
   const int ql = lane & 31, hh = lane >> 5;
   const int d = a.d;
 
-  // every K slot [64][DQK] and V^T slot [DV][64] is rewritten by each tile's staging pass (zeros beyond d / lk),
-  // so pad columns and pad rows always hold finite values
-
   // Q fragments (B operand): lane (query ql, half hh) holds dd = ks*16 + hh*8 .. +7
-  half8 qf[KS];
-  {
-    const int qi = q0 + ql;
+  half8 qf[QT][KS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qi = q0 + qt * 32 + ql;
     const _Float16* qp = a.q + ((long long)b * a.lq + (qi < a.lq ? qi : 0)) * a.ldq + h * d;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int dd = ks * 16 + hh * 8;
       if (qi < a.lq && dd < d) {
-        qf[ks] = *reinterpret_cast<const half8*>(qp + dd);
+        qf[qt][ks] = *reinterpret_cast<const half8*>(qp + dd);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (_Float16)0.0f;
+        for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (_Float16)0.0f;
       }
     }
   }
 
-  float16v o[DVT];
+  float16v o[QT][DVT];
 #pragma unroll
-  for (int t = 0; t < DVT; ++t)
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
-  float m_run = -__builtin_inff(), l_run = 0.0f;
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qt][t][r] = 0.0f;
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -__builtin_inff(); l_run[qt] = 0.0f; }
 
+  // ---- DMA descriptors.  K: rows = keys of this (batch, head) slice, valid bytes end with key lk-1; V^T: rows = head
+  // dims, valid bytes end with row d-1.  Anything beyond fails the range check and lands in LDS as zeros.
   const _Float16* kbase = a.k + (long long)b * a.lk * a.ldk + h * d;
   const _Float16* vbase = a.vt + ((long long)b * a.heads + h) * d * (long long)a.ldv;
-  const int kchunks = d / 8;            // 16-byte chunks per K row
-  __syncthreads();
-
-  // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t is multiplied
-  constexpr int KCH = DQK / 8;                       // 16-byte chunk slots per K row (>= d/8)
-  constexpr int K_ITEMS = (BKV * KCH + 255) / 256;
-  constexpr int V_ITEMS = DV * (BKV / 8) / 256;      // = DVT
-  uint4 rk[K_ITEMS];
-  half8 rv[V_ITEMS];
-  auto load_regs = [&](int key0) {
-#pragma unroll
-    for (int i = 0; i < K_ITEMS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it / KCH, ch = it - row * KCH;
-      const int key = key0 + row;
-      rk[i] = (row < BKV && ch < kchunks && key < a.lk)
-                  ? *reinterpret_cast<const uint4*>(kbase + (long long)key * a.ldk + ch * 8)
-                  : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < V_ITEMS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it >> 3, ch = it & 7;
-      const int key = key0 + ch * 8;
-      half8 v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
-      if (row < d) {
-        if (key + 8 <= a.lk) {
-          v = *reinterpret_cast<const half8*>(vbase + (long long)row * a.ldv + key);
-        } else if (key < a.lk) {
-          const _Float16* p = vbase + (long long)row * a.ldv + key;
-          for (int j = 0; j < a.lk - key; ++j) v[j] = p[j];
-        }
-      }
-      rv[i] = v;
-    }
+  auto make_rsrc = [](const void* p, unsigned bytes) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
   };
-  auto store_regs = [&](int buf) {
-    _Float16* Ks = Kbuf[buf];
-    _Float16* Vs = Vbuf[buf];
+  const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kbase, (unsigned)(((long long)(a.lk - 1) * a.ldk + d) * 2));
+  const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vbase, (unsigned)((long long)d * a.ldv * 2));
+  constexpr unsigned OOB = 0x80000000u;
+  const int l_row = lane >> 3, l_slot = lane & 7;
+  unsigned k_off[K_DMA], v_off[V_DMA];
 #pragma unroll
-    for (int i = 0; i < K_ITEMS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it / KCH, ch = it - row * KCH;
-      if (row < BKV) *reinterpret_cast<uint4*>(&Ks[row * K_STRIDE + ch * 8]) = rk[i];
+  for (int j = 0; j < K_DMA; ++j) {
+    const int idx = wave * K_DMA + j;                 // instruction index inside the stage: panel = idx / 8
+    const int panel = idx >> 3, row = (idx & 7) * 8 + l_row;
+    const int chunk = panel * 8 + swz64(row, l_slot); // 8-half chunk of the head dimension
+    k_off[j] = chunk * 8 < d ? (unsigned)(row * a.ldk * 2 + chunk * 16) : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < V_DMA; ++j) {
+    const int row = (wave * V_DMA + j) * 8 + l_row;
+    v_off[j] = (unsigned)(row * a.ldv * 2 + swz64(row, l_slot) * 16);
+  }
+  const unsigned k_step = (unsigned)(BKV * a.ldk * 2), v_step = BKV * 2;   // bytes per key tile
+  auto issue_tile = [&](int buf, int tile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16* kd = Kbuf[buf] + wave * (K_DMA * 512);
+    _Float16* vd = Vbuf[buf] + wave * (V_DMA * 512);
+#pragma unroll
+    for (int j = 0; j < K_DMA; ++j) {
+      const unsigned off = k_off[j] == OOB ? OOB : k_off[j] + tile * k_step;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(kd + j * 512), 16, off, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < V_ITEMS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it >> 3, ch = it & 7;
-      // 8 halves = two 8-byte LDS writes (rows are 8-byte aligned, not 16)
-      half4 lo = {rv[i][0], rv[i][1], rv[i][2], rv[i][3]}, hi = {rv[i][4], rv[i][5], rv[i][6], rv[i][7]};
-      *reinterpret_cast<half4*>(&Vs[row * VT_STRIDE + ch * 8]) = lo;
-      *reinterpret_cast<half4*>(&Vs[row * VT_STRIDE + ch * 8 + 4]) = hi;
+    for (int j = 0; j < V_DMA; ++j) {
+      const int row = (wave * V_DMA + j) * 8 + l_row;
+      if (ONES < 0 || row != ONES)       // the ones row is written once below and never overwritten
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(vd + j * 512), 16, v_off[j] + tile * v_step, 0, 0, 0);
     }
+#endif
   };
+  if (ONES >= 0 && tid < 16) {           // 2 stages x 8 chunks of the ones row
+    half8 one;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one[j] = (_Float16)1.0f;
+    *reinterpret_cast<half8*>(&Vbuf[tid >> 3][(ONES >= 0 ? ONES : 0) * 64 + (tid & 7) * 8]) = one;
+  }
 
-  load_regs(0);
-  int stage = 0;
-  for (int key0 = 0; key0 < a.lk; key0 += BKV, stage ^= 1) {
-    store_regs(stage);
-    __syncthreads();            // stage `stage` is complete; every wave finished reading stage^1 one iteration ago
-    if (key0 + BKV < a.lk) load_regs(key0 + BKV);
+  const int ntiles = (a.lk + BKV - 1) / BKV;
+  issue_tile(0, 0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int stage = tile & 1, key0 = tile * BKV;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile `tile` has landed
+    __builtin_amdgcn_s_barrier();                        // ... and everyone's; all waves are done reading stage^1
+    if (tile + 1 < ntiles) issue_tile(stage ^ 1, tile + 1);
     const _Float16* Ks = Kbuf[stage];
     const _Float16* Vs = Vbuf[stage];
 
-    // ---- S^T = K Q^T  (two 32-key tiles)
-    float16v s[2];
+    // ---- S^T = K Q^T  (two 32-key tiles x QT query tiles; each K fragment is read once)
+    float16v s[QT][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.0f;
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[qt][t][r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        half8 kf = *reinterpret_cast<const half8*>(&Ks[(t * 32 + ql) * K_STRIDE + ks * 16 + hh * 8]);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[t], 0, 0, 0);
+        const int row = t * 32 + ql;
+        const half8 kf = *reinterpret_cast<const half8*>(&Ks[(ks >> 2) * (BKV * 64) + row * 64 + swz64(row, 2 * (ks & 3) + hh) * 8]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qt][ks], s[qt][t], 0, 0, 0);
       }
-    }
     // ---- online softmax (per-lane scalars; the partner lane holds the other 32 keys of this query).
     // Scores stay RAW in the accumulators; scale*log2(e) rides in the FMA that forms the exp2 argument.  The
     // running max is only raised when it would grow by more than RESCALE_THR (log2 units): P may then reach
     // 2^THR (fine in fp16/fp32) and the O / l rescale becomes a rare, wave-uniformly skipped branch.
-    if (key0 + BKV > a.lk) {   // wave-uniform: only the last tile can be ragged
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    half8 pf[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (key0 + BKV > a.lk) {   // wave-uniform: only the last tile can be ragged
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            s[qt][t][r] = key < a.lk ? s[qt][t][r] : -__builtin_inff();
+          }
+      }
+      float mx = fmaxf(s[qt][0][0], s[qt][1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[qt][0][r]), s[qt][1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;   // scale > 0: max commutes with the scaling
+      constexpr float RESCALE_THR = 6.0f;
+      const bool need = mx > m_run[qt] + RESCALE_THR;      // first tile: m_run = -inf -> true
+      if (__any(need)) {
+        const float m_new = need ? mx : m_run[qt];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);   // 1 when unchanged, 0 on the first tile
+        m_run[qt] = m_new;
+        l_run[qt] *= alpha;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qt][t][r] *= alpha;
+      }
+      const f32x2 c2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_run[qt], -m_run[qt]};
+      f32x2 ps2 = {0.0f, 0.0f};
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          s[t][r] = key < a.lk ? s[t][r] : -__builtin_inff();
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv = {s[qt][t][r], s[qt][t][r + 1]};
+          const f32x2 e = __builtin_elementwise_fma(sv, c2, nm2);
+          const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+          if constexpr (ONES < 0) ps2 += p;
+          pf[qt][t * 2 + (r >> 3)][r & 7] = (_Float16)p.x;
+          pf[qt][t * 2 + (r >> 3)][(r & 7) + 1] = (_Float16)p.y;
         }
+      if constexpr (ONES < 0) l_run[qt] += ps2.x + ps2.y;
     }
-    float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;   // scale > 0: max commutes with the scaling
-    constexpr float RESCALE_THR = 6.0f;
-    const bool need = mx > m_run + RESCALE_THR;          // first tile: m_run = -inf -> true
-    if (__any(need)) {
-      const float m_new = need ? mx : m_run;
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 1 when unchanged, 0 on the first tile
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int t = 0; t < DVT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-    }
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 c2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_run, -m_run};
-    f32x2 ps2 = {0.0f, 0.0f};
-    half8 pf[4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 sv = {s[t][r], s[t][r + 1]};
-        const f32x2 e = __builtin_elementwise_fma(sv, c2, nm2);
-        const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
-        ps2 += p;
-        pf[t * 2 + (r >> 3)][r & 7] = (_Float16)p.x;
-        pf[t * 2 + (r >> 3)][(r & 7) + 1] = (_Float16)p.y;
-      }
-    l_run += ps2.x + ps2.y;
-    // ---- O^T += V^T P^T, 16 keys per MFMA, keys in accumulator-register order
+    // ---- O^T += V^T P^T, 16 keys per MFMA, keys in accumulator-register order {0-3, 8-11} + 4*hh of each 16-key
+    // step: two 8-byte reads from the chunks 2*st and 2*st+1 of the row; each V^T fragment feeds QT MFMAs
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      const int base = (st >> 1) * 32 + (st & 1) * 16 + 4 * hh;
 #pragma unroll
       for (int t = 0; t < DVT; ++t) {
-        const _Float16* vp = &Vs[(t * 32 + ql) * VT_STRIDE + base];
-        half4 lo = *reinterpret_cast<const half4*>(vp);
-        half4 hi = *reinterpret_cast<const half4*>(vp + 8);
-        half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[st], o[t], 0, 0, 0);
+        const int row = t * 32 + ql;
+        const _Float16* vr = &Vs[row * 64 + 4 * hh];
+        const half4 lo = *reinterpret_cast<const half4*>(vr + swz64(row, 2 * st) * 8);
+        const half4 hi = *reinterpret_cast<const half4*>(vr + swz64(row, 2 * st + 1) * 8);
+        const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qt][st], o[qt][t], 0, 0, 0);
       }
     }
   }
 
   // ---- normalise and store: lane (query, half) owns dd = t*32 + 8*(r>>2) + 4*hh + (r&3)
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  const int qi = q0 + ql;
-  if (qi < a.lq) {
-    _Float16* op = a.out + ((long long)b * a.lq + qi) * a.ldo + h * d;
 #pragma unroll
-    for (int t = 0; t < DVT; ++t)
+  for (int qt = 0; qt < QT; ++qt) {
+    float l_tot;
+    if constexpr (ONES >= 0) {
+      // row ONES of O^T is the denominator: it sits in register (ONES%32 / 8)*4 of the hh = 0 lane of each query
+      static_assert(ONES % 8 == 0, "the ones row must start an 8-row group");
+      l_tot = __shfl(o[qt][ONES / 32][((ONES % 32) / 8) * 4], ql);
+    } else {
+      l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32);
+    }
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + qt * 32 + ql;
+    if (qi < a.lq) {
+      _Float16* op = a.out + ((long long)b * a.lq + qi) * a.ldo + h * d;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dd = t * 32 + 8 * g + 4 * hh;
-        if (dd < d) {
-          half4 v = {(_Float16)(o[t][g * 4 + 0] * inv), (_Float16)(o[t][g * 4 + 1] * inv),
-                     (_Float16)(o[t][g * 4 + 2] * inv), (_Float16)(o[t][g * 4 + 3] * inv)};
-          *reinterpret_cast<half4*>(op + dd) = v;
+      for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = t * 32 + 8 * g + 4 * hh;
+          if (dd < d) {
+            half4 v = {(_Float16)(o[qt][t][g * 4 + 0] * inv), (_Float16)(o[qt][t][g * 4 + 1] * inv),
+                       (_Float16)(o[qt][t][g * 4 + 2] * inv), (_Float16)(o[qt][t][g * 4 + 3] * inv)};
+            *reinterpret_cast<half4*>(op + dd) = v;
+          }
         }
-      }
+    }
   }
 }
 
@@ -256,19 +292,21 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   if (!q || !k || !vt || !out) return fail(COMA_E_INVALID, "sd_attention_f16: null pointer");
   if (batch <= 0 || heads <= 0 || lq <= 0 || lk <= 0) return fail(COMA_E_INVALID, "sd_attention_f16: bad sizes");
   if (d % 8 || d <= 0 || d > 160) return fail(COMA_E_INVALID, "sd_attention_f16: head dim %d unsupported (multiple of 8, <= 160)", d);
-  if (ldq < heads * d || ldk < heads * d || ldo < heads * d || ldv < lk || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
+  if (ldq < heads * d || ldk < heads * d || ldo < heads * d || ldv < ((lk + 7) & ~7) || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
     return fail(COMA_E_INVALID, "sd_attention_f16: bad leading dimensions");
   AttnArgs a;
   a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.vt = (const _Float16*)vt; a.out = (_Float16*)out;
   a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.scale_log2 = scale * 1.4426950408889634f;
-  dim3 grid((unsigned)((lq + 127) / 128), (unsigned)heads, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
-  if (d <= 48) hipLaunchKernelGGL((attention_kernel<3, 2>), grid, dim3(256), 0, s, a);
-  else if (d <= 64) hipLaunchKernelGGL((attention_kernel<4, 2>), grid, dim3(256), 0, s, a);
-  else if (d <= 80) hipLaunchKernelGGL((attention_kernel<5, 3>), grid, dim3(256), 0, s, a);
-  else if (d <= 96) hipLaunchKernelGGL((attention_kernel<6, 3>), grid, dim3(256), 0, s, a);
-  else if (d <= 128) hipLaunchKernelGGL((attention_kernel<8, 4>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((attention_kernel<10, 5>), grid, dim3(256), 0, s, a);
+  const bool two = lq >= 1024;                 // 64 queries per wave once there are enough blocks to fill the chip
+  dim3 grid((unsigned)((lq + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)heads, (unsigned)batch);
+  if (d == 40 && two) hipLaunchKernelGGL((attention_kernel<3, 2, 2, 40>), grid, dim3(256), 0, s, a);
+  else if (d == 40) hipLaunchKernelGGL((attention_kernel<3, 2, 1, 40>), grid, dim3(256), 0, s, a);
+  else if (d <= 48) hipLaunchKernelGGL((attention_kernel<3, 2, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
+  else if (d <= 64) hipLaunchKernelGGL((attention_kernel<4, 2, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
+  else if (d <= 96) hipLaunchKernelGGL((attention_kernel<6, 3, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
+  else if (d <= 128) hipLaunchKernelGGL((attention_kernel<8, 4, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attention_kernel<10, 5, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
   return check_launch("attention_kernel");
 }

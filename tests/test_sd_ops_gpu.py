@@ -139,7 +139,7 @@ def test_layernorm(ops, c):
 
 
 @pytest.mark.parametrize("heads,d,lq,lk", [(8, 40, 200, 200), (8, 40, 256, 77), (8, 80, 130, 130), (8, 160, 64, 64),
-                                           (2, 64, 33, 500), (8, 160, 70, 77)])
+                                           (2, 64, 33, 500), (8, 160, 70, 77), (2, 40, 1100, 333), (2, 40, 1024, 77), (2, 80, 300, 264)])
 def test_attention(ops, heads, d, lq, lk):
     B, C = 2, heads * d
     q, k, v = rnd(B, lq, C, seed=1), rnd(B, lk, C, seed=2), rnd(B, lk, C, seed=3)
