@@ -575,7 +575,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const bool k64 = d->c0 % 64 == 0 && d->c1 % 64 == 0;
   const bool deep = g.K >= 2048 && k64;
   // 256 x 320 tile: N a multiple of 320 (every layer of the SD UNet), enough rows to fill the chip with 1 block / CU
-  const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
+  const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && g.M >= 256 * 128 && !(d->epi & ((1 << 20) | (1 << 21)));
   // GEGLU (needs an even number of MFMA column tiles per wave): 256 x 256, 8 waves, wave tile 64 x 128
   const bool big_geglu = geglu && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 16 && !(d->epi & (1 << 20));
   // VAE widths (128 / 256 / 512 channels at up to 512 x 512 pixels): 256 x 256 and 256 x 128 tiles, 8 waves
@@ -589,7 +589,8 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const int bn = (big || mid) ? 320 : ((big_geglu || big256) ? 256 : ((wide || big128) ? 128 : 64));
   const int bk = mid ? 32 : ((big || big_geglu || big256 || big128 || deep) ? 64 : 32);
   const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((d->n + bn - 1) / bn);
-  // split-K when the tile grid cannot fill the chip: aim at >= 2 blocks per CU, keep >= 256 of K per split
+  // split-K when the tile grid cannot fill the chip: as many splits as keep every block resident at once (2 per CU,
+  // 512 in total -- a partial second round costs more than it buys), at least 384 of K per split
   g.ksplit = 1;
   g.partial = (float*)d->workspace;
   g.colstats = (float*)d->colstats;
@@ -597,13 +598,15 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: colstats needs M %% 64 == 0, N %% 8 == 0, no GEGLU / batching");
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
-  const int min_tiles = 256 / bk;
+  const int min_tiles = 384 / bk;
   if (!g.colstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
-    int s = (int)((512 + blocks - 1) / blocks);
+    int s = (int)(512 / blocks);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;
     while (s > 1 && (size_t)s * g.M * g.N * sizeof(float) > d->workspace_bytes) --s;
     if (s > 1) g.ksplit = s;
+    const int force = (d->epi >> 24) & 15;      // tuning knob: forced split factor
+    if (force && (size_t)force * g.M * g.N * sizeof(float) <= d->workspace_bytes) g.ksplit = force > nk ? nk : force;
   }
   const long long lin_blocks = gx >= 16 ? 8LL * ((gx + 7) / 8) * gy : (long long)gx * gy;   // XCD-banded order (see kernel)
   if (lin_blocks > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: grid too large");
@@ -615,6 +618,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   else if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
   else if (big_geglu || big256) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
   else if (big128) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 2, 64, 2>), grid, dim3(512), 0, st, g);
+  else if (mid && (d->epi & (1 << 23))) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 2>), grid, dim3(256), 0, st, g);
   else if (mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 3>), grid, dim3(256), 0, st, g);
   else if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2>), grid, dim3(256), 0, st, g);
   else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 32, 4>), grid, dim3(256), 0, st, g);

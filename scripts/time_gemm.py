@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coma_amd.sd import ops
 dev = "cuda:0"
+WS = torch.empty(96 << 20, dtype=torch.float32, device=dev)
 
 
 def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
@@ -20,6 +21,7 @@ def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
     b = torch.randn(N, device=dev).half()
     r = torch.randn(M, N, device=dev).half() if res else None
     out = torch.empty(M, N if not (epi & 1) else N // 2, device=dev, dtype=torch.float16)
+    kw["workspace"] = WS
     for _ in range(3):
         ops.conv_gemm(x, w, out, bias=b, res=r, epi=epi, **kw)
     torch.cuda.synchronize()
@@ -32,13 +34,16 @@ def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
     return ms, 2 * M * N * K / ms / 1e9
 
 
+if os.environ.get("SMALL"):
+    SHAPES_OVERRIDE = [(1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64), (4096, 1280, 1280, 1, None), (4096, 1280, 11520, 9, 256),
+                       (4096, 640, 5760, 9, 256), (1024, 1280, 1280, 1, None)]
 SHAPES = [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 1280, 1, None), (65536, 640, 5760, 9, 4096),
           (16384, 640, 640, 1, None), (16384, 640, 5760, 9, 1024), (16384, 1280, 11520, 9, 1024),
           (4096, 1280, 1280, 1, None), (4096, 1280, 5120, 1, None), (4096, 1280, 11520, 9, 256), (4096, 1280, 23040, 9, 256),
           (1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64)]
 GEGLU = [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)]
 knobs = [0] + [sum(1 << int(b) for b in a.split("+")) for a in sys.argv[1:]]
-for (M, N, K, taps, hw) in SHAPES:
+for (M, N, K, taps, hw) in (SHAPES_OVERRIDE if os.environ.get('SMALL') else SHAPES):
     row = []
     for epi in knobs:
         ms, tf = bench(M, N, K, taps=taps, epi=epi, hw=hw, res=True)
