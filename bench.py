@@ -135,10 +135,13 @@ def bench_inpaint(args, dev, world, rank):
                                    "(BASELINE.json config 2); random-init weights of the SD-1.5-inpainting architecture",
                        "parallelism": f"independent image batches on {world} GPU(s), no collective"},
             "tflop_per_image": flops_img / 1e12, "achieved_tflops_whole_loop": value / world * flops_img / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "sd::conv_gemm_kernel<128> (all conv3x3/1x1/linear launches of one UNet forward)",
+            "roofline": {"bound": "mfma", "kernel": "sd::conv_gemm_kernel<WM,WN,TN,BK,STAGES> (all conv3x3/1x1/linear launches of one UNet forward)",
                          "achieved": g_fl / g_ms / 1e9, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, "launches": len(gemm),
-                         "avg_launch_ms": g_ms / len(gemm), "flops_per_forward": g_fl, "traffic": None,
+                         "avg_launch_ms": g_ms / len(gemm), "flops_per_forward": g_fl, "traffic": UNET_GEMM_PMC_TRAFFIC_BYTES if B == 8 else None,
+                         "traffic_source": "profiles/r01_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
+                                           "the launches of eager UNet forwards at batch 16 (fabric-side requests of the 8 L2s: "
+                                           "weights are pulled once per XCD and mostly hit the Infinity Cache)",
                          "unet_forward_ms_eager_sum": tot_ms,
                          "attention": {"achieved": sum(f for f, _ in attn) / sum(m for _, m in attn) / 1e9, "unit": "TFLOP/s"}},
         }
@@ -283,6 +286,7 @@ def bench_occupancy(args, dev, world, rank):
 
 # HBM bytes per contact_accumulate_kernel launch from the committed rocprofv3 PMC pass (profiles/r01_contact_pmc.txt):
 # FETCH_SIZE 1.91553e6 KiB (x2: gfx950 reports half of a coalesced stream) + WRITE_SIZE 3.71135e6 KiB
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(185.78e6)
 CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91553e6 + 3.71135e6) * 1024)
 
 
