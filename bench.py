@@ -330,7 +330,7 @@ def main():
         out = dict(primary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_inpaint() if args.workload == "inpaint" else cpu_baseline()
-        if not args.no_secondary:
+        if not args.no_secondary and world == 1:      # single-GPU extras (rank 0 alone must never enter a collective)
             try:
                 out["occupancy"] = bench_occupancy(args, dev, world, rank)
             except Exception as e:   # noqa: BLE001  (never lose the primary line)

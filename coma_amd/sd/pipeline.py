@@ -141,11 +141,14 @@ class SyntheticHumanMaskPredictor:
     """Deterministic stand-in for PointRend (weights cannot be provisioned offline): thresholds the luminance of the
     decoded x0 image inside an ellipse.  Same plugin contract as PointRendPredictor.__call__ (:1225-1236)."""
     use_visualizer = False
+    _ellipses = {}
 
     def __call__(self, image_u8):
         H, W = image_u8.shape[:2]
-        yy, xx = np.mgrid[0:H, 0:W]
-        ell = ((yy - H / 2) / (H * 0.3)) ** 2 + ((xx - W / 2) / (W * 0.18)) ** 2 <= 1.0
+        ell = self._ellipses.get((H, W))
+        if ell is None:
+            yy, xx = np.mgrid[0:H, 0:W]
+            ell = self._ellipses[(H, W)] = ((yy - H / 2) / (H * 0.3)) ** 2 + ((xx - W / 2) / (W * 0.18)) ** 2 <= 1.0
         lum = image_u8.astype(np.float32).mean(-1)
         return {"mask": (ell & (lum > lum.mean() - 40)).astype(np.uint8), "vis": None, "asset_mask": None}
 
