@@ -314,12 +314,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # COMA_BENCH_SHARED_DEVICE=1: control-flow test of the N>1 path on a 1-GPU box (all ranks on cuda:0, gloo instead of
+    # RCCL, which refuses two ranks on one device); never set by the driver
+    shared = os.environ.get("COMA_BENCH_SHARED_DEVICE") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.workload == "contact":
         args.contact_steps = args.steps

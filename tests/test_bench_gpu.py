@@ -1,0 +1,41 @@
+"""GPU: bench.py's contract -- one JSON line with the required keys at N=1, and the N>1 control flow (barriers, MAX over
+ranks, the ComA all-reduce, rank-0-only printing) exercised with two ranks sharing cuda:0 over gloo
+(COMA_BENCH_SHARED_DEVICE=1: RCCL refuses two ranks on one device; the driver's multi-GPU run uses RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline"}
+SMALL = ["--steps", "1", "--warmup", "0", "--ddim-steps", "3", "--contact-steps", "1", "--samples", "4", "--human-res", "512",
+         "--no-cpu-baseline"]
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{\"metric\"")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(hip_lib):
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + SMALL, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert KEYS <= set(line) and line["n_gpus"] == 1 and line["value"] > 0
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
+    assert "workload" in line["config"] and line["secondary"]["value"] > 0
+
+
+def test_two_ranks_control_flow(hip_lib):
+    env = dict(os.environ, COMA_BENCH_SHARED_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", "bench.py", "--gpus", "2"] + SMALL
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["secondary"]["n_gpus"] == 2
