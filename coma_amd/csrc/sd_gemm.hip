@@ -581,13 +581,16 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   // VAE widths (128 / 256 / 512 channels at up to 512 x 512 pixels): 256 x 256 and 256 x 128 tiles, 8 waves
   const bool big256 = !geglu && !big && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
   const bool big128 = !geglu && !big && !big256 && nz == 1 && k64 && d->n % 128 == 0 && g.M >= 256 * 256 && !(d->epi & (1 << 20));
+  // 512 x 128, 8 waves (wave tile 64 x 128), BK = 32, 3 stages: the 128-channel 3x3 convs of the VAE at 512 x 512
+  // (K = 1152: +17 % over 256 x 128; slower than it at K = 2304)
+  const bool tall128 = big128 && g.K <= 1152 && !(d->epi & (1 << 20));
   // 128 x 320, 4 waves (wave tile 64 x 160): mid-size M where 256-row tiles would leave CUs idle
   const bool mid = !big && !big256 && !big128 && !geglu && nz == 1 && d->n % 320 == 0 && g.M >= 128 * 64 &&
                    (d->n <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20));
   const bool wide = d->n % 128 == 0 || d->n > 256;
-  const int bm = (big || big_geglu || big256 || big128) ? 256 : 128;
+  const int bm = tall128 ? 512 : ((big || big_geglu || big256 || big128) ? 256 : 128);
   const int bn = (big || mid) ? 320 : ((big_geglu || big256) ? 256 : ((wide || big128) ? 128 : 64));
-  const int bk = mid ? 32 : ((big || big_geglu || big256 || big128 || deep) ? 64 : 32);
+  const int bk = (mid || tall128) ? 32 : ((big || big_geglu || big256 || big128 || deep) ? 64 : 32);
   const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((d->n + bn - 1) / bn);
   // split-K when the tile grid cannot fill the chip: as many splits as keep every block resident at once (2 per CU,
   // 512 in total -- a partial second round costs more than it buys), at least 384 of K per split
@@ -617,6 +620,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2, true>), grid, dim3(256), 0, st, g);
   else if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
   else if (big_geglu || big256) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
+  else if (tall128) hipLaunchKernelGGL((conv_gemm_kernel<8, 1, 4, 32, 3>), grid, dim3(512), 0, st, g);
   else if (big128) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 2, 64, 2>), grid, dim3(512), 0, st, g);
   else if (mid && (d->epi & (1 << 23))) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 2>), grid, dim3(256), 0, st, g);
   else if (mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 3>), grid, dim3(256), 0, st, g);

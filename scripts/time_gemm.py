@@ -19,7 +19,7 @@ def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
         kw = dict(batch=M, in_h=1, in_w=1, c0=K, n=N)
     w = torch.randn(N, K, device=dev).half() * K ** -0.5
     b = torch.randn(N, device=dev).half()
-    r = torch.randn(M, N, device=dev).half() if res else None
+    r = torch.randn(M, N, device=dev).half() if (res and M < 1000000) else None
     out = torch.empty(M, N if not (epi & 1) else N // 2, device=dev, dtype=torch.float16)
     kw["workspace"] = WS
     for _ in range(3):
@@ -37,13 +37,16 @@ def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
 if os.environ.get("SMALL"):
     SHAPES_OVERRIDE = [(1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64), (4096, 1280, 1280, 1, None), (4096, 1280, 11520, 9, 256),
                        (4096, 640, 5760, 9, 256), (1024, 1280, 1280, 1, None)]
+if os.environ.get("VAE"):
+    SHAPES_OVERRIDE = [(2097152, 128, 1152, 9, 262144), (2097152, 128, 2304, 9, 262144), (524288, 256, 2304, 9, 65536),
+                       (131072, 512, 4608, 9, 16384), (2097152, 64, 1152, 9, 262144)]
 SHAPES = [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 1280, 1, None), (65536, 640, 5760, 9, 4096),
           (16384, 640, 640, 1, None), (16384, 640, 5760, 9, 1024), (16384, 1280, 11520, 9, 1024),
           (4096, 1280, 1280, 1, None), (4096, 1280, 5120, 1, None), (4096, 1280, 11520, 9, 256), (4096, 1280, 23040, 9, 256),
           (1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64)]
 GEGLU = [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)]
 knobs = [0] + [sum(1 << int(b) for b in a.split("+")) for a in sys.argv[1:]]
-for (M, N, K, taps, hw) in (SHAPES_OVERRIDE if os.environ.get('SMALL') else SHAPES):
+for (M, N, K, taps, hw) in (SHAPES_OVERRIDE if (os.environ.get('SMALL') or os.environ.get('VAE')) else SHAPES):
     row = []
     for epi in knobs:
         ms, tf = bench(M, N, K, taps=taps, epi=epi, hw=hw, res=True)
