@@ -29,6 +29,8 @@ SIGNATURES = {
     "coma_significant_pairs_u8": (_i, [_vp, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "coma_masked_max_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "coma_entropy_f32": (_i, [_vp, _i64, _i, _f, _f, _vp, _vp]),
+    "coma_row_argmax_i64": (_i, [_vp, _i64, _i, _i64, _i64, _vp, _vp, _vp]),
+    "coma_contact_select_u8": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "coma_occupancy_splat": (_i, [_vp, _i, _i, _i, _vp, _d, _d, _vp, _vp]),
     "coma_occupancy_reduce": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "coma_nearest_vertex_i64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

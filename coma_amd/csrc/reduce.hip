@@ -4,6 +4,8 @@
 //
 // replaces: utils/coma.py:328-330 (normalize), :342-356 (contact map), :376-377 (significant pairs),
 //           :402-427 (masked max), :455-475 (entropy score).
+#include <cstdint>
+
 #include "common.h"
 
 namespace coma {
@@ -127,6 +129,60 @@ __global__ void masked_max_kernel(const float* __restrict__ C, const uint8_t* __
   }
 }
 
+// ---- consumer of the accumulator state (src/application/optimize.py:190-196)
+// NumPy ordering: argmax returns the FIRST maximum and treats NaN as the maximum (first NaN wins); max propagates NaN.
+__device__ __forceinline__ bool np_better(float v, int64_t i, float bv, int64_t bi) {
+  const bool vn = v != v, bn = bv != bv;
+  if (vn != bn) return vn;                 // a NaN beats any number
+  if (vn) return i < bi;                   // both NaN: first one
+  return v > bv || (v == bv && i < bi);
+}
+
+// idx[m] = argmax_k x[m*row_stride + col_offset + k], k < n; optional val[m] = np.max of the same row
+__global__ __launch_bounds__(kRowWaves* kWave) void row_argmax_kernel(const float* __restrict__ x, int64_t M, int n,
+                                                                       int64_t row_stride, int64_t col_offset,
+                                                                       int64_t* __restrict__ idx, float* __restrict__ val) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t m = (int64_t)blockIdx.x * kRowWaves + threadIdx.x / kWave;
+  if (m >= M) return;
+  const float* row = x + m * row_stride + col_offset;
+  float bv = -__builtin_inff();
+  int64_t bi = INT64_MAX;
+  for (int k = lane; k < n; k += kWave) {
+    const float v = row[k];
+    if (np_better(v, k, bv, bi)) { bv = v; bi = k; }
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    const float ov = __shfl_xor(bv, msk);
+    const int64_t oi = __shfl_xor(bi, msk);
+    if (np_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) {
+    if (idx) idx[m] = bi;
+    if (val) val[m] = bv;
+  }
+}
+
+// sel[h] = (max_o nom[h,o] / den[h,o]) > thr   (NaN anywhere in the row -> max is NaN -> false, as np.max / `>` give)
+__global__ __launch_bounds__(kRowWaves* kWave) void contact_select_kernel(const float* __restrict__ nom, const float* __restrict__ den,
+                                                                           int H, int O, float thr, uint8_t* __restrict__ sel) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int h = blockIdx.x * kRowWaves + threadIdx.x / kWave;
+  if (h >= H) return;
+  float mx = -__builtin_inff();
+  bool nan = false;
+  for (int o = lane; o < O; o += kWave) {
+    const float v = nom[(int64_t)h * O + o] / den[(int64_t)h * O + o];
+    nan |= v != v;
+    mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk));
+  nan = __any(nan);
+  if (lane == 0) sel[h] = (!nan && mx > thr) ? 1 : 0;
+}
+
 }  // namespace coma
 
 using namespace coma;
@@ -180,4 +236,23 @@ extern "C" int coma_masked_max_f32(const float* contact, const uint8_t* col_any,
   hipLaunchKernelGGL(masked_max_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, contact, col_any,
                      row_any, H, O, which, out);
   return check_launch("masked_max_kernel");
+}
+
+extern "C" int coma_row_argmax_i64(const float* x, int64_t rows, int n, int64_t row_stride, int64_t col_offset, int64_t* idx,
+                                   float* val, void* stream) {
+  if (!x || (!idx && !val)) return fail(COMA_E_INVALID, "coma_row_argmax_i64: null pointer");
+  if (rows <= 0 || n <= 0 || row_stride < n || col_offset < 0) return fail(COMA_E_INVALID, "coma_row_argmax_i64: bad sizes");
+  const int64_t blocks = (rows + kRowWaves - 1) / kRowWaves;
+  hipLaunchKernelGGL(row_argmax_kernel, dim3((unsigned)blocks), dim3(kRowWaves * kWave), 0, (hipStream_t)stream, x, rows, n,
+                     row_stride, col_offset, idx, val);
+  return check_launch("row_argmax_kernel");
+}
+
+extern "C" int coma_contact_select_u8(const float* nom, const float* den, int H, int O, float threshold, uint8_t* selected,
+                                      void* stream) {
+  if (!nom || !den || !selected) return fail(COMA_E_INVALID, "coma_contact_select_u8: null pointer");
+  if (H <= 0 || O <= 0) return fail(COMA_E_INVALID, "coma_contact_select_u8: bad sizes");
+  hipLaunchKernelGGL(contact_select_kernel, dim3((unsigned)((H + kRowWaves - 1) / kRowWaves)), dim3(kRowWaves * kWave), 0,
+                     (hipStream_t)stream, nom, den, H, O, threshold, selected);
+  return check_launch("contact_select_kernel");
 }

@@ -88,6 +88,18 @@ int coma_masked_max_f32(const float* contact, const uint8_t* col_any, const uint
  * prob [M,N] in/out is normalised in place first; score[m] = 1 + sum_k plogp(round(p*n_bin)/n_bin)/ln(n_bin). */
 int coma_entropy_f32(float* prob, int64_t M, int N, float eps, float n_bin, float* score, void* stream);
 
+/* Consumer of the accumulator state: the optimisation app's target selection.
+ * replaces: src/application/optimize.py:190-192 (`np.argmax(prob_grid_canon_human_wrt_obj[:, o_ref, :], axis=1)` -> the
+ *           bin whose direction becomes the per-vertex orientation target) and :195-196 (`np.nonzero(np.max(nom / denom,
+ *           axis=1) > contact_threshold)`, `np.argmax(nom[selected], axis=1)`).
+ * coma_row_argmax_i64: idx[m] = argmax_k x[m*row_stride + col_offset + k] (k < n) with NumPy's rules -- the FIRST
+ *   maximum, NaN counts as the maximum; val (optional) = that element (= np.max of the row).  idx or val may be NULL.
+ * coma_contact_select_u8: selected[h] = (max_o nom[h,o]/den[h,o]) > threshold, NaN-propagating max (false). */
+int coma_row_argmax_i64(const float* x, int64_t rows, int n, int64_t row_stride, int64_t col_offset, int64_t* idx,
+                        float* val, void* stream);
+int coma_contact_select_u8(const float* nom, const float* den, int H, int O, float threshold, uint8_t* selected,
+                           void* stream);
+
 /* K5  occupancy splat.
  * replaces: utils/coma_occupancy.py:287-295 (dense [H,R,R,R] f64 distance test) by an equivalent
  *           sparse test over the voxels whose centres can lie inside the threshold sphere.

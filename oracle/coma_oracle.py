@@ -309,3 +309,15 @@ def vertex_normals(verts: np.ndarray, faces: np.ndarray) -> np.ndarray:
     nrm = np.sqrt((n[:, 0] ** 2 + n[:, 1] ** 2) + n[:, 2] ** 2)
     out = np.where(nrm[:, None] > 0, n / np.where(nrm > 0, nrm, 1.0)[:, None], np.array([0.0, 0.0, 1.0]))
     return out
+
+
+def orientation_and_contact_targets(info, reference_object_vertex_index, contact_threshold):
+    """src/application/optimize.py:190-196, restated line by line (NumPy on the exported dict)."""
+    grid_prob = info["prob_grid_canon_human_wrt_obj"][:, reference_object_vertex_index, :]
+    max_prob_indices = np.argmax(grid_prob, axis=1)
+    relative_orientation_GT = np.array([info["canon_normal_grid"][i].reshape((3,)) for i in max_prob_indices])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = info["contact_dist_expectation_grid_nom"] / info["contact_dist_expectation_grid_denom"]
+    selected_human_indices = np.nonzero(np.max(ratio, axis=1) > contact_threshold)
+    corresponding_object_indices = np.argmax(info["contact_dist_expectation_grid_nom"][selected_human_indices], axis=1)
+    return max_prob_indices, relative_orientation_GT, selected_human_indices, corresponding_object_indices

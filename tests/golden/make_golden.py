@@ -299,6 +299,45 @@ def main():
         table.append(f"{np.dtype(dt).name}->{t.dtype}->{n.dtype}")
     out["g12_dtype_table"] = np.array(table)
 
+    # ---------------- G17 the optimisation app's reading of the state (src/application/optimize.py:190-196) ----------------
+    # those lines sit inside optimize_smpl (which needs smplx / COAP / VPoser); they are executed here verbatim, read from
+    # the reference file at generation time, on states exported by the reference's own ComA
+    import textwrap
+    with open(os.path.join(REF, "src", "application", "optimize.py")) as fh:
+        lines = fh.read().split("\n")[189:196]          # file lines 190-196
+    assert lines[0].lstrip().startswith("grid_prob = affordance_info") and "corresponding_object_indices" in lines[-1], lines
+    consumer_src = textwrap.dedent("\n".join(lines))
+
+    def run_consumer(info, o_ref, thr):
+        ns = dict(np=np, affordance_info=info, reference_object_vertex_index=o_ref, contact_threshold=thr)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            exec(consumer_src, ns)
+        return (ns["max_prob_indices"], ns["relative_orientation_GT"], ns["selected_human_indices"][0],
+                ns["corresponding_object_indices"])
+
+    tricky = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in exp.items()}
+    P = tricky["prob_grid_canon_human_wrt_obj"]
+    P[3, 5, :] = 0.0                                  # all-equal row -> first index
+    P[4, 5, 17] = P[4, 5, 200] = P[4, 5].max() * 2     # tie of two maxima -> the first
+    P[6, 5, 9] = np.nan                                # NaN counts as the maximum
+    tricky["contact_dist_expectation_grid_denom"][7, :] = 0.0     # 0/0 and x/0 in the ratio
+    tricky["contact_dist_expectation_grid_nom"][7, :3] = 0.0
+    tricky["contact_dist_expectation_grid_nom"][8, 2] = tricky["contact_dist_expectation_grid_nom"][8, 6] = 99.0   # tie
+    for k in ["prob_grid_canon_human_wrt_obj", "contact_dist_expectation_grid_nom", "contact_dist_expectation_grid_denom"]:
+        out[f"g17t_{k}"] = tricky[k]
+    ratio = exp["contact_dist_expectation_grid_nom"] / exp["contact_dist_expectation_grid_denom"]
+    thr_mid = float(np.median(ratio.max(1)))
+    out["g17_thresholds"] = np.array([0.0, thr_mid, 10.0])
+    for tag, info in (("", exp), ("t", tricky)):
+        for o_ref in (0, 5):
+            for ti, thr in enumerate(out["g17_thresholds"]):
+                got = run_consumer(info, o_ref, float(thr))
+                mine17 = orc.orientation_and_contact_targets(info, o_ref, float(thr))
+                for name, a, b in zip(("argmax", "orientation", "selected", "objects"), got,
+                                      (mine17[0], mine17[1], mine17[2][0], mine17[3])):
+                    out[f"g17{tag}_{name}_o{o_ref}_t{ti}"] = np.asarray(a)
+                    check(f"G17{tag} {name} o={o_ref} thr#{ti}", np.asarray(b), np.asarray(a))
+
     bad = [n for n, ok in chk if not ok]
     if bad:
         raise SystemExit(f"oracle does not reproduce the reference on: {bad}")

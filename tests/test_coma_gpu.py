@@ -363,3 +363,38 @@ def test_product_path_refuses_cpu_tensors(hip_lib):
     smp = make_samples(4, 2, 1, 0, 0.03)[0]
     with pytest.raises(ComaHipError):
         c.aggregate_single_sample(**smp)
+
+
+# ---- consumer of the state: src/application/optimize.py:190-196
+@pytest.mark.parametrize("tricky", [False, True])
+def test_optimisation_app_targets_bit_exact_vs_reference_vectors(golden, tricky, dev, hip_lib):
+    from coma_amd.consumer import orientation_and_contact_targets
+    pre, tag = ("g17t_", "g17t") if tricky else ("g4_", "g17")
+    info = {k: golden[pre + k] for k in ("prob_grid_canon_human_wrt_obj", "contact_dist_expectation_grid_nom",
+                                         "contact_dist_expectation_grid_denom")}
+    info["canon_normal_grid"] = golden["g4_canon_normal_grid_f32"]
+    for o_ref in (0, 5):
+        for ti, thr in enumerate(golden["g17_thresholds"]):
+            am, ori, sel, obj = orientation_and_contact_targets(info, o_ref, float(thr), device=dev)
+            assert am.dtype == np.int64 and obj.dtype == np.int64 and sel[0].dtype == np.int64
+            assert np.array_equal(am, golden[f"{tag}_argmax_o{o_ref}_t{ti}"])
+            assert np.array_equal(ori, golden[f"{tag}_orientation_o{o_ref}_t{ti}"], equal_nan=True)
+            assert np.array_equal(sel[0], golden[f"{tag}_selected_o{o_ref}_t{ti}"])
+            assert np.array_equal(obj, golden[f"{tag}_objects_o{o_ref}_t{ti}"])
+
+
+def test_optimisation_app_targets_full_size_vs_oracle(dev, hip_lib):
+    """H=10475 rows, O=180, N=250 with quantised values (many exact ties) -> first-maximum rule at scale."""
+    from coma_amd.consumer import orientation_and_contact_targets
+    rng = np.random.default_rng(17)
+    H, O, N = 10475, 6, 250
+    info = {"prob_grid_canon_human_wrt_obj": rng.integers(0, 6, size=(H, O, N)).astype(np.float32),
+            "contact_dist_expectation_grid_nom": rng.integers(0, 9, size=(H, 180)).astype(np.float32),
+            "contact_dist_expectation_grid_denom": rng.integers(1, 5, size=(H, 180)).astype(np.float32),
+            "canon_normal_grid": orc.fibonacci_sphere(N).astype(np.float32)}
+    got = orientation_and_contact_targets(info, -2, 7.5, device=dev)        # negative index as NumPy allows
+    ref = orc.orientation_and_contact_targets(info, -2, 7.5)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    assert np.array_equal(got[2][0], ref[2][0]) and np.array_equal(got[3], ref[3]) and 0 < len(ref[3]) < H
+    with pytest.raises(IndexError):
+        orientation_and_contact_targets(info, O, 2.5, device=dev)

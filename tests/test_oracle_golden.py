@@ -2,6 +2,7 @@
 import copy
 
 import numpy as np
+import pytest
 
 from oracle import coma_oracle as orc
 
@@ -101,3 +102,25 @@ def test_nearest_vertex_first_minimum(golden):
     idx = orc.nearest_vertex(golden["g11_points"], golden["g11_verts"])
     assert np.array_equal(idx, golden["g11_idx"])
     assert golden["g11_idx"][5] == 45        # duplicated vertex 45/123: first index wins
+
+
+def _g17_info(golden, tricky):
+    pre = "g17t_" if tricky else "g4_"
+    return {"prob_grid_canon_human_wrt_obj": golden[pre + "prob_grid_canon_human_wrt_obj"],
+            "contact_dist_expectation_grid_nom": golden[pre + "contact_dist_expectation_grid_nom"],
+            "contact_dist_expectation_grid_denom": golden[pre + "contact_dist_expectation_grid_denom"],
+            "canon_normal_grid": golden["g4_canon_normal_grid_f32"]}
+
+
+@pytest.mark.parametrize("tricky", [False, True])
+def test_optimisation_app_targets(golden, tricky):
+    """G17: src/application/optimize.py:190-196 executed by the generator on reference-exported states (plain, and with
+    ties / an all-equal row / NaN / zero denominators injected)."""
+    info, tag = _g17_info(golden, tricky), "g17t" if tricky else "g17"
+    for o_ref in (0, 5):
+        for ti, thr in enumerate(golden["g17_thresholds"]):
+            am, ori, sel, obj = orc.orientation_and_contact_targets(info, o_ref, float(thr))
+            assert np.array_equal(am, golden[f"{tag}_argmax_o{o_ref}_t{ti}"])
+            assert np.array_equal(ori, golden[f"{tag}_orientation_o{o_ref}_t{ti}"], equal_nan=True)
+            assert np.array_equal(sel[0], golden[f"{tag}_selected_o{o_ref}_t{ti}"])
+            assert np.array_equal(obj, golden[f"{tag}_objects_o{o_ref}_t{ti}"])
