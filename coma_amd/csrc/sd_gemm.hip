@@ -11,11 +11,12 @@
 //   m = (batch, oy, ox),  k = (tap, ci),  A[m,k] = X[batch, oy*stride + ky - pad, ox*stride + kx - pad, ci].
 // Both operands are K-contiguous, so A and W fragments are the same 16-byte LDS reads.
 //
-// Tiling (wave64, MFMA v_mfma_f32_32x32x16_f16): block = 4 waves (2x2) computing 128 x BN (BN = 128 or 64),
-// each wave 64 x BN/2 as 2 x (BN/64) MFMA tiles; BK = 32 (two MFMA k-steps); register-staged global->LDS
-// double buffer, one barrier per K tile; LDS rows padded to 80 B so the ds_read_b128 fragment reads of a
-// 16-lane group hit 16 distinct 16-byte slots.  Epilogue fuses bias, per-(batch) bias (time embedding),
-// residual add, SiLU, and GEGLU (value/gate columns interleaved per wave at weight-prep time).
+// Tiling (wave64, MFMA v_mfma_f32_32x32x16_f16): block = WM x WN waves, a wave owns 64 x (TN * 32) outputs; tiles from
+// 128 x 64 to 256 x 320 / 512 x 128 (table at the kernel).  K tiles of 32 or 64 reach LDS by LDS-DMA
+// (`buffer_load_dwordx4 ... offen lds`) into unpadded XOR-swizzled rows, 2-4 stages with counted vmcnt waits and one raw
+// s_barrier per K tile; zero padding is the buffer range check.  The epilogue fuses bias, per-(batch) bias (time
+// embedding), residual add, SiLU, GEGLU (value/gate columns interleaved per wave at weight-prep time) and, on request,
+// per-64-row column sums / sums of squares of the stored tensor (the consumer's GroupNorm statistics).
 #include <hip/hip_fp16.h>
 
 #include <type_traits>

@@ -28,6 +28,9 @@ extern "C" {
 #define SD_EPI_GEGLU 1      /* out[:, j] = v_j * gelu(g_j); weight rows pre-interleaved per 64 columns: [32 v | 32 g] */
 #define SD_EPI_SILU 2       /* out = silu(acc + bias) */
 #define SD_EPI_BIAS_ROWS 4  /* bias indexed by output row instead of column (A = weights, W = activations) */
+/* bits 20..27 select kernel variants for tuning runs (scripts/time_gemm.py): 20 = generic 128x128 tiles only, 21 = 128x320
+ * tile, 22 = tile DMA in one burst, 23 = 2-stage 128x320, 24..27 = forced split-K factor.  Results are identical. */
+#define SD_EPI_TUNING_MASK 0x0ff00000
 
 /* out[m, n] = sum_k A[m, k] * W[n, k] (+ epilogue) with A gathered from one or two NHWC sources:
  *   m = (b, oy, ox), k = (tap, ci);  taps = 9: 3x3, zero pad 1;  taps = 1: 1x1 / linear
