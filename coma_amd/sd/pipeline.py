@@ -183,6 +183,23 @@ class AdaptiveMaskInpaintPipeline:
                             set_alpha_to_one=False)
         return cls(vae, unet, sch, device=dev)
 
+    @classmethod
+    def from_pretrained(cls, weights_dir, batch_size=1, height=512, width=512, device="cuda", with_encoder=True, use_graph=True):
+        """diffusers-layout checkpoint directory (`unet/diffusion_pytorch_model.safetensors`,
+        `vae/diffusion_pytorch_model.safetensors`), what `DiffusionPipeline.from_pretrained(...)` reads in the reference
+        (src/generation/inpaint.py:64-70).  Scheduler constants are the reference's (`:54-59`)."""
+        import os
+        from .weights import check_state, load_safetensors
+        dev = torch.device(device)
+        ust = check_state(load_safetensors(os.path.join(weights_dir, "unet", "diffusion_pytorch_model.safetensors")), unet_shapes(), "UNet")
+        vst = check_state(load_safetensors(os.path.join(weights_dir, "vae", "diffusion_pytorch_model.safetensors")), vae_shapes(), "VAE")
+        unet = HipUNet2DConditionModel(ust, batch=2 * batch_size, height=height // 8, width=width // 8, device=dev, use_graph=use_graph)
+        vae = HipAutoencoderKL(vst, batch=batch_size, height=height, width=width, device=dev, with_encoder=with_encoder,
+                               use_graph=use_graph)
+        sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                            set_alpha_to_one=False)
+        return cls(vae, unet, sch, device=dev)
+
     def to(self, device):
         return self
 

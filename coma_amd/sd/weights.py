@@ -163,6 +163,17 @@ def load_safetensors(path, device="cpu", dtype=torch.float16):
     return {k: v.to(dtype).to(device) for k, v in load_file(path).items()}
 
 
+def check_state(state, shapes, what="model"):
+    """A checkpoint must carry exactly the tensors of the architecture the kernels were laid out for (diffusers' key
+    names); a wrong family (e.g. a text-to-image UNet with a 4-channel conv_in) is reported before anything is launched."""
+    missing = sorted(k for k in shapes if k not in state)
+    wrong = sorted(f"{k}: {tuple(state[k].shape)} != {tuple(shapes[k])}" for k in shapes if k in state and tuple(state[k].shape) != tuple(shapes[k]))
+    if missing or wrong:
+        raise ValueError(f"{what} checkpoint does not match the SD-1.5-inpainting layout: {len(missing)} missing "
+                         f"(first: {missing[:3]}), {len(wrong)} with other shapes (first: {wrong[:3]})")
+    return {k: state[k] for k in shapes}          # extra tensors (e.g. position ids) are ignored
+
+
 # ------------------------------------------------------------------ kernel layouts
 def conv_weight(w, cin_pad=None, cout_pad=None):
     """[Cout, Cin, kh, kw] -> [Cout(_pad), kh*kw*Cin(_pad)] fp16, K ordered (ky, kx, ci)."""

@@ -131,14 +131,7 @@ def set_pipeline(ldm_model_key, adaptive_mask_model_type, default_ddim_steps, we
     from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
     assert ldm_model_key in HF_MODEL_KEYS
     if weights_dir:
-        from coma_amd.sd.scheduler import DDIMScheduler
-        from coma_amd.sd.unet import HipUNet2DConditionModel
-        from coma_amd.sd.vae import HipAutoencoderKL
-        from coma_amd.sd.weights import load_safetensors
-        unet = HipUNet2DConditionModel(load_safetensors(f"{weights_dir}/unet/diffusion_pytorch_model.safetensors"), batch=2, device=device)
-        vae = HipAutoencoderKL(load_safetensors(f"{weights_dir}/vae/diffusion_pytorch_model.safetensors"), batch=1, device=device)
-        sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False)
-        pipeline = AdaptiveMaskInpaintPipeline(vae, unet, sch, device=device)
+        pipeline = AdaptiveMaskInpaintPipeline.from_pretrained(weights_dir, batch_size=1, device=device)
     else:
         pipeline = AdaptiveMaskInpaintPipeline.from_random(batch_size=1, device=device)
     pipeline.scheduler.set_timesteps(default_ddim_steps)

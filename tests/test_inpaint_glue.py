@@ -141,3 +141,17 @@ def test_inpaint_cli_flags_match_reference():
         assert f in flags, f
     d = build_parser().parse_args([])
     assert (d.default_cfg_scale, d.default_strength, d.default_ddim_steps, d.num_img_per_combination) == (11.0, 0.98, 50, 10)
+
+
+def test_checkpoint_layout_check():
+    """A checkpoint of another family is refused with a readable message before any launch (weights.check_state)."""
+    import torch
+    from coma_amd.sd import weights
+    shapes = weights.unet_shapes()
+    meta = {k: torch.empty(v, device="meta") for k, v in shapes.items()}
+    assert set(weights.check_state(dict(meta, extra=torch.empty(1, device="meta")), shapes)) == set(shapes)
+    t2i = dict(meta)
+    t2i["conv_in.weight"] = torch.empty(320, 4, 3, 3, device="meta")          # text-to-image UNet: 4 input channels
+    del t2i["mid_block.resnets.0.conv1.bias"]
+    with pytest.raises(ValueError, match="1 missing.*conv1.bias.*1 with other shapes.*conv_in.weight"):
+        weights.check_state(t2i, shapes, "UNet")

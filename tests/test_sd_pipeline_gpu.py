@@ -100,3 +100,31 @@ def test_adaptive_loop_full_resolution(hip_lib):
     assert (m <= mask[0, 0].numpy()).all(), "adapted mask must stay inside the default mask"
     b = run()
     assert torch.equal(a, b), "same generator seed -> identical image"
+
+
+def test_from_pretrained_reads_a_diffusers_layout_checkpoint(tmp_path, hip_lib):
+    """Write the SD-1.5-inpainting tensors under diffusers' key names as safetensors, load them through
+    AdaptiveMaskInpaintPipeline.from_pretrained (the reference's DiffusionPipeline.from_pretrained call,
+    src/generation/inpaint.py:64-70) and require the same image as the pipeline built from the same tensors in memory."""
+    from safetensors.torch import save_file
+    from coma_amd.sd import weights
+    from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline
+    for sub, shapes, seed in (("unet", weights.unet_shapes(), 0), ("vae", weights.vae_shapes(), 1)):
+        (tmp_path / sub).mkdir()
+        st = weights.random_state(shapes, seed=seed)
+        st["not_a_weight.position_ids"] = torch.arange(4)            # extra tensors are tolerated
+        save_file({k: v.contiguous() for k, v in st.items()}, str(tmp_path / sub / "diffusion_pytorch_model.safetensors"))
+    g = torch.Generator().manual_seed(5)
+    image = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, 512, 512)
+    mask[:, :, 100:400, 150:380] = 1
+    pe, ne = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    outs = []
+    for pipe in (AdaptiveMaskInpaintPipeline.from_pretrained(str(tmp_path), batch_size=1, device=DEV),
+                 AdaptiveMaskInpaintPipeline.from_random(batch_size=1, device=DEV, seed=0)):
+        gen = torch.Generator(device=DEV).manual_seed(3)
+        outs.append(pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=2,
+                         guidance_scale=7.5, generator=gen, output_type="u8", use_adaptive_mask=False).images.cpu())
+        del pipe
+        torch.cuda.empty_cache()
+    assert outs[0].shape == (1, 512, 512, 3) and torch.equal(outs[0], outs[1])
