@@ -294,6 +294,8 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   if (d % 8 || d <= 0 || d > 160) return fail(COMA_E_INVALID, "sd_attention_f16: head dim %d unsupported (multiple of 8, <= 160)", d);
   if (ldq < heads * d || ldk < heads * d || ldo < heads * d || ldv < ((lk + 7) & ~7) || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
     return fail(COMA_E_INVALID, "sd_attention_f16: bad leading dimensions");
+  if ((long long)lk * ldk * 2 >= 0x80000000LL || (long long)d * ldv * 2 >= 0x80000000LL)
+    return fail(COMA_E_INVALID, "sd_attention_f16: K / V^T slice of one (batch, head) exceeds 2 GiB");
   AttnArgs a;
   a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.vt = (const _Float16*)vt; a.out = (_Float16*)out;
   a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;

@@ -563,6 +563,12 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   g.rows_per_batch = d->out_h * d->out_w;
   long long M = (long long)d->batch * g.rows_per_batch;
   if (M > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: M too large");
+  // the LDS-DMA addresses rows with 32-bit byte offsets from the tensor base (bit 31 marks zero padding)
+  const long long a_bytes = (long long)d->batch * d->in_h * d->in_w * (d->c0 > d->c1 ? d->c0 : d->c1) * 2;
+  const long long w_bytes = (long long)d->n * d->taps * (d->c0 + d->c1) * 2;
+  if (a_bytes >= 0x80000000LL || w_bytes >= 0x80000000LL)
+    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a source tensor (%lld B) or the weights (%lld B) exceed 2 GiB per launch; split the batch",
+                a_bytes, w_bytes);
   g.M = (int)M; g.N = d->n; g.K = d->taps * (d->c0 + d->c1);
   g.w = (const _Float16*)d->w; g.bias = (const _Float16*)d->bias; g.bias_bn = (const _Float16*)d->bias_bn;
   g.res = (const _Float16*)d->res; g.ldr = d->ldr > 0 ? d->ldr : d->n;

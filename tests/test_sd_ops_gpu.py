@@ -249,3 +249,21 @@ def test_groupnorm_statistics_fused_into_the_gemm_epilogue(ops, M, c0, c1, n, hw
     ops.groupnorm_colstats(out, ga2.to(DEV), be2.to(DEV), y2, stats, cs, batch=B, hw=hw, c0=n, x1=out, c1=n, colstats1=cs, eps=1e-5,
                            silu=False)
     close(y2, so.groupnorm_ref(torch.cat([out.cpu(), out.cpu()], -1), ga2, be2, batch=B, hw=hw, eps=1e-5, silu=False))
+
+
+def test_argument_errors_are_reported_not_launched(ops):
+    """Error behaviour of the C ABI: bad arguments come back as an error code + coma_last_error text, nothing is launched."""
+    from coma_amd._lib import ComaHipError
+    x = torch.zeros(64, 64, dtype=F16, device=DEV)
+    w = torch.zeros(64, 64, dtype=F16, device=DEV)
+    out = torch.zeros(64, 64, dtype=F16, device=DEV)
+    with pytest.raises(ComaHipError, match="taps must be 1 or 9"):
+        ops.conv_gemm(x, w, out, batch=64, in_h=1, in_w=1, c0=64, n=64, taps=5)
+    with pytest.raises(ComaHipError, match="multiples of 32"):
+        ops.conv_gemm(x, w, out, batch=64, in_h=1, in_w=1, c0=40, n=64)
+    with pytest.raises(ComaHipError, match="exceed 2 GiB"):          # sizes only: refused before any memory is touched
+        ops.conv_gemm(x, w, out, batch=16, in_h=512, in_w=512, c0=256, n=64, taps=9)
+    with pytest.raises(ComaHipError, match="head dim 44 unsupported"):
+        ops.attention(x, x, x, out, batch=1, heads=1, lq=64, lk=64, d=44, ldq=64, ldk=64, ldv=64, ldo=64, scale=1.0)
+    with pytest.raises(ComaHipError, match="must live on a HIP device"):
+        ops.conv_gemm(x.cpu(), w, out, batch=64, in_h=1, in_w=1, c0=64, n=64)
