@@ -22,6 +22,8 @@
 // quarter rate ~510 cycles, ~75 more full-rate instructions); the staging is kept off the VALU entirely.
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/sd_hip.h"
 
@@ -163,7 +165,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
 
   const int ntiles = (a.lk + BKV - 1) / BKV;
   issue_tile(0, 0);
-  for (int tile = 0; tile < ntiles; ++tile) {
+  // the key-tile body exists twice: full tiles carry no masking code at all (left inside one body the compiler hoists
+  // the 32 key-index adds and compares of the ragged case out of their wave-uniform branch, +64 VALU per tile)
+  auto process_tile = [&](int tile, auto ragged_c) {
+    constexpr bool RAGGED = decltype(ragged_c)::value;
     const int stage = tile & 1, key0 = tile * BKV;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile `tile` has landed
     __builtin_amdgcn_s_barrier();                        // ... and everyone's; all waves are done reading stage^1
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     half8 pf[QT][4];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      if (key0 + BKV > a.lk) {   // wave-uniform: only the last tile can be ragged
+      if constexpr (RAGGED) {    // only the last tile can be ragged
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -251,7 +256,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
         for (int qt = 0; qt < QT; ++qt) o[qt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qt][st], o[qt][t], 0, 0, 0);
       }
     }
-  }
+  };
+  const int nfull = a.lk / BKV;
+  for (int tile = 0; tile < nfull; ++tile) process_tile(tile, std::false_type{});
+  if (nfull < ntiles) process_tile(nfull, std::true_type{});
 
   // ---- normalise and store: lane (query, half) owns dd = t*32 + 8*(r>>2) + 4*hh + (r&3)
 #pragma unroll
