@@ -149,8 +149,9 @@ class SyntheticHumanMaskPredictor:
         if ell is None:
             yy, xx = np.mgrid[0:H, 0:W]
             ell = self._ellipses[(H, W)] = ((yy - H / 2) / (H * 0.3)) ** 2 + ((xx - W / 2) / (W * 0.18)) ** 2 <= 1.0
-        lum = image_u8.astype(np.float32).mean(-1)
-        return {"mask": (ell & (lum > lum.mean() - 40)).astype(np.uint8), "vis": None, "asset_mask": None}
+        s3 = image_u8[..., 0].astype(np.uint16) + image_u8[..., 1] + image_u8[..., 2]    # 3 x luminance, integer
+        thr = s3.mean(dtype=np.float64) - 120.0                      # lum > mean(lum) - 40
+        return {"mask": (ell & (s3 > thr)).view(np.uint8), "vis": None, "asset_mask": None}
 
 
 class _Output(dict):
