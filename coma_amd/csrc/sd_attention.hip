@@ -315,6 +315,7 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   else if (d == 40) hipLaunchKernelGGL((attention_kernel<3, 2, 1, 40>), grid, dim3(256), 0, s, a);
   else if (d <= 48) hipLaunchKernelGGL((attention_kernel<3, 2, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
   else if (d <= 64) hipLaunchKernelGGL((attention_kernel<4, 2, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
+  else if (d <= 80) hipLaunchKernelGGL((attention_kernel<5, 3, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
   else if (d <= 96) hipLaunchKernelGGL((attention_kernel<6, 3, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
   else if (d <= 128) hipLaunchKernelGGL((attention_kernel<8, 4, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((attention_kernel<10, 5, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
