@@ -267,3 +267,60 @@ def test_argument_errors_are_reported_not_launched(ops):
         ops.attention(x, x, x, out, batch=1, heads=1, lq=64, lk=64, d=44, ldq=64, ldk=64, ldv=64, ldo=64, scale=1.0)
     with pytest.raises(ComaHipError, match="must live on a HIP device"):
         ops.conv_gemm(x.cpu(), w, out, batch=64, in_h=1, in_w=1, c0=64, n=64)
+
+
+@pytest.mark.parametrize("M,N,K,taps,hw,epi", [
+    (32768, 320, 640, 1, None, 0),          # 256 x 320 tile
+    (32768, 512, 576, 9, 4096, 0),          # 256 x 256 tile (3x3, 64 channels)
+    (65536, 128, 1152, 9, 4096, 0),         # 512 x 128 tile
+    (65536, 128, 2304, 9, 4096, 0),         # 256 x 128 tile
+    (8192, 640, 640, 1, None, 0),           # 128 x 320 tile, 3 stages
+    (4096, 1280, 2560, 1, None, 0),         # 128 x 128, BK = 64
+    (4096, 1280, 640, 1, None, 0),          # 128 x 128, BK = 32, 4 stages
+    (1024, 1280, 5760, 9, 64, 0),           # split-K
+    (4096, 2560, 320, 1, None, 1),          # GEGLU, 256 x 256
+    (4096, 96, 640, 1, None, 0),            # 128 x 64
+])
+def test_gemm_race_screen(ops, M, N, K, taps, hw, epi):
+    """Every tile family relies on counted vmcnt waits and raw barriers around in-flight LDS-DMA: the same launch must
+    give bit-identical results run after run (a missing wait shows up as rare differing tiles), and match fp32."""
+    C = K // taps
+    x = rnd(M, C, seed=1)
+    w, b = rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    kw = dict(batch=M // hw, in_h=int(hw ** 0.5), in_w=int(hw ** 0.5), c0=C, n=N, taps=9) if taps == 9 else \
+        dict(batch=M, in_h=1, in_w=1, c0=K, n=N)
+    ws = torch.empty(32 << 20, dtype=torch.float32, device=DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    if epi & 1:
+        from coma_amd.sd.weights import geglu_interleave
+        wd, bd = (t.to(DEV) for t in geglu_interleave(w, b))
+    outs = []
+    for rep in range(12):
+        out = torch.empty(M, N // 2 if epi & 1 else N, dtype=F16, device=DEV)
+        ops.conv_gemm(xd, wd, out, bias=bd, epi=epi, workspace=ws, **kw)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    if taps == 1:
+        ref = x.float() @ w.float().T + b.float()
+        if epi & 1:
+            ref = ref[:, :N // 2] * torch.nn.functional.gelu(ref[:, N // 2:])
+        close(outs[0], ref)
+
+
+def test_attention_race_screen(ops):
+    B, H, L, d = 2, 8, 1200, 40
+    C = H * d
+    q, k = rnd(B, L, C, seed=1).to(DEV), rnd(B, L, C, seed=2).to(DEV)
+    ldv = (L + 7) // 8 * 8
+    vt = torch.zeros(B, C, ldv, dtype=F16, device=DEV)
+    vt[:, :, :L] = rnd(B, C, L, seed=3).to(DEV)
+    outs = []
+    for rep in range(12):
+        out = torch.empty(B, L, C, dtype=F16, device=DEV)
+        ops.attention(q, k, vt, out, batch=B, heads=H, lq=L, lk=L, d=d, ldq=C, ldk=C, ldv=ldv, ldo=C, scale=d ** -0.5)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
