@@ -16,7 +16,6 @@ Reference map (file:line in the reference repo):
 """
 from __future__ import annotations
 
-import math
 import pickle
 from copy import deepcopy
 from functools import partial

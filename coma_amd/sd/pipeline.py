@@ -24,7 +24,7 @@ from . import ops
 from .scheduler import DDIMScheduler
 from .unet import HipUNet2DConditionModel
 from .vae import HipAutoencoderKL
-from .weights import UNET_CFG, VAE_CFG, random_state, unet_shapes, vae_shapes
+from .weights import random_state, unet_shapes, vae_shapes
 
 try:
     import PIL.Image

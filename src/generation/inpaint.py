@@ -19,7 +19,6 @@ import pickle
 import sys
 from glob import glob
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:

@@ -12,7 +12,6 @@ import os
 import sys
 import types
 import copy
-import pickle
 import tempfile
 
 import numpy as np

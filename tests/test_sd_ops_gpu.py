@@ -1,9 +1,7 @@
 """GPU parity of every sd_* operator against a torch fp32 reference of the same op on the same fp16-rounded
 inputs (oracle/sd_oracle.py).  Tolerance: fp16 storage / fp32 accumulation -> |err| <= 3e-3 * max|ref| unless a
 test states otherwise (GroupNorm/attention outputs are O(1), so this is ~1.5 fp16 ulps of the largest values)."""
-import math
 
-import numpy as np
 import pytest
 import torch
 
