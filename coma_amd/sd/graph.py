@@ -60,6 +60,17 @@ class LaunchGraph:
                  tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}")
         return out
 
+    def dup(self, src, dst):
+        """dst = [src | src] along the batch axis (two identical CFG halves); the GroupNorm column sums of src follow."""
+        assert dst.numel() == 2 * src.numel()
+        self.add(lambda: dst.view(2, -1).copy_(src.view(1, -1)), tag=f"dup {src.numel() * 2 >> 20} MiB")
+        cs = self._colstats.get(src.data_ptr())
+        if cs is not None:
+            cs2 = torch.zeros(2 * cs.shape[0], *cs.shape[1:], dtype=cs.dtype, device=self.device)
+            self.add(lambda: cs2.view(2, -1).copy_(cs.view(1, -1)), tag="dup colstats")
+            self._colstats[dst.data_ptr()] = cs2
+        return dst
+
     def groupnorm(self, x0, gamma, beta, out, *, batch, hw, c0, x1=None, c1=0, eps, silu):
         stats = self.gn_scratch(batch, hw)
         cs0 = self._colstats.get(x0.data_ptr())

@@ -177,7 +177,7 @@ class AdaptiveMaskInpaintPipeline:
         """Seeded random SD-1.5-inpainting weights (no checkpoint is reachable offline); batch_size = images per call."""
         dev = torch.device(device)
         unet = HipUNet2DConditionModel(random_state(unet_shapes(), seed=seed), batch=2 * batch_size, height=height // 8,
-                                       width=width // 8, device=dev, use_graph=use_graph)
+                                       width=width // 8, device=dev, use_graph=use_graph, cfg_shared_prefix=True)
         vae = HipAutoencoderKL(random_state(vae_shapes(), seed=seed + 1), batch=batch_size, height=height, width=width, device=dev,
                                with_encoder=with_encoder, use_graph=use_graph)
         sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
@@ -194,7 +194,7 @@ class AdaptiveMaskInpaintPipeline:
         dev = torch.device(device)
         ust = check_state(load_safetensors(os.path.join(weights_dir, "unet", "diffusion_pytorch_model.safetensors")), unet_shapes(), "UNet")
         vst = check_state(load_safetensors(os.path.join(weights_dir, "vae", "diffusion_pytorch_model.safetensors")), vae_shapes(), "VAE")
-        unet = HipUNet2DConditionModel(ust, batch=2 * batch_size, height=height // 8, width=width // 8, device=dev, use_graph=use_graph)
+        unet = HipUNet2DConditionModel(ust, batch=2 * batch_size, height=height // 8, width=width // 8, device=dev, use_graph=use_graph, cfg_shared_prefix=True)
         vae = HipAutoencoderKL(vst, batch=batch_size, height=height, width=width, device=dev, with_encoder=with_encoder,
                                use_graph=use_graph)
         sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,

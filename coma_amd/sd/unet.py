@@ -28,7 +28,12 @@ class _Cfg(dict):
 
 
 class HipUNet2DConditionModel:
-    def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True):
+    def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
+                 cfg_shared_prefix=False):
+        """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
+        (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
+        Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
+        sees identical inputs in both halves; it is computed once on batch/2 and duplicated -- bit-identical outputs."""
         self.cfgd = cfg
         self.config = _Cfg(in_channels=cfg["in_channels"], out_channels=cfg["out_channels"], sample_size=height)
         self.device = torch.device(device)
@@ -36,6 +41,8 @@ class HipUNet2DConditionModel:
         self.heads = cfg["heads"]
         self.ctx_dim = cfg["cross_attention_dim"]
         self.use_graph = use_graph
+        self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
+        self._B = batch                              # batch the block builders currently emit launches for
         self.dtype = F16
         self.s = {k: v.to(self.device, F16) for k, v in state.items()}
         self.g = LaunchGraph(self.device)        # per-step graph
@@ -78,15 +85,17 @@ class HipUNet2DConditionModel:
         # --- conv_in (9 -> 64 padded input channels)
         H, W = self.H, self.W
         w_in = conv_weight(s["conv_in.weight"], cin_pad=64)
-        h = g.buf(B * H * W, ch[0])
-        g.conv(self.x_in, w_in, h, batch=B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9, bias=s["conv_in.bias"], stats=True)
-        skips = [(h, ch[0], H, W)]
+        if self.cfg_shared_prefix:
+            self._B = B // 2                         # shared CFG prefix: first half of x_in / timesteps only
+        h = g.buf(self._B * H * W, ch[0])
+        g.conv(self.x_in, w_in, h, batch=self._B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9, bias=s["conv_in.bias"], stats=True)
+        skips = [(g.dup(h, g.buf(B * H * W, ch[0])) if self.cfg_shared_prefix else h, ch[0], H, W)]
         cin = ch[0]
         for i, cout in enumerate(ch):
             for j in range(self.cfgd["layers_per_block"]):
                 h = self._resnet(f"down_blocks.{i}.resnets.{j}", h, cin, None, 0, cout, H, W)
                 if self.cfgd["down_has_attn"][i]:
-                    h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cout, H, W)
+                    h = self._transformer(f"down_blocks.{i}.attentions.{j}", h, cout, H, W)   # returns at the full batch
                 cin = cout
                 skips.append((h, cout, H, W))
             if i < len(ch) - 1:
@@ -120,7 +129,7 @@ class HipUNet2DConditionModel:
                bias=pad_vec(s["conv_out.bias"], 64))
 
     def _resnet(self, p, x0, c0, x1, c1, cout, H, W):
-        g, s, B = self.g, self.s, self.batch
+        g, s, B = self.g, self.s, self._B
         M, cin = B * H * W, c0 + c1
         n1 = g.buf(M, cin)
         g.groupnorm(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=c0, x1=x1, c1=c1, eps=1e-5,
@@ -144,7 +153,7 @@ class HipUNet2DConditionModel:
         return out
 
     def _transformer(self, p, x, C, H, W):
-        g, s, B, heads = self.g, self.s, self.batch, self.heads
+        g, s, B, heads = self.g, self.s, self._B, self.heads
         L, M, d = H * W, B * H * W, C // heads
         t = p + ".transformer_blocks.0"
         gn = g.buf(M, C)
@@ -166,6 +175,12 @@ class HipUNet2DConditionModel:
         h1 = g.buf(M, C)
         g.conv(a, s[t + ".attn1.to_out.0.weight"], h1, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[t + ".attn1.to_out.0.bias"],
                res=h)
+        if B != self.batch:
+            # end of the shared CFG prefix: from the first cross-attention on the two halves differ
+            B = self._B = self.batch
+            M = B * L
+            h1 = g.dup(h1, g.buf(M, C))
+            x = g.dup(x, g.buf(M, C))
         # ---- cross attention (K, V^T of the context live in the per-prompt graph)
         n2 = g.buf(M, C)
         g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)

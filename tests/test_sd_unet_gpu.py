@@ -56,3 +56,37 @@ def test_unet_responds_to_timestep_and_context(setup):
     ref_b = so.unet_ref(state, sample, torch.tensor([1.0, 1.0]), ctx, __import__("coma_amd.sd.weights", fromlist=["x"]).UNET_CFG)
     rel, cos = _metrics(b, ref_b)
     assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+
+
+@pytest.mark.parametrize("hw,batch", [(16, 4), (64, 16)])
+def test_shared_cfg_prefix_is_bit_identical(setup, hw, batch):
+    """Classifier-free guidance feeds the UNet [uncond | cond] with the SAME sample and timestep in both halves
+    (utils/adaptive_mask_inpainting.py:990): computing the layers before the first cross-attention once and duplicating
+    them must not change a single bit of the output (and the fp32 reference still agrees)."""
+    state, _, _, _, _, UNet = setup
+    g = torch.Generator().manual_seed(7)
+    half = torch.randn(batch // 2, 9, hw, hw, generator=g).half().float()
+    sample = torch.cat([half, half])
+    ctx = torch.randn(batch, 77, 768, generator=g).half().float()
+    t = torch.full((batch,), 441.0)
+    outs = []
+    for shared in (False, True):
+        unet = UNet(state, batch=batch, height=hw, width=hw, device=DEV, use_graph=True, cfg_shared_prefix=shared)
+        assert unet.cfg_shared_prefix == shared
+        outs.append(unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV))[0].clone())
+        flops = unet.g.flops
+        del unet
+        torch.cuda.empty_cache()
+        outs.append(flops)
+    if batch == 16:
+        # benchmark configuration: the half-batch launches pick the same tile families -> not a single bit changes
+        assert torch.equal(outs[0], outs[2])
+    else:
+        # small batches may pick another split-K factor for the half-batch prefix: equal up to fp16 rounding
+        assert float((outs[0] - outs[2]).abs().max()) <= 2e-3 * float(outs[0].abs().max())
+    assert outs[3] < outs[1]                                    # fewer MFMA flops issued
+    assert not torch.equal(outs[0][:batch // 2], outs[0][batch // 2:])   # the halves do differ (context)
+    if hw == 16:
+        from coma_amd.sd import weights
+        rel, cos = _metrics(outs[2], so.unet_ref(state, sample, t, ctx, weights.UNET_CFG))
+        assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
