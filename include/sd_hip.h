@@ -86,9 +86,11 @@ int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* 
 /* Fused multi-head attention (online softmax), fp16 in/out, fp32 accumulate.
  *   q   : [batch, lq, ldq]   head h at columns [h*d, (h+1)*d)          (ldq >= heads*d)
  *   k   : [batch, lk, ldk]   same column convention
- *   vt  : [batch, heads*d, ldv]  V TRANSPOSED: row h*d+i holds component i of every key (ldv >= lk, mult. of 8)
+ *   vt  : [batch, heads*d, ldv]  V TRANSPOSED: row h*d+i holds component i of every key (ldv >= lk rounded up to 8, a
+ *         multiple of 8); the pad columns lk..ldv-1 must hold finite values (they meet zero softmax weights)
  *   out : [batch, lq, ldo]
- * out = softmax(q k^T * scale) v per (batch, head).  d in {40, 64, 80, 160} (multiples of 8, <= 160).
+ * out = softmax(q k^T * scale) v per (batch, head).  d: any multiple of 8 up to 160.  The K and V^T slices of one
+ * (batch, head) must stay below 2 GiB (32-bit LDS-DMA offsets); violations return an error, nothing is launched.
  * replaces: diffusers Attention (xformers / AttnProcessor2_0 scaled_dot_product_attention) in the UNet. */
 int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk,
                      int d, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
