@@ -626,6 +626,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (big && spread) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2, true>), grid, dim3(512), 0, st, g);
   else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2, true>), grid, dim3(256), 0, st, g);
   else if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
+  else if ((big_geglu || big256) && spread) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2, true>), grid, dim3(512), 0, st, g);
   else if (big_geglu || big256) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
   else if (tall128) hipLaunchKernelGGL((conv_gemm_kernel<8, 1, 4, 32, 3>), grid, dim3(512), 0, st, g);
   else if (big128) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 2, 64, 2>), grid, dim3(512), 0, st, g);
