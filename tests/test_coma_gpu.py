@@ -95,6 +95,32 @@ def test_accumulation_composes_over_batches_and_single_samples(golden, dev, hip_
     assert orc.max_rel_err(_np(b.prob_grid_canon_human_wrt_obj), _np(a.prob_grid_canon_human_wrt_obj)) <= 1e-5
 
 
+@pytest.mark.parametrize("p,sp", [([1, 0, 0], [0, 1, 0]), ([0, 1, 0], [0, 0, 1]), ([0.6, 0.0, 0.8], [0, 1, 0])])
+def test_principle_vector_other_than_z(p, sp, dev, hip_lib):
+    """K2 with p != z: the reference's literal (incomplete) skew matrix `b_cross` (utils/coma.py:149-155) only equals
+    b x p for p = z, so this pins the quirk on the device (G2 pins the oracle against the reference for p = x)."""
+    from utils.coma import ComA
+    H, O, N = 24, 10, 250
+    samples = make_samples(H, O, 3, seed=31, thres=0.05, const_obj=False)
+    for s in samples:
+        s["obj_normals"] = s["obj_normals"].copy()
+        s["obj_normals"][0] = [-v for v in p]          # exactly opposite of p -> mirrored branch about sub_p
+        s["obj_normals"][1] = p
+        s["human_normals"][0] = [-v for v in p]
+    coma = ComA(H, O, N, 0, proximity_settings=dict(spatial_grid_size=0.07, spatial_grid_thres=0.05), principle_vec=p,
+                sub_principle_vec=sp, rel_dist_method="dist", normal_gaussian_sigma=0.25, eps=1e-10, device=dev)
+    _fill(coma, samples)
+    m = orc.ComAOracle(H, O, N, 0.07, 0.05, principle_vec=p, sub_principle_vec=sp, sigma=0.25, eps=1e-10)
+    z = orc.ComAOracle(H, O, N, 0.07, 0.05, sigma=0.25, eps=1e-10)
+    for s in samples:
+        m.aggregate_sample(**s)
+        z.aggregate_sample(**s)
+    assert np.array_equal(_np(coma.significant_contact_count), m.cnt)
+    assert orc.max_rel_err(_np(coma.prob_grid_canon_human_wrt_obj), m.P_h_wrt_o) <= RTOL
+    assert orc.max_rel_err(_np(coma.prob_grid_canon_obj_wrt_human), m.P_o_wrt_h) <= RTOL
+    assert orc.max_rel_err(m.P_h_wrt_o, z.P_h_wrt_o) > 0.1      # and p really matters for these inputs
+
+
 @pytest.mark.parametrize("N", [1, 63, 64, 65, 250, 256, 257, 600])
 def test_bin_counts_ragged_and_multi_chunk(N, dev, hip_lib):
     H, O, S = 9, 7, 3     # H*O = 63: not a multiple of the 8-pair wave tile

@@ -304,7 +304,60 @@ def test_gemm_race_screen(ops, M, N, K, taps, hw, epi):
         ref = x.float() @ w.float().T + b.float()
         if epi & 1:
             ref = ref[:, :N // 2] * torch.nn.functional.gelu(ref[:, N // 2:])
-        close(outs[0], ref)
+    else:
+        ref = so.conv_ref(x, w.reshape(N, 9, C), batch=M // hw, h=int(hw ** 0.5), w_=int(hw ** 0.5), taps=9, bias=b)
+    close(outs[0], ref)
+
+
+# The tile families the benchmark (BASELINE config 2 / 3) actually launches, as 3x3 convolutions against the fp32 oracle:
+# halo rows (zero padding by the buffer range check), rows >= M, the XCD-banded tile order and the two-source /
+# stride-2 / nearest-x2 gathers are all exercised on the big tiles here, not only on the 128-wide fallbacks.
+BIG_CONV = [
+    # B, H, W, c0, c1, n, stride, up      tile family selected by sd_conv_gemm_f16
+    (8, 64, 64, 320, 0, 320, 1, 0),       # 256 x 320 (SPREAD), M = 32768: UNet 64x64 ResNet conv
+    (8, 64, 64, 320, 320, 320, 1, 0),     # 256 x 320, two concatenated sources (up-block skip)
+    (8, 32, 32, 320, 0, 640, 1, 1),       # 256 x 320, nearest-x2 upsampled source (M = 32768)
+    (32, 64, 64, 320, 0, 320, 2, 0),      # 256 x 320, stride-2 down-sampler at M = 32768
+    (16, 64, 64, 320, 0, 320, 2, 0),      # stride 2 down-sampler, M = 16384 -> 128 x 320 mid tile
+    (8, 32, 32, 320, 0, 640, 1, 0),       # 128 x 320 mid tile (M = 8192), 3 stages
+    (8, 32, 32, 640, 320, 640, 1, 0),     # 128 x 320, two sources
+    (2, 128, 128, 256, 0, 256, 1, 0),     # 256 x 256 (VAE 256-channel conv), M = 32768
+    (2, 64, 64, 512, 0, 512, 1, 1),       # 256 x 256 with upsample (VAE up-block)
+    (1, 256, 256, 128, 0, 128, 1, 0),     # 512 x 128 tall tile (K = 1152), M = 65536
+    (1, 256, 256, 256, 0, 128, 1, 0),     # 256 x 128 (K = 2304), M = 65536
+    (1, 250, 250, 128, 0, 128, 1, 0),     # 512 x 128, ragged M (62500 rows: last tile partly beyond M)
+    (3, 100, 110, 320, 0, 320, 1, 0),     # 256 x 320, ragged M = 33000, non-square image
+]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,n,stride,up", BIG_CONV)
+def test_conv3x3_big_tiles_match_fp32(ops, B, H, W, c0, c1, n, stride, up):
+    x0, x1 = rnd(B * H * W, c0, seed=1), (rnd(B * H * W, c1, seed=2) if c1 else None)
+    w = rnd(n, 9, c0 + c1, seed=3, scale=(9 * (c0 + c1)) ** -0.5)
+    b, tb, = rnd(n, seed=4), rnd(B, n, seed=5)
+    oh, ow = (H // 2, W // 2) if stride == 2 else ((2 * H, 2 * W) if up else (H, W))
+    res = rnd(B * oh * ow, n, seed=6)
+    out = torch.empty(B * oh * ow, n, dtype=F16, device=DEV)
+    ws = torch.empty(32 << 20, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(x0.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, in_h=H, in_w=W, out_h=oh, out_w=ow, c0=c0, n=n,
+                  a1=x1.to(DEV) if c1 else None, c1=c1, taps=9, stride=stride, upsample=up, bias=b.to(DEV),
+                  bias_bn=tb.to(DEV), res=res.to(DEV), workspace=ws)
+    xc = torch.cat([x0, x1], -1) if c1 else x0
+    ref = so.conv_ref(xc, w, batch=B, h=H, w_=W, taps=9, stride=stride, upsample=bool(up), bias=b, bias_bn=tb, res=res)
+    close(out, ref)
+
+
+def test_conv3x3_colstats_on_big_tile(ops):
+    """The producer-side GroupNorm statistics (per-64-row column sums of the stored tensor) on the 256 x 320 tile."""
+    B, H, c, n = 8, 64, 320, 320
+    x, w, b = rnd(B * H * H, c, seed=1), rnd(n, 9, c, seed=3, scale=(9 * c) ** -0.5), rnd(n, seed=4)
+    out = torch.empty(B * H * H, n, dtype=F16, device=DEV)
+    cs = torch.zeros(B * H * H // 64, 2, n, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, in_h=H, in_w=H, c0=c, n=n, taps=9, bias=b.to(DEV), colstats=cs)
+    close(out, so.conv_ref(x, w, batch=B, h=H, w_=H, taps=9, bias=b))
+    o = out.float().reshape(-1, 64, n)
+    assert torch.allclose(cs[:, 0], o.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(cs[:, 1], (o * o).sum(1), rtol=1e-4, atol=1e-3)
 
 
 def test_attention_race_screen(ops):

@@ -48,3 +48,31 @@ def test_encoder_moments_and_sampling(vae_setup):
     ops.vae_sample(vae.enc.moments, 64, noise.to(DEV), 0.18215, 128, lat32=lat)
     exp = (mom[:, :, :4].cpu() + torch.exp(0.5 * mom[:, :, 4:].cpu().clamp(-30, 20)) * noise) * 0.18215
     assert float((lat.cpu() - exp).abs().max()) <= 1e-5 * float(exp.abs().max()) + 1e-6
+
+
+@pytest.fixture(scope="module")
+def vae512(hip_lib):
+    from coma_amd.sd import weights
+    from coma_amd.sd.vae import HipAutoencoderKL
+    state = weights.random_state(weights.vae_shapes(), seed=3)
+    return state, weights.VAE_CFG, HipAutoencoderKL(state, batch=1, height=512, width=512, device=DEV)
+
+
+def test_decoder_512_matches_fp32_reference(vae512):
+    """The benchmark's resolution: 64x64 latent -> 512x512 image.  Here M runs up to 262144 rows, so the 256 x 256,
+    256 x 128 and 512 x 128 tile families and the 4096-token mid-block attention are what is being compared."""
+    state, cfg, vae = vae512
+    z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5)).half().float()
+    out = vae.decode(z.to(DEV), return_dict=False)[0]
+    assert tuple(out.shape) == (1, 3, 512, 512)
+    rel, cos = _metrics(out, so.vae_decode_ref(state, z, cfg))
+    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+
+
+def test_encoder_512_matches_fp32_reference(vae512):
+    state, cfg, vae = vae512
+    img = (torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(6)) * 2 - 1).half().float()
+    mode = vae.encode(img.to(DEV)).latent_dist.mode()
+    ref = so.vae_encode_ref(state, img, cfg)
+    rel, cos = _metrics(mode, ref[:, :4])
+    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
