@@ -38,6 +38,7 @@ SIGNATURES = {
     # include/sd_hip.h
     "sd_conv_gemm_f16": (_i, [_vp, _vp]),
     "sd_conv_gemm_workspace_bytes": (C.c_size_t, []),
+    "sd_debug_timestamps": (_i, [_vp, _i]),
     "sd_groupnorm_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "sd_groupnorm_colstats_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sd_layernorm_f16": (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp]),

@@ -16,9 +16,10 @@
 // (`buffer_load_dwordx4 ... offen lds`) into unpadded XOR-swizzled rows, 2-4 stages with counted vmcnt waits and one raw
 // s_barrier per K tile; zero padding is the buffer range check.  The epilogue fuses bias, per-(batch) bias (time
 // embedding), residual add, SiLU, GEGLU (value/gate columns interleaved per wave at weight-prep time) and, on request,
-// per-64-row column sums / sums of squares of the stored tensor (the consumer's GroupNorm statistics).
+// per-32-row column sums / sums of squares of the stored tensor (the consumer's GroupNorm statistics).
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -34,6 +35,11 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int BKMIN = 32;   // source channel counts must be multiples of this (and of 64 for the deep-K variant)
+
+// Tuning aid (SD_GEMM_DBG=1): blocks 0..DBG_BLOCKS-1 record s_memtime at kernel entry, first tile landed, end of the K loop and
+// end of the epilogue; read back with sd_debug_timestamps().
+constexpr int DBG_BLOCKS = 4096;
+__device__ unsigned long long g_dbg_stamps[DBG_BLOCKS * 4];
 
 struct GemmArgs {
   const _Float16* a0;
@@ -52,11 +58,16 @@ struct GemmArgs {
   _Float16* out;
   int ldo;
   int epi;
-  float* colstats;            // optional [M/64][2][N] fp32: per 64-row block column sums / sums of squares of the OUTPUT
+  float* colstats;            // optional [M/32][2][N] fp32: per 32-row block column sums / sums of squares of the OUTPUT
   int ksplit;                 // >1: blockIdx.z selects a K range and fp32 partials go to `partial`
   float* partial;             // [ksplit][M][N] fp32
   long long sa, sw, so, sr;   // per-blockIdx.z strides in elements (batched mode, ksplit == 1)
+  unsigned long long* dbg;    // nullptr unless SD_GEMM_DBG is set
 };
+
+__device__ __forceinline__ void dbg_stamp(const GemmArgs& g, int slot) {
+  if (g.dbg && blockIdx.y == 0 && blockIdx.x < DBG_BLOCKS && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + slot] = __builtin_readcyclecounter();
+}
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 // x * Phi(x) = 0.5 x erfc(-x / sqrt 2) with erfc from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, relative in the
@@ -99,6 +110,286 @@ __device__ __forceinline__ int swz(int row, int chunk) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Epilogue shared by every kernel of the family: acc[2][TN] (MFMA C layout, see below) -> bias / per-sample bias / SiLU /
+// residual / GEGLU / GroupNorm column statistics -> fp16 output (or fp32 split-K slab), staged through LDS per wave.
+template <int WM, int WN, int TN, int TM>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)[TM][TN], _Float16* lds, const int m0, const int n0,
+                                              const int wave, const int lane, const long long z, const bool split) {
+  constexpr int EP_STRIDE = 32 + 4;                 // floats per staged row (one 32x32 MFMA tile per wave at a time)
+  const int wr = wave / WN, wc = wave % WN;
+  // ---------------------------------------------------------------- epilogue
+  // The MFMAs were issued as D = W_frag . A_frag^T, so a lane owns ONE output row m = (lane & 31) of each 32-row
+  // tile and its 16 registers run along output columns n = 8*(r>>2) + 4*(lane>>5) + (r&3): four consecutive
+  // registers are four consecutive columns.  Each wave stages one 32 x 32 fp32 MFMA tile at a time in LDS (16-byte
+  // writes) and re-reads it row-major so that bias / residual / output move as coalesced 16-byte vectors.
+  wait_vmcnt<0>();
+  __syncthreads();                              // every wave is done with the operand tiles (all DMA drained)
+  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
+  const int lrow = lane & 31, hh = lane >> 5;
+  if (split) {
+    float* part = g.partial + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = m0 + wr * (TM * 32) + i * 32 + lrow;
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = n0 + wc * (TN * 32) + j * 32 + 8 * q + 4 * hh;
+          if (col < g.N)   // N % 8 == 0 on this path
+            *reinterpret_cast<float4*>(part + (long long)row * g.N + col) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+    }
+    return;
+  }
+  _Float16* outp = g.out + z * g.so;
+  const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
+  const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
+  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS) &&
+                      (!g.bias_bn || (g.rows_per_batch % 32 == 0 && g.ldbb % 8 == 0));
+  // read-back role: 32 rows x 4 chunks of 8 columns = 128 items, two per lane; the column chunk is fixed per lane
+  const int cl = (lane & 3) * 8;
+  if (geglu) {
+    if constexpr (TN % 2 == 0) {
+      // tile pairs (2p, 2p+1) = (32 value columns, their 32 gate columns): weight rows interleaved at prep time
+#pragma unroll
+      for (int p = 0; p < TN / 2; ++p) {
+        const int ncol0 = n0 + wc * (TN * 32) + p * 64;        // permuted value columns [ncol0, +32), gates [+32, +64)
+        const int ocol0 = (ncol0 >> 1);
+        float bv[4][4], bg[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = ncol0 + 8 * q + 4 * hh + e;
+            bv[q][e] = g.bias ? (float)g.bias[c] : 0.0f;
+            bg[q][e] = g.bias ? (float)g.bias[c + 32] : 0.0f;
+          }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mbase = m0 + wr * (TM * 32) + i * 32;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              o[e] = (acc[i][2 * p][4 * q + e] + bv[q][e]) * gelu_erf(acc[i][2 * p + 1][4 * q + e] + bg[q][e]);
+            *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int rl = (lane + 64 * k) >> 2;
+            const int row = mbase + rl;
+            const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
+            const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
+            half8 o = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w, (_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
+            if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocol0 + cl) = o;
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+      }
+    }
+    return;
+  }
+  // Residual / per-sample-bias tiles are fetched DEPTH tiles ahead of their use: with one tile in flight per wave the
+  // epilogue was latency-bound (16 loads in flight per CU; measured 34 k cycles for a 256 x 320 tile -- longer than a
+  // K = 320 main loop); DEPTH tiles ahead it moves at the HBM rate.  All of it goes through buffer descriptors: one
+  // 32-bit row offset per lane for the whole epilogue, the tile position in the scalar offset, rows >= M dropped by the
+  // range check -- no 64-bit address arithmetic and few live registers next to the 32 * TN accumulators.
+  constexpr int NT = TM * TN;                           // 32 x 32 tiles of this wave, j-major (column tile), i-minor
+  constexpr int DEPTH = NT <= 4 ? NT : (TN >= 5 ? 2 : 4);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  auto rsrc_of = [](const void* p, long long bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
+  };
+  const bool fast = vec_ok && (long long)(g.M + 512) * g.ldo * 2 < 0x7fffffffLL &&
+                    (!resp || (long long)(g.M + 512) * g.ldr * 2 < 0x7fffffffLL) && !(g.bias_bn && resp);
+  if (fast) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t out_rsrc = rsrc_of(outp, (long long)g.M * g.ldo * 2);
+    const __amdgpu_buffer_rsrc_t pre_rsrc = resp ? rsrc_of(resp, (long long)g.M * g.ldr * 2)
+                                                 : rsrc_of(g.bias_bn ? g.bias_bn : g.out, g.bias_bn ? 0x7fffffffLL : 0);
+    const int colbase = n0 + wc * (TN * 32) + cl;
+    const int rowbase = m0 + wr * (TM * 32) + (lane >> 2);              // + 16 k + 32 i
+    const int ld_pre = resp ? g.ldr : 0;
+    int voff_out[2], voff_pre[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      voff_out[k] = ((rowbase + 16 * k) * g.ldo + colbase) * 2;
+      voff_pre[k] = ((rowbase + 16 * k) * ld_pre + colbase) * 2;
+    }
+    u32x4 pf[NT][2];                                             // residual rows (k = 0, 1) or, in [0], the per-sample bias
+    auto prefetch = [&](const int t) {
+      const int j = t / TM, i = t % TM;
+      if (resp) {
+        const int soff = __builtin_amdgcn_readfirstlane((i * 32 * g.ldr + j * 32) * 2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) pf[t][k] = __builtin_amdgcn_raw_buffer_load_b128(pre_rsrc, voff_pre[k], soff, 0);
+      } else if (g.bias_bn) {
+        const int mb = min(m0 + wr * (TM * 32) + i * 32, g.M - 1);
+        const int soff = __builtin_amdgcn_readfirstlane(((mb / g.rows_per_batch) * g.ldbb + j * 32) * 2);
+        pf[t][0] = __builtin_amdgcn_raw_buffer_load_b128(pre_rsrc, voff_pre[0], soff, 0);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t) prefetch(t);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      half8 bcol = {0, 0, 0, 0, 0, 0, 0, 0};                        // kept packed: registers are scarce next to 32 * TN accumulators
+      const bool oob = colbase + j * 32 + 8 > g.N;                // column chunk of this lane beyond N: loads give 0, stores are dropped
+      if (g.bias && !oob) bcol = *reinterpret_cast<const half8*>(g.bias + colbase + j * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int t = TM * j + i;
+        if (t + DEPTH < NT) prefetch(t + DEPTH);
+        float cs[8], cq[8];        // GroupNorm statistics of the consumer: column sums over the 32 rows of this tile
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) =
+              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int soff_out = __builtin_amdgcn_readfirstlane((i * 32 * g.ldo + j * 32) * 2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int rl = (lane + 64 * k) >> 2;
+          const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
+          const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
+          float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)bcol[e];
+          if (g.bias_bn) {
+            const half8 tb = __builtin_bit_cast(half8, pf[t][0]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)tb[e];
+          }
+          if (g.epi & SD_EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+          }
+          if (resp) {
+            const half8 r8 = __builtin_bit_cast(half8, pf[t][k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+          }
+          half8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rsrc, oob ? (int)0x80000000 : voff_out[k], soff_out, 0);
+          if (g.colstats && !oob && m0 + wr * (TM * 32) + i * 32 + rl < g.M) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)o[e];     // statistics of the stored (fp16-rounded) tensor, as a GroupNorm pass would see it
+              cs[e] += f;
+              cq[e] += f * f;
+            }
+          }
+        }
+        if (g.colstats) {
+          // fold the 16 lanes that share a column chunk (lane & 3 fixed), fixed order -> reproducible: lanes +4, +8, +12 of
+          // the 16-lane row by two DPP row rotations (VALU speed), then the four rows by two cross-lane exchanges
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            cs[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs[e]), 0x128, 0xf, 0xf, false));
+            cq[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cq[e]), 0x128, 0xf, 0xf, false));
+            cs[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs[e]), 0x124, 0xf, 0xf, false));
+            cq[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cq[e]), 0x124, 0xf, 0xf, false));
+          }
+#pragma unroll
+          for (int mask = 16; mask < 64; mask <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              cs[e] += __shfl_xor(cs[e], mask);
+              cq[e] += __shfl_xor(cq[e], mask);
+            }
+          if (lane < 4 && !oob) {
+            float* dst = g.colstats + (long long)((m0 + wr * (TM * 32) + i * 32) >> 5) * 2 * g.N + colbase + j * 32;
+            *reinterpret_cast<float4*>(dst) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+            *reinterpret_cast<float4*>(dst + g.N) = make_float4(cq[0], cq[1], cq[2], cq[3]);
+            *reinterpret_cast<float4*>(dst + g.N + 4) = make_float4(cq[4], cq[5], cq[6], cq[7]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+#endif
+    return;
+  }
+  // generic path (ragged N, unaligned leading dimensions, row bias, both a residual and a per-sample bias): one tile at a time
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wc * (TN * 32) + j * 32 + cl;
+    const bool col_ok = col + 8 <= g.N;
+    float bcol[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bcol[e] = 0.0f;
+    if (vec_ok && col_ok && g.bias) {
+      const half8 bvv = *reinterpret_cast<const half8*>(g.bias + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bcol[e] = (float)bvv[e];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mbase = m0 + wr * (TM * 32) + i * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int rl = (lane + 64 * k) >> 2;
+        const int row = mbase + rl;
+        const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
+        const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
+        float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        if (row >= g.M) continue;
+        if (vec_ok && col_ok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bcol[e];
+          if (g.bias_bn) {
+            const half8 tb = *reinterpret_cast<const half8*>(g.bias_bn + (long long)(mbase / g.rows_per_batch) * g.ldbb + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)tb[e];
+          }
+          if (g.epi & SD_EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
+          }
+          if (resp) {
+            const half8 r8 = *reinterpret_cast<const half8*>(resp + (long long)row * g.ldr + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+          }
+          half8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+          *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
+        } else {
+          for (int e = 0; e < 8; ++e)
+            if (col + e < g.N)
+              outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 // STAGES-deep LDS-DMA pipeline: tiles kt+1 .. kt+STAGES-1 are in flight while tile kt is multiplied.
 // Block = WM x WN waves; a wave owns 64 rows x (TN * 32) columns = 2 x TN MFMA tiles.  Instantiations:
 //   <WM=2, WN=2, TN=2, BK=64, ST=2>  128 x 128, 64 KiB, 2 blocks/CU : generic deep-K (and GEGLU, which needs TN even)
@@ -108,10 +399,10 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 //        cycles per wave instruction and NOT overlapped with MFMA issue, the limiter of the 128 x 128 tile (0.5 DMA per
 //        MFMA) -- drops to 0.225 DMA per MFMA.
 //   <WM=2, WN=1/2, ...> 64-wide fallbacks for small N.
-template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false>
+template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false, int TM = 2>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per block
-  constexpr int BM_ = WM * 64, BN = WN * TN * 32;
+  constexpr int BM_ = WM * TM * 32, BN = WN * TN * 32;
   constexpr int CPR = BK / 8;                       // 16-byte chunks per tile row
   constexpr int RPI = 64 / CPR;                     // tile rows written by one wave-wide DMA instruction
   static_assert((BM_ / RPI) % NW == 0 && (BN / RPI) % NW == 0, "DMA instructions must divide evenly over the waves");
@@ -125,6 +416,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   _Float16* const As0 = lds;
   _Float16* const Bs0 = lds + STAGES * BM_ * BK;
 
+  dbg_stamp(g, 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -267,9 +559,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     advance_tile();
   };
 
-  float16v acc[2][TN];
+  float16v acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -277,9 +569,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
 
   // fragment addressing: row = base + (lane & 31), K-chunk = 2*ks + (lane >> 5), slot = chunk ^ swizzle(row)
   const int frow = lane & 31, fhalf = lane >> 5;
-  int a_fr[2], b_fr[TN];
+  int a_fr[TM], b_fr[TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) a_fr[i] = wr * 64 + i * 32 + frow;
+  for (int i = 0; i < TM; ++i) a_fr[i] = wr * (TM * 32) + i * 32 + frow;
 #pragma unroll
   for (int j = 0; j < TN; ++j) b_fr[j] = wc * (TN * 32) + j * 32 + frow;
 
@@ -300,6 +592,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
       if (younger >= 2) wait_vmcnt<2 * LPT>(); else if (younger == 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) dbg_stamp(g, 1);
     // every wave has finished reading the stage that tile kt+STAGES-1 overwrites (it held tile kt-1)
     const int nbuf = (kt + STAGES - 1) % STAGES;
     if constexpr (NEXT && !SPREAD) issue_tile(nbuf);
@@ -308,9 +601,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
       ([&] {
         constexpr int ks = KSI;
-        half8 af[2], bf[TN];
+        half8 af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
           af[i] = *reinterpret_cast<const half8*>(Ab + a_fr[i] * BK + swz<BK>(a_fr[i], 2 * ks + fhalf) * 8);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -318,7 +611,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
         if constexpr (NEXT && SPREAD)      // this K step's share of the next tile's DMA, between its LDS reads and MFMAs
           issue_range(nbuf, std::integral_constant<int, ks * LPT / KS>{}, std::integral_constant<int, (ks + 1) * LPT / KS>{});
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
@@ -331,188 +624,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     for (; kt + STAGES - 1 < nk; ++kt) k_tile(kt, std::true_type{});
     for (; kt < nk; ++kt) k_tile(kt, std::false_type{});
   }
+  dbg_stamp(g, 2);
 
-  // ---------------------------------------------------------------- epilogue
-  // The MFMAs were issued as D = W_frag . A_frag^T, so a lane owns ONE output row m = (lane & 31) of each 32-row
-  // tile and its 16 registers run along output columns n = 8*(r>>2) + 4*(lane>>5) + (r&3): four consecutive
-  // registers are four consecutive columns.  Each wave stages one 32 x 32 fp32 MFMA tile at a time in LDS (16-byte
-  // writes) and re-reads it row-major so that bias / residual / output move as coalesced 16-byte vectors.
-  wait_vmcnt<0>();
-  __syncthreads();                              // every wave is done with the operand tiles (all DMA drained)
-  float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
-  const int lrow = lane & 31, hh = lane >> 5;
-  if (split) {
-    float* part = g.partial + (long long)blockIdx.y * g.M * g.N;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = m0 + wr * 64 + i * 32 + lrow;
-      if (row >= g.M) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col = n0 + wc * (TN * 32) + j * 32 + 8 * q + 4 * hh;
-          if (col < g.N)   // N % 8 == 0 on this path
-            *reinterpret_cast<float4*>(part + (long long)row * g.N + col) =
-                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-        }
-    }
-    return;
-  }
-  _Float16* outp = g.out + z * g.so;
-  const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
-  const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
-  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS) &&
-                      (!g.bias_bn || (g.rows_per_batch % 32 == 0 && g.ldbb % 8 == 0));
-  // read-back role: 32 rows x 4 chunks of 8 columns = 128 items, two per lane; the column chunk is fixed per lane
-  const int cl = (lane & 3) * 8;
-  if (geglu) {
-    if constexpr (TN % 2 == 0) {
-      // tile pairs (2p, 2p+1) = (32 value columns, their 32 gate columns): weight rows interleaved at prep time
-#pragma unroll
-      for (int p = 0; p < TN / 2; ++p) {
-        const int ncol0 = n0 + wc * (TN * 32) + p * 64;        // permuted value columns [ncol0, +32), gates [+32, +64)
-        const int ocol0 = (ncol0 >> 1);
-        float bv[4][4], bg[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = ncol0 + 8 * q + 4 * hh + e;
-            bv[q][e] = g.bias ? (float)g.bias[c] : 0.0f;
-            bg[q][e] = g.bias ? (float)g.bias[c + 32] : 0.0f;
-          }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int mbase = m0 + wr * 64 + i * 32;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              o[e] = (acc[i][2 * p][4 * q + e] + bv[q][e]) * gelu_erf(acc[i][2 * p + 1][4 * q + e] + bg[q][e]);
-            *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
-          }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int rl = (lane + 64 * k) >> 2;
-            const int row = mbase + rl;
-            const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
-            const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
-            half8 o = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w, (_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
-            if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocol0 + cl) = o;
-          }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wc * (TN * 32) + j * 32 + cl;
-    const bool col_ok = col + 8 <= g.N;
-    float cs[8], cq[8];          // GroupNorm statistics of the consumer: column sums over this wave's 64 rows
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
-    float bcol[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bcol[e] = 0.0f;
-    if (vec_ok && col_ok && g.bias) {
-      const half8 bvv = *reinterpret_cast<const half8*>(g.bias + col);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bcol[e] = (float)bvv[e];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int mbase = m0 + wr * 64 + i * 32;
-      // issue the residual / per-sample-bias loads of this tile first: they fly while the tile goes through LDS
-      half8 rv[2], tb;
-      bool have_tb = false;
-      if (vec_ok && col_ok) {
-        if (g.bias_bn && mbase < g.M) {
-          tb = *reinterpret_cast<const half8*>(g.bias_bn + (long long)(mbase / g.rows_per_batch) * g.ldbb + col);
-          have_tb = true;
-        }
-        if (resp) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int row = mbase + ((lane + 64 * k) >> 2);
-            if (row < g.M) rv[k] = *reinterpret_cast<const half8*>(resp + (long long)row * g.ldr + col);
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) =
-            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int rl = (lane + 64 * k) >> 2;
-        const int row = mbase + rl;
-        const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
-        const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
-        float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-        if (row >= g.M) continue;
-        if (vec_ok && col_ok) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bcol[e];
-          if (have_tb) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)tb[e];
-          }
-          if (g.epi & SD_EPI_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu(v[e]);
-          }
-          if (resp) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rv[k][e];
-          }
-          half8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-          *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
-          if (g.colstats) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float f = (float)o[e];     // statistics of the stored (fp16-rounded) tensor, as a GroupNorm pass would see it
-              cs[e] += f;
-              cq[e] += f * f;
-            }
-          }
-        } else {
-          for (int e = 0; e < 8; ++e)
-            if (col + e < g.N)
-              outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp);
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if (g.colstats) {
-      // fold the 16 lanes that share a column chunk (lane & 3 fixed): fixed butterfly order -> reproducible
-#pragma unroll
-      for (int mask = 4; mask < 64; mask <<= 1)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          cs[e] += __shfl_xor(cs[e], mask);
-          cq[e] += __shfl_xor(cq[e], mask);
-        }
-      if (lane < 4 && col_ok) {
-        float* dst = g.colstats + (long long)((m0 >> 6) + wr) * 2 * g.N + col;
-        *reinterpret_cast<float4*>(dst) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
-        *reinterpret_cast<float4*>(dst + g.N) = make_float4(cq[0], cq[1], cq[2], cq[3]);
-        *reinterpret_cast<float4*>(dst + g.N + 4) = make_float4(cq[4], cq[5], cq[6], cq[7]);
-      }
-    }
-  }
+  gemm_epilogue<WM, WN, TN, TM>(g, acc, lds, m0, n0, wave, lane, z, split);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  dbg_stamp(g, 3);
 }
 
 // sum the split-K slabs in a fixed order and apply the epilogue (8 columns per thread)
@@ -541,6 +657,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 using namespace sd;
 
 extern "C" size_t sd_conv_gemm_workspace_bytes(void) { return (size_t)64 << 20; }
+
+extern "C" int sd_debug_timestamps(unsigned long long* host_dst, int n_blocks) {
+  if (!host_dst || n_blocks <= 0 || n_blocks > DBG_BLOCKS) return fail(COMA_E_INVALID, "sd_debug_timestamps: bad arguments");
+  if (hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_dbg_stamps), (size_t)n_blocks * 4 * sizeof(unsigned long long)) != hipSuccess)
+    return fail(COMA_E_LAUNCH, "sd_debug_timestamps: copy failed");
+  return COMA_OK;
+}
 
 extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (!d) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
@@ -582,7 +705,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const bool k64 = d->c0 % 64 == 0 && d->c1 % 64 == 0;
   const bool deep = g.K >= 2048 && k64;
   // 256 x 320 tile: N a multiple of 320 (every layer of the SD UNet), enough rows to fill the chip with 1 block / CU
-  const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && g.M >= 256 * 128 && !(d->epi & ((1 << 20) | (1 << 21)));
+  const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && (long long)((g.M + 255) / 256) * (d->n / 320) >= 192 && !(d->epi & ((1 << 20) | (1 << 21)));
   // GEGLU (needs an even number of MFMA column tiles per wave): 256 x 256, 8 waves, wave tile 64 x 128
   const bool big_geglu = geglu && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 16 && !(d->epi & (1 << 20));
   // VAE widths (128 / 256 / 512 channels at up to 512 x 512 pixels): 256 x 256 and 256 x 128 tiles, 8 waves
@@ -594,18 +717,26 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   // 128 x 320, 4 waves (wave tile 64 x 160): mid-size M where 256-row tiles would leave CUs idle
   const bool mid = !big && !big256 && !big128 && !geglu && nz == 1 && d->n % 320 == 0 && g.M >= 128 * 64 &&
                    (d->n <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20));
+  // 128 x 320 with EIGHT waves (wave tile 32 x 160, two waves per SIMD) instead of four: the partner wave covers each
+  // wave's LDS-read / DMA-issue latency, which the 4-wave tile leaves exposed (knob 23 selects the 4-wave form)
+  const bool mid8 = mid && k64 && g.K >= 256 && !(d->epi & (1 << 23));
   const bool wide = d->n % 128 == 0 || d->n > 256;
   const int bm = tall128 ? 512 : ((big || big_geglu || big256 || big128) ? 256 : 128);
   const int bn = (big || mid) ? 320 : ((big_geglu || big256) ? 256 : ((wide || big128) ? 128 : 64));
-  const int bk = (mid || tall128) ? 32 : ((big || big_geglu || big256 || big128 || deep) ? 64 : 32);
+  const int bk = ((mid && !mid8) || tall128) ? 32 : ((big || big_geglu || big256 || big128 || deep || mid8) ? 64 : 32);
   const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((d->n + bn - 1) / bn);
   // split-K when the tile grid cannot fill the chip: as many splits as keep every block resident at once (2 per CU,
   // 512 in total -- a partial second round costs more than it buys), at least 384 of K per split
   g.ksplit = 1;
+  static const bool dbg_on = getenv("SD_GEMM_DBG") != nullptr;
+  g.dbg = nullptr;
+  if (dbg_on) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dbg_stamps)) == hipSuccess) g.dbg = (unsigned long long*)p; }
   g.partial = (float*)d->workspace;
   g.colstats = (float*)d->colstats;
-  if (g.colstats && (geglu || nz != 1 || g.M % 64 || d->n % 8 || (d->epi & SD_EPI_BIAS_ROWS)))
-    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: colstats needs M %% 64 == 0, N %% 8 == 0, no GEGLU / batching");
+  if (g.colstats && (geglu || nz != 1 || g.M % 32 || d->n % 8 || (d->epi & SD_EPI_BIAS_ROWS) || g.ldo % 8 || (g.res && g.ldr % 8) ||
+                     (g.bias_bn && (g.res || g.rows_per_batch % 32 || g.ldbb % 8)) || (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL ||
+                     (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
+    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: colstats needs M %% 32 == 0, N %% 8 == 0, 16-byte aligned rows, < 2 GiB tensors, no GEGLU / batching");
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
@@ -630,7 +761,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   else if (big_geglu || big256) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
   else if (tall128) hipLaunchKernelGGL((conv_gemm_kernel<8, 1, 4, 32, 3>), grid, dim3(512), 0, st, g);
   else if (big128) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 2, 64, 2>), grid, dim3(512), 0, st, g);
-  else if (mid && (d->epi & (1 << 23))) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 2>), grid, dim3(256), 0, st, g);
+  else if (mid8) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2, true, 1>), grid, dim3(512), 0, st, g);
   else if (mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 3>), grid, dim3(256), 0, st, g);
   else if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2>), grid, dim3(256), 0, st, g);
   else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 32, 4>), grid, dim3(256), 0, st, g);

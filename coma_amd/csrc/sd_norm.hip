@@ -127,14 +127,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   gn_write_affine(s, q, count, eps, b, g, C / groups, C, gamma, beta, affine, lane);
 }
 
-// the same from per-64-row-block column sums [rb][2][C] of one or two producers: one 256-thread block per (b, g),
+// the same from per-32-row-block column sums [rb][2][C] of one or two producers: one 256-thread block per (b, g),
 // thread t owns channel (t % cg) of the group and every (256 / cg)-th row block; LDS fold in a fixed order
 __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* __restrict__ cs0, const float* __restrict__ cs1,
                                                                   int c0, int c1, int hw, int groups, float eps,
                                                                   const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
                                                                   float* __restrict__ affine) {
   __shared__ float rs[256], rq[256];
-  const int C = c0 + c1, cg = C / groups, rbs = hw / 64;
+  const int C = c0 + c1, cg = C / groups, rbs = hw / 32;
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int per = 256 / cg;                       // row-block lanes (cg <= 80 in every SD layer)
   const int tc = threadIdx.x % cg, tr = threadIdx.x / cg;
@@ -377,7 +377,7 @@ extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0,
   if (!x0 || !gamma || !beta || !out || !stats || !colstats0) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: null pointer");
   if (c1 > 0 && (!x1 || !colstats1)) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: second source incomplete");
   const int C = c0 + c1;
-  if (batch <= 0 || hw <= 0 || hw % 64 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || c1 % 8)
+  if (batch <= 0 || hw <= 0 || hw % 32 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || c1 % 8)
     return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: bad shape C=%d groups=%d hw=%d", C, groups, hw);
   hipStream_t s = (hipStream_t)stream;
   const int total = batch * groups;

@@ -22,7 +22,7 @@ class LaunchGraph:
         self._graph = None
         self._gn_stats = None
         self._ws = None             # split-K workspace shared by every GEMM of the graph (launches are serial)
-        self._colstats = {}         # data_ptr of a GEMM output -> its [M/64][2][N] column-sum buffer (GroupNorm statistics)
+        self._colstats = {}         # data_ptr of a GEMM output -> its [M/32][2][N] column-sum buffer (GroupNorm statistics)
         self.fuse_gn_stats = True
 
     # ---- memory
@@ -50,8 +50,8 @@ class LaunchGraph:
         kw.setdefault("workspace", self._ws)
         # GroupNorm statistics of the consumer come for free from the epilogue of large, never-split GEMMs
         M = batch * oh * ow
-        if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= 16384 and M % 64 == 0:
-            cs = torch.zeros(M // 64, 2, n, dtype=torch.float32, device=self.device)
+        if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= 16384 and M % 32 == 0:
+            cs = torch.zeros(M // 32, 2, n, dtype=torch.float32, device=self.device)
             kw["colstats"] = cs
             self._colstats[out.data_ptr()] = cs
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
@@ -75,7 +75,7 @@ class LaunchGraph:
         stats = self.gn_scratch(batch, hw)
         cs0 = self._colstats.get(x0.data_ptr())
         cs1 = self._colstats.get(x1.data_ptr()) if x1 is not None else None
-        if cs0 is not None and (x1 is None or cs1 is not None) and hw % 64 == 0:
+        if cs0 is not None and (x1 is None or cs1 is not None) and hw % 32 == 0:
             self.add(lambda: ops.groupnorm_colstats(x0, gamma, beta, out, stats, cs0, batch=batch, hw=hw, c0=c0, x1=x1, c1=c1,
                                                     colstats1=cs1, eps=eps, silu=silu),
                      tag=f"groupnorm(colstats) B={batch} hw={hw} C={c0 + c1}")

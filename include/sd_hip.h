@@ -29,7 +29,7 @@ extern "C" {
 #define SD_EPI_SILU 2       /* out = silu(acc + bias) */
 #define SD_EPI_BIAS_ROWS 4  /* bias indexed by output row instead of column (A = weights, W = activations) */
 /* bits 20..27 select kernel variants for tuning runs (scripts/time_gemm.py): 20 = generic 128x128 tiles only, 21 = 128x320
- * tile, 22 = tile DMA in one burst, 23 = 2-stage 128x320, 24..27 = forced split-K factor.  Results are identical. */
+ * tile, 22 = tile DMA in one burst, 23 = 4-wave 128x320 tile, 24..27 = forced split-K factor.  Results are identical. */
 #define SD_EPI_TUNING_MASK 0x0ff00000
 
 /* out[m, n] = sum_k A[m, k] * W[n, k] (+ epilogue) with A gathered from one or two NHWC sources:
@@ -60,12 +60,16 @@ typedef struct sd_conv_gemm_desc {
   int64_t stride_a, stride_w, stride_out, stride_res;
   void* workspace;      /* optional fp32 scratch for split-K (small M*N, deep K); NULL disables split-K */
   size_t workspace_bytes;
-  float* colstats;      /* optional fp32 [M/64][2][n]: per 64-row block, column sums and sums of squares of the stored output
-                           (the GroupNorm statistics of the consumer, sd_groupnorm_f16 colstats0/1); needs M % 64 == 0 */
+  float* colstats;      /* optional fp32 [M/32][2][n]: per 32-row block, column sums and sums of squares of the stored output
+                           (the GroupNorm statistics of the consumer, sd_groupnorm_colstats_f16 colstats0/1); needs M % 32 == 0 */
 } sd_conv_gemm_desc;
 
 int sd_conv_gemm_f16(const sd_conv_gemm_desc* desc, void* stream);
 size_t sd_conv_gemm_workspace_bytes(void); /* recommended workspace size */
+/* Tuning aid: with SD_GEMM_DBG set in the environment, the first 4096 workgroups of every sd_conv_gemm_f16 launch record the
+ * shader clock at {entry, first K tile landed, end of the K loop, end of the epilogue}; this copies [n_blocks][4] u64 stamps of the
+ * most recent launch to the host (synchronises the device). */
+int sd_debug_timestamps(unsigned long long* host_dst, int n_blocks);
 
 /* GroupNorm (+ optional SiLU) over NHWC fp16, reading the channel concatenation of two sources and writing one
  * tensor [batch, hw, c0+c1].  replaces: nn.GroupNorm(groups, C, eps) + nn.SiLU in diffusers ResnetBlock2D /
@@ -74,7 +78,7 @@ size_t sd_conv_gemm_workspace_bytes(void); /* recommended workspace size */
 int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                      const void* gamma, const void* beta, int silu, void* out, float* stats, void* stream);
 /* Same, but the statistics come from the column sums the producing GEMMs left behind (sd_conv_gemm_desc.colstats of x0
- * and, with two sources, of x1): no statistics pass over the tensor.  hw % 64 == 0. */
+ * and, with two sources, of x1): no statistics pass over the tensor.  hw % 32 == 0. */
 int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                               const void* gamma, const void* beta, int silu, void* out, float* stats, const float* colstats0,
                               const float* colstats1, void* stream);

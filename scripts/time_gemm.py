@@ -41,6 +41,9 @@ if os.environ.get("OVH"):
     SHAPES_OVERRIDE = [(16384, 640, 64, 1, None), (16384, 640, 320, 1, None), (16384, 640, 640, 1, None), (16384, 640, 1280, 1, None),
                        (4096, 1280, 64, 1, None), (4096, 1280, 640, 1, None), (4096, 1280, 1280, 1, None), (4096, 1280, 2560, 1, None),
                        (65536, 320, 64, 1, None), (65536, 320, 320, 1, None)]
+if os.environ.get("ONLY"):
+    SHAPES_OVERRIDE = [(65536, 640, 5760, 9, 4096), (65536, 320, 2880, 9, 4096), (65536, 320, 1280, 1, None)]
+    pass
 if os.environ.get("VAE"):
     SHAPES_OVERRIDE = [(2097152, 128, 1152, 9, 262144), (2097152, 128, 2304, 9, 262144), (524288, 256, 2304, 9, 65536),
                        (131072, 512, 4608, 9, 16384), (2097152, 64, 1152, 9, 262144)]
@@ -48,9 +51,9 @@ SHAPES = [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 
           (16384, 640, 640, 1, None), (16384, 640, 5760, 9, 1024), (16384, 1280, 11520, 9, 1024),
           (4096, 1280, 1280, 1, None), (4096, 1280, 5120, 1, None), (4096, 1280, 11520, 9, 256), (4096, 1280, 23040, 9, 256),
           (1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64)]
-GEGLU = [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)]
+GEGLU = [] if os.environ.get("ONLY") else [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)]
 knobs = [0] + [sum(1 << int(b) for b in a.split("+")) for a in sys.argv[1:]]
-for (M, N, K, taps, hw) in (SHAPES_OVERRIDE if (os.environ.get('SMALL') or os.environ.get('VAE') or os.environ.get('OVH')) else SHAPES):
+for (M, N, K, taps, hw) in (SHAPES_OVERRIDE if (os.environ.get('SMALL') or os.environ.get('VAE') or os.environ.get('OVH') or os.environ.get('ONLY')) else SHAPES):
     row = []
     for epi in knobs:
         ms, tf = bench(M, N, K, taps=taps, epi=epi, hw=hw, res=not os.environ.get('NORES'))
