@@ -34,6 +34,8 @@ SIGNATURES = {
     "coma_occupancy_splat": (_i, [_vp, _i, _i, _i, _vp, _d, _d, _vp, _vp]),
     "coma_occupancy_reduce": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "coma_nearest_vertex_i64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "coma_dlt_score_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "coma_ransac_mse_f64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
     "coma_vertex_normals_f64": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp]),
     # include/sd_hip.h
     "sd_conv_gemm_f16": (_i, [_vp, _vp]),

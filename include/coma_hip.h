@@ -127,6 +127,21 @@ int coma_occupancy_reduce(float* counts, const uint8_t* select, int H, int64_t R
 int coma_nearest_vertex_i64(const double* points, const double* verts, int P, int V, int64_t* idx,
                             void* stream);
 
+/* Two-view DLT triangulation + candidate scoring.
+ * replaces: src/generation/optimize_depth.py:202-237 (solve_DLT) and :291-295 (reprojection MSE in both views).
+ * views f64 [n_views][28]: per camera {rot[9], trans[3]} of get_projection_matrix (:164-183), {mr[9] = R C, tmr[3] = t R C} of
+ * get_view2joints_render (:185-200), scale, max(resolution), resolution/2 (x, y) -- built on the host with the reference's own
+ * expressions.  ref_xy f64 [J,2] pixel joints of the reference view; cand_view i32 [P], cand_xy f64 [P,J,2] ->
+ * tri f64 [P,J,3], ref_mse / other_mse f64 [P].  <= 1e-9 relative against np.linalg.pinv on well-conditioned pairs. */
+int coma_dlt_score_f64(const double* views, int n_views, int ref_view, const double* ref_xy, const int* cand_view,
+                       const double* cand_xy, int P, int J, double* tri, double* ref_mse, double* other_mse, void* stream);
+
+/* RANSAC reprojection matrix over the selected candidates sel i32 [C] (indices into the P candidates above):
+ * mse[a][b] = mean_j |xy_b[j] - render_{view(b)}(tri_a[j])|^2, counts[a] = #{b : mse[a][b] < threshold}.
+ * replaces: src/generation/optimize_depth.py:329-350 (the candidates^2 loop). */
+int coma_ransac_mse_f64(const double* views, const double* tri, const int* cand_view, const double* cand_xy, const int* sel,
+                        int C, int J, double threshold, double* mse, int* counts, void* stream);
+
 /* Sample ingestion: area-weighted vertex normals of S posed meshes with one shared topology.
  * replaces: open3d TriangleMesh.compute_vertex_normals() + normalize_vectors_np in
  *           prepare_affordance_extraction_inputs (utils/coma.py:672-686).
