@@ -261,27 +261,39 @@ def bench_occupancy(args, dev, world, rank):
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     q = (torch.rand([S, H, 3], generator=g, device=dev) * 2.6 - 1.3).contiguous()      # ~21 % of the points fall outside the grid
     occ.accumulate_device(q[:8])
+    occ.return_aggregated_spatial_grids()                # warm-up of the fused pass
     torch.cuda.synchronize()
-    occ.spatial_occupancy_grids.zero_()
-    a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    occ.reset()
+    a, b = (torch.cuda.Event(enable_timing=True) for _ in range(2))
     a.record()
-    occ.accumulate_device(q)
-    b.record()
+    occ.accumulate_device(q)                             # staged only: the reducer below runs splat + row sums + max as one pass
     out = occ.return_aggregated_spatial_grids()
     if world > 1:
         cdist.all_reduce_max_nan(out)
-    c.record()
+    b.record()
     torch.cuda.synchronize()
-    ms_splat, ms_reduce = a.elapsed_time(b), b.elapsed_time(c)
+    ms = a.elapsed_time(b)
+    # the unfused route (global-atomic splat, row sums, normalise + max: three passes over the grid) for comparison
+    occ.reset()
+    c, d = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+    c.record()
+    occ.accumulate_device(q, lazy=False)
+    occ.return_aggregated_spatial_grids()
+    d.record()
+    torch.cuda.synchronize()
+    ms_unfused = c.elapsed_time(d)
     if rank != 0:
         return None
-    cells = 113.1                                   # 4/3 pi 3^3 voxels inside the threshold sphere
-    alg = S * H * (12 + cells * 8) + 4 * H * R**3   # structure A of SURVEY.md 8d: RMW per lit cell + the grid itself
-    return {"metric": "occupancy splats/s (ComA_Occupancy K5, R=128)", "value": world * S * H / (ms_splat * 1e-3), "unit": "splats/s",
-            "dense_equivalent_voxel_tests_per_s": world * S * H * R**3 / (ms_splat * 1e-3), "splat_ms": ms_splat,
-            "reduce_ms": ms_reduce, "config": {"workload": f"H={H} rows/GPU (10475/8), R={R}, S={S}, scale_tolerance 3 (config 5 per-GPU share)"},
-            "roofline": {"bound": "hbm", "kernel": "coma::occupancy_splat_kernel", "achieved": alg / (ms_splat * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms_splat * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    # algorithmic bytes of SURVEY.md 8d structure B: the per-vertex grid written once + the samples re-read once per x-plane slab
+    slabs = R // max(1, 20480 // (R * R)) if R * R <= 20480 else R
+    alg = 4 * H * R**3 + 12 * S * H * slabs
+    return {"metric": "occupancy splats/s (ComA_Occupancy K5+K6 fused, R=128)", "value": world * S * H / (ms * 1e-3), "unit": "splats/s",
+            "dense_equivalent_voxel_tests_per_s": world * S * H * R**3 / (ms * 1e-3), "fused_ms": ms, "unfused_ms": ms_unfused,
+            "config": {"workload": f"H={H} rows/GPU (10475/8), R={R}, S={S}, scale_tolerance 3 (config 5 per-GPU share): zero grid, splat, "
+                                   "row sums, max over humans; raw per-vertex grid left in HBM"},
+            "roofline": {"bound": "hbm", "kernel": "coma::occupancy_fused_kernel (+ rowprep, groupmax)", "achieved": alg / (ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes": alg, "traffic": None}}
 
 
 # HBM bytes per contact_accumulate_kernel launch from the committed rocprofv3 PMC pass (profiles/r01_contact_pmc.txt):

@@ -56,8 +56,16 @@ class ComA_Occupancy:
         self.N_z = self.spatial_grid_metadata["N_z"]
         self.spatial_grid = torch.from_numpy(self.spatial_grid).to(device)   # f64 [3,R,R,R]
 
-        self.spatial_occupancy_grids = torch.zeros([self.human_res, self.N_x, self.N_y, self.N_z], dtype=torch.float32,
-                                                   device=device)
+        # Per-vertex counts.  Samples aggregated into a still-pristine grid are only staged on the device (_pending); the
+        # first thing that needs the grid -- export, an outside read of the attribute, or return_aggregated_spatial_grids --
+        # runs splat + row sums + max over humans as ONE pass that writes the grid once (coma_occupancy_fused, SURVEY.md 8d
+        # structure B).  The reference's in-place normalisation by the reducer is applied lazily (_needs_norm) the next time
+        # the grid itself is looked at.
+        self._grid = torch.zeros([self.human_res, self.N_x, self.N_y, self.N_z], dtype=torch.float32, device=device)
+        self._pending = []          # staged q tensors [S,H,3]
+        self._pristine = True       # nothing has been accumulated into _grid and nobody outside has seen it
+        self._field_all = None      # max over ALL humans computed by the fused pass, valid until the grid is exposed
+        self._needs_norm = False    # a reduction has happened: outside readers must see counts / row sums
         self.cache_count = 0
         self.used_count = 0
         self.cache = dict()
@@ -73,6 +81,34 @@ class ComA_Occupancy:
         self.eps = eps
         self.debug_obj_vert = None
         self.debug_obj_normal = None
+
+    @property
+    def spatial_occupancy_grids(self):
+        self._materialize()
+        self._field_all, self._pristine = None, False      # the caller may modify it in place
+        return self._grid
+
+    @spatial_occupancy_grids.setter
+    def spatial_occupancy_grids(self, value):
+        self._pending, self._pristine, self._field_all, self._needs_norm = [], False, None, False
+        self._grid = value
+
+    def reset(self):
+        """Back to the state after construction (extension: lets a long-lived object be re-used)."""
+        self._grid.zero_()
+        self._pending, self._pristine, self._field_all, self._needs_norm = [], True, None, False
+        self.cache, self.used, self.cache_count, self.used_count = dict(), dict(), 0, 0
+
+    def _materialize(self):
+        """Make _grid hold what the reference's attribute would hold right now."""
+        if self._pending:
+            if self._pristine and self._fusable():
+                self._field_all = self._fused(None)
+            else:
+                self._flush()
+        if self._needs_norm:
+            self._needs_norm = False
+            self._classic_reduce(None)
 
     def register_sample_to_cache(self, **kwargs):
         self.cache[f"{self.cache_count:05}"] = kwargs
@@ -119,31 +155,106 @@ class ComA_Occupancy:
         self.accumulate_device(q)
 
     def _axis_centers(self):
-        g = self.spatial_grid.to(torch.float64)
-        return torch.stack([g[0, :, 0, 0], g[1, 0, :, 0], g[2, 0, 0, :]]).contiguous()
+        c = getattr(self, "_centers", None)
+        if c is None:
+            g = self.spatial_grid.to(torch.float64)
+            c = self._centers = torch.stack([g[0, :, 0, 0], g[1, 0, :, 0], g[2, 0, 0, :]]).contiguous()
+        return c
 
-    def accumulate_device(self, q):
+    def accumulate_device(self, q, lazy=True):
         """q: f32 [S,H,3] on the HIP device, already relative to object point 0."""
+        assert tuple(q.shape[1:]) == (self.human_res, 3)
+        if lazy and self._pristine and self._fusable():
+            self._pending.append(q)
+            return
+        self._materialize()
+        self._field_all = None
+        self._splat(q)
+
+    def _fusable(self):
+        R = self.spatial_res
+        return self.N_x == self.N_y == self.N_z == R and (R * R) % 4 == 0 and R * R <= 20480 and R <= 255
+
+    def _flush(self):
+        pend, self._pending = self._pending, []
+        for q in pend:
+            self._splat(q)
+
+    def _splat(self, q):
+        self._pristine = False
         L = _lib.lib()
         S, H, R = q.shape[0], self.human_res, self.spatial_res
         assert tuple(q.shape) == (S, H, 3) and self.N_x == self.N_y == self.N_z == R
         centers = self._axis_centers()
         rc = L.coma_occupancy_splat(_lib.ptr(q, torch.float32, "q"), S, H, R, _lib.ptr(centers, torch.float64),
                                     float(self.spatial_grid_metadata["voxel_size"]), float(self.rel_dist_thres),
-                                    _lib.ptr(self.spatial_occupancy_grids, torch.float32, "spatial_occupancy_grids"),
-                                    _lib.stream_ptr(q.device))
+                                    _lib.ptr(self._grid, torch.float32, "spatial_occupancy_grids"), _lib.stream_ptr(q.device))
         _lib.check(rc, "coma_occupancy_splat")
 
-    def _reduce(self, human_indices):
+    @staticmethod
+    def _sqrt_cut(thres):
+        """Smallest double x with sqrt(x) >= thres: `(dx^2+dy^2)+dz^2 < x` is then bit-for-bit `sqrt(..) < thres` (sqrt is
+        correctly rounded, hence monotone)."""
+        y = np.float64(thres) * np.float64(thres)
+        while np.sqrt(y) >= thres:
+            y = np.nextafter(y, np.float64(0.0))
+        while np.sqrt(y) < thres:
+            y = np.nextafter(y, np.float64(np.inf))
+        return float(y)
+
+    def _cut(self, thres):
+        if getattr(self, "_cut_cache", (None, None))[0] != thres:
+            self._cut_cache = (thres, self._sqrt_cut(thres))
+        return self._cut_cache[1]
+
+    def _fused(self, sel):
+        """All staged samples -> raw counts (written once) + row sums + max of counts / row sums over the selected humans."""
         L = _lib.lib()
+        q = self._pending[0] if len(self._pending) == 1 else torch.cat(self._pending, dim=0)
+        q = q.contiguous()
+        self._pending, self._pristine = [], False
+        S, H, R = int(q.shape[0]), self.human_res, self.spatial_res
+        dev = self._grid.device
+        voxel, thres = float(self.spatial_grid_metadata["voxel_size"]), float(self.rel_dist_thres)
+        window = int(np.ceil(2.0 * thres / voxel - 1e-9)) + 2
+        nbytes = int(L.coma_occupancy_fused_workspace_bytes(S, H, R))
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # kept: the next call re-uses it
+        rowsum = torch.empty([H], dtype=torch.float32, device=dev)
+        out = torch.empty([R, R, R], dtype=torch.float32, device=dev)
+        centers = self._axis_centers()
+        rc = L.coma_occupancy_fused(_lib.ptr(q, torch.float32, "q"), S, H, R, _lib.ptr(centers, torch.float64), voxel, thres,
+                                    self._cut(thres), window, _lib.ptr(sel), 1, _lib.ptr(self._grid, torch.float32),
+                                    _lib.ptr(rowsum), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "coma_occupancy_fused")
+        return out
+
+    def _reduce(self, human_indices):
         H = self.human_res
-        R3 = self.N_x * self.N_y * self.N_z
-        g = self.spatial_occupancy_grids
-        dev = g.device
+        dev = self._grid.device
         sel = None
         if human_indices is not None:
             sel = torch.zeros([H], dtype=torch.uint8, device=dev)
             sel[torch.as_tensor(list(human_indices), dtype=torch.long, device=dev)] = 1
+        if self._pending and self._pristine and self._fusable():
+            out = self._fused(sel)
+            self._needs_norm = True
+            return out
+        if sel is None and self._field_all is not None and not self._needs_norm:
+            out, self._field_all = self._field_all, None
+            self._needs_norm = True
+            return out
+        self._materialize()
+        self._field_all = None
+        return self._classic_reduce(sel)
+
+    def _classic_reduce(self, sel):
+        L = _lib.lib()
+        H = self.human_res
+        R3 = self.N_x * self.N_y * self.N_z
+        g = self._grid
+        dev = g.device
         rowsum = torch.empty([H], dtype=torch.float32, device=dev)
         out = torch.empty([self.N_x, self.N_y, self.N_z], dtype=torch.float32, device=dev)
         rc = L.coma_occupancy_reduce(_lib.ptr(g, torch.float32), _lib.ptr(sel), H, R3, _lib.ptr(rowsum), _lib.ptr(out),
@@ -164,6 +275,8 @@ class ComA_Occupancy:
 
     def export(self, save_pth=None):
         to_export = {k: v for k, v in vars(self).items() if k not in ("cache", "used") and not k.startswith("_")}
+        self._materialize()
+        to_export["spatial_occupancy_grids"] = self._grid
         to_export = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else deepcopy(v)) for k, v in to_export.items()}
         to_export = to_np_torch_recursive(to_export, use_torch=False, device="cpu")
         if save_pth is None:
@@ -177,3 +290,4 @@ class ComA_Occupancy:
         loadables = to_np_torch_recursive(loadables, use_torch=True, device=self.device)
         for k, v in loadables.items():
             setattr(self, k, v)
+        self._centers = None            # derived from spatial_grid

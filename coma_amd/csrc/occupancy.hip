@@ -122,6 +122,218 @@ __global__ __launch_bounds__(256) void occupancy_norm_max4_kernel(float* __restr
   *reinterpret_cast<float4*>(out + i) = make_float4(m[0], m[1], m[2], m[3]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Structure B of SURVEY.md 8d: splat + normalise + max over humans in one pass, the grid written ONCE.
+// replaces: utils/coma_occupancy.py:272-312 end to end (aggregate every cached sample into a zero grid, then
+//           return_aggregated_spatial_grids): afterwards counts holds the NORMALISED grid exactly as the reference leaves it.
+//   pass 1  occupancy_rowprep_kernel   one workgroup per human vertex: per sample the candidate range along x and the
+//                                       number of hits (-> row sum, exact integer), one 16-byte record per (vertex, sample)
+//   pass 2  occupancy_fused_kernel     workgroup = (slab of P x-planes, row group): for every row of the group the slab lives in
+//                                       LDS as u32 counters, the row's samples that reach the slab are compacted, their
+//                                       (W x W) candidate windows tested at full lane occupancy, then one sweep converts /
+//                                       normalises / stores the slab (coalesced 16-byte stores) and folds it into a running
+//                                       maximum each thread keeps in registers for its own cells
+//   pass 3  occupancy_groupmax_kernel  NaN-propagating max over the row groups
+// The distance test is the reference's: d = sqrt((dx^2 + dy^2) + dz^2) < thres in f64.  sqrt is correctly rounded, hence
+// monotone, so "sqrt(x) < thres" is EXACTLY "x < T2" with T2 = the smallest double whose square root is >= thres (found on the
+// host by stepping ulps) -- same bits, no f64 sqrt per candidate.
+constexpr int kFusedThreads = 512;
+constexpr int kFusedMaxChunks = 5;                               // 8-cell chunks per thread -> slabs of <= 20480 cells
+constexpr int kFusedMaxCells = kFusedThreads * kFusedMaxChunks * 8;
+constexpr int kFusedListCap = 512;                               // samples of one row compacted per round (14 KB of LDS)
+
+struct OccRec { float x, y, z; unsigned pack; };                 // pack: lo_x | n_x << 8 (n_x = 0: never inside the grid)
+
+__device__ __forceinline__ void axis_range(double qc, double thres, double c0, double inv, int R, int& lo, int& n) {
+  int a = (int)floor((qc - thres - c0) * inv - 0.01);           // conservative (0.01-voxel margin), as in the splat kernel
+  int b = (int)ceil((qc + thres - c0) * inv + 0.01);
+  a = a < 0 ? 0 : a;
+  b = b > R - 1 ? R - 1 : b;
+  lo = a;
+  n = b - a + 1;
+}
+
+__global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __restrict__ q, int S, int H, int R,
+                                                                const double* __restrict__ centers, double voxel, double thres,
+                                                                double t2, OccRec* __restrict__ rec, float* __restrict__ rowsum) {
+  __shared__ unsigned part[4];
+  __shared__ double cen[3 * 256];                                 // per-axis centres: LDS, not three dependent global loads per test
+  for (int i = threadIdx.x; i < 3 * R; i += 256) cen[i] = centers[i];
+  __syncthreads();
+  const int h = blockIdx.x;
+  const double inv = 1.0 / voxel;
+  unsigned hits = 0;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const float* qp = q + ((int64_t)s * H + h) * 3;
+    const float fx = qp[0], fy = qp[1], fz = qp[2];
+    const double qc[3] = {(double)fx, (double)fy, (double)fz};
+    int lo[3], n[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) axis_range(qc[c], thres, cen[c * R], inv, R, lo[c], n[c]);
+    const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
+    if (!empty) {
+      for (int ix = lo[0]; ix < lo[0] + n[0]; ++ix) {
+        const double dx = cen[ix] - qc[0];
+        for (int iy = lo[1]; iy < lo[1] + n[1]; ++iy) {
+          const double dy = cen[R + iy] - qc[1];
+          const double dxy = dx * dx + dy * dy;
+          for (int iz = lo[2]; iz < lo[2] + n[2]; ++iz) {
+            const double dz = cen[2 * R + iz] - qc[2];
+            hits += (dxy + dz * dz) < t2 ? 1u : 0u;
+          }
+        }
+      }
+    }
+    OccRec r = {fx, fy, fz, empty ? 0u : ((unsigned)lo[0] | ((unsigned)n[0] << 8))};
+    rec[(int64_t)h * S + s] = r;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) hits += __shfl_xor(hits, m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) rowsum[h] = (float)((part[0] + part[1]) + (part[2] + part[3]));   // exact below 2^24, like the f32 row sum
+}
+
+struct OccItem { float x, y, z; int lo_y, lo_z, px0, pn; };      // a sample that reaches the slab: planes [px0, px0 + pn) of it
+
+// Counters are 16-bit halves of LDS words (a cell sees at most S < 65536 hits per row), so a 128 x 128 plane is 32 KB and
+// two workgroups share a CU: one's candidate tests (VALU / LDS) run under the other's slab stores (HBM).
+__global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
+    const OccRec* __restrict__ rec, const float* __restrict__ rowsum, const uint8_t* __restrict__ select, int S, int H, int R, int P,
+    int W, int groups, int write_raw, const double* __restrict__ centers, double voxel, double thres, double t2,
+    float* __restrict__ counts, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int RR = R * R;
+  const int x0 = blockIdx.x * P;
+  const int np = min(P, R - x0);                                 // planes of this slab
+  const int cells = np * RR;                                     // multiple of 4 whenever RR is (checked on the host)
+  unsigned* cnt = reinterpret_cast<unsigned*>(smem);
+  const size_t cnt_bytes = (((size_t)P * RR * 2 + 15) / 16) * 16;
+  OccItem* items = reinterpret_cast<OccItem*>(smem + cnt_bytes);
+  double* cen = reinterpret_cast<double*>(smem + cnt_bytes + (size_t)kFusedListCap * sizeof(OccItem));   // [3][R]
+  for (int i = threadIdx.x; i < 3 * R; i += kFusedThreads) cen[i] = centers[i];
+  __shared__ int n_items;
+  const int g = blockIdx.y;
+  const int h_lo = (int)((int64_t)H * g / groups), h_hi = (int)((int64_t)H * (g + 1) / groups);
+  const double inv = 1.0 / voxel;
+  const int n8 = (cells + 7) >> 3;                               // 8-cell chunks; cells % 4 == 0, so a chunk is whole or its first half
+  float mx[kFusedMaxChunks][8];
+#pragma unroll
+  for (int k = 0; k < kFusedMaxChunks; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx[k][e] = -__builtin_inff();
+  for (int i = threadIdx.x; i < n8; i += kFusedThreads) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+  const int WW = W * W;
+  const int w_shift = __builtin_ctz(W);
+  int pl_shift = 0;
+  while ((1 << pl_shift) < min(np, W)) ++pl_shift;
+  // The records of a row's first kFusedListCap samples are fetched BEFORE the previous row's slab is stored: a wave's loads
+  // return in order behind its own stores (vmcnt), so a load issued after the sweep would wait for the whole slab to reach
+  // HBM and serialise the test phase with the store drain (measured: 13.8 k cycles per row and plane instead of ~7 k).
+  constexpr int RPT = kFusedListCap / kFusedThreads;             // records per thread per round
+  OccRec nxt[RPT];
+  auto fetch = [&](int hh, int s0) {
+#pragma unroll
+    for (int kk = 0; kk < RPT; ++kk) {
+      const int s = s0 + threadIdx.x + kk * kFusedThreads;
+      nxt[kk] = s < S ? rec[(int64_t)hh * S + s] : OccRec{0.f, 0.f, 0.f, 0u};
+    }
+  };
+  if (h_lo < h_hi) fetch(h_lo, 0);
+  for (int h = h_lo; h < h_hi; ++h) {
+    for (int s0 = 0; s0 < S; s0 += kFusedListCap) {               // the compacted list holds kFusedListCap samples at a time
+      if (s0 > 0) fetch(h, s0);
+      if (threadIdx.x == 0) n_items = 0;
+      __syncthreads();
+      // ---- samples of this row that reach the slab, with their y / z windows.  Hits can only lie in the first W cells of
+      // a conservative range (it is at most one cell wider than W = ceil(2 thres / voxel) + 2 on its far side).
+#pragma unroll
+      for (int kk = 0; kk < RPT; ++kk) {
+        const OccRec r = nxt[kk];
+        const int lx = r.pack & 0xff, nx = (r.pack >> 8) & 0xff;
+        const int a = max(lx, x0), b = min(lx + min(nx, W), x0 + np);
+        if (nx > 0 && a < b) {
+          int lo_y, ny, lo_z, nz;
+          axis_range((double)r.y, thres, cen[R], inv, R, lo_y, ny);
+          axis_range((double)r.z, thres, cen[2 * R], inv, R, lo_z, nz);
+          if (ny > 0 && nz > 0) {
+            const int i = atomicAdd(&n_items, 1);
+            items[i] = {r.x, r.y, r.z, lo_y, lo_z, a, b - a};
+          }
+        }
+      }
+      __syncthreads();
+      // ---- candidate tests: item = (sample, plane, window cell), every lane busy
+      // W and the planes-per-item count are powers of two (host), so the item decode is shifts and masks
+      const int total = n_items << (pl_shift + 2 * w_shift);
+      for (int w = threadIdx.x; w < total; w += kFusedThreads) {
+        const int it = w >> (pl_shift + 2 * w_shift), c = w & ((1 << (pl_shift + 2 * w_shift)) - 1);
+        const OccItem m = items[it];
+        const int pl = c >> (2 * w_shift), wc = c & (WW - 1);
+        const int iy = m.lo_y + (wc >> w_shift), iz = m.lo_z + (wc & (W - 1));
+        if (pl < m.pn && iy < R && iz < R) {
+          const int ix = m.px0 + pl;
+          const double dx = cen[ix] - (double)m.x, dy = cen[R + iy] - (double)m.y, dz = cen[2 * R + iz] - (double)m.z;
+          if (((dx * dx + dy * dy) + dz * dz) < t2) {
+            const int cell = (ix - x0) * RR + iy * R + iz;
+            atomicAdd(&cnt[cell >> 1], 1u << ((cell & 1) * 16));
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (h + 1 < h_hi) fetch(h + 1, 0);
+    // ---- sweep: normalise, store the slab of row h, fold into the running maximum, leave the counters zero
+    const float rs = rowsum[h];
+    const bool sel = !select || select[h];
+    float4* dst = reinterpret_cast<float4*>(counts + (int64_t)h * R * RR + (int64_t)x0 * RR);
+#pragma unroll
+    for (int k = 0; k < kFusedMaxChunks; ++k) {
+      const int i = threadIdx.x + k * kFusedThreads;
+      if (i < n8) {
+        const uint4 c4 = reinterpret_cast<uint4*>(cnt)[i];
+        reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+        const unsigned w[4] = {c4.x, c4.y, c4.z, c4.w};
+        float c[8], v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { c[2 * e] = (float)(w[e] & 0xffffu); c[2 * e + 1] = (float)(w[e] >> 16); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = c[e] / rs;               // 0/0 = NaN as in the reference
+        const bool second = i * 8 + 4 < cells;
+        dst[2 * i] = write_raw ? make_float4(c[0], c[1], c[2], c[3]) : make_float4(v[0], v[1], v[2], v[3]);
+        if (second) dst[2 * i + 1] = write_raw ? make_float4(c[4], c[5], c[6], c[7]) : make_float4(v[4], v[5], v[6], v[7]);
+        if (sel) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mx[k][e] = (v[e] > mx[k][e] || v[e] != v[e]) ? v[e] : mx[k][e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float4* pout = reinterpret_cast<float4*>(partial + (int64_t)g * R * RR + (int64_t)x0 * RR);
+#pragma unroll
+  for (int k = 0; k < kFusedMaxChunks; ++k) {
+    const int i = threadIdx.x + k * kFusedThreads;
+    if (i < n8) {
+      pout[2 * i] = make_float4(mx[k][0], mx[k][1], mx[k][2], mx[k][3]);
+      if (i * 8 + 4 < cells) pout[2 * i + 1] = make_float4(mx[k][4], mx[k][5], mx[k][6], mx[k][7]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void occupancy_groupmax_kernel(const float* __restrict__ partial, int groups, int64_t R3,
+                                                                 float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R3) return;
+  float m = -__builtin_inff();
+  for (int g = 0; g < groups; ++g) {
+    const float v = partial[(int64_t)g * R3 + i];
+    m = (v > m || v != v || m != m) ? ((m != m) ? m : v) : m;      // NaN sticks
+  }
+  out[i] = m;
+}
+
 }  // namespace coma
 
 using namespace coma;
@@ -153,4 +365,46 @@ extern "C" int coma_occupancy_reduce(float* counts, const uint8_t* select, int H
                        counts, select, rowsum, H, R3, out);
   }
   return check_launch("occupancy reduce kernels");
+}
+
+
+extern "C" size_t coma_occupancy_fused_workspace_bytes(int S, int H, int R) {
+  if (S <= 0 || H <= 0 || R <= 0) return 0;
+  const int64_t R3 = (int64_t)R * R * R;
+  const int P = kFusedMaxCells / (R * R);
+  if (P < 1) return 0;
+  const int slabs = (R + P - 1) / P;
+  int groups = (768 + slabs - 1) / slabs;   // three resident workgroups per CU (80 VGPRs, <= 50 KB of LDS each)
+  if (groups > H) groups = H;
+  return (size_t)S * H * sizeof(OccRec) + (size_t)groups * R3 * sizeof(float) + 256;
+}
+
+extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const double* centers, double voxel, double thres,
+                                    double thres_sq_cut, int window, const uint8_t* select, int write_raw, float* counts, float* rowsum,
+                                    float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!q || !centers || !counts || !rowsum || !out || !workspace) return fail(COMA_E_INVALID, "coma_occupancy_fused: null pointer");
+  if (window > 2 && (window & (window - 1))) { int w2 = 1; while (w2 < window) w2 <<= 1; window = w2; }   // cell decode by shifts
+  if (S <= 0 || H <= 0 || R <= 0 || R > 255 || (R * R) % 4 || !(voxel > 0.0) || !(thres > 0.0) || window < 2 || window > 16)
+    return fail(COMA_E_INVALID, "coma_occupancy_fused: bad sizes S=%d H=%d R=%d window=%d (R*R must be a multiple of 4, R <= 255)", S, H, R, window);
+  const int RR = R * R;
+  const int P = kFusedMaxCells / RR;
+  if (P < 1) return fail(COMA_E_INVALID, "coma_occupancy_fused: R=%d too large for an LDS-resident plane (use splat + reduce)", R);
+  const size_t need = coma_occupancy_fused_workspace_bytes(S, H, R);
+  if (workspace_bytes < need) return fail(COMA_E_INVALID, "coma_occupancy_fused: workspace %zu < %zu bytes", workspace_bytes, need);
+  const int slabs = (R + P - 1) / P;
+  int groups = (768 + slabs - 1) / slabs;   // three resident workgroups per CU (80 VGPRs, <= 50 KB of LDS each)
+  if (groups > H) groups = H;
+  const size_t lds = (((size_t)P * RR * 2 + 15) / 16) * 16 + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double);
+  if (S >= 65536) return fail(COMA_E_INVALID, "coma_occupancy_fused: S=%d >= 65536 samples per call (16-bit counters)", S);
+  hipStream_t st = (hipStream_t)stream;
+  OccRec* rec = reinterpret_cast<OccRec*>(workspace);
+  float* partial = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + (((size_t)S * H * sizeof(OccRec) + 255) & ~(size_t)255));
+  hipLaunchKernelGGL(occupancy_rowprep_kernel, dim3((unsigned)H), dim3(256), 0, st, q, S, H, R, centers, voxel, thres, thres_sq_cut, rec, rowsum);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupancy_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(COMA_E_LAUNCH, "coma_occupancy_fused: cannot reserve %zu bytes of LDS", lds);
+  hipLaunchKernelGGL(occupancy_fused_kernel, dim3((unsigned)slabs, (unsigned)groups), dim3(kFusedThreads), lds, st, rec, rowsum, select, S, H, R, P,
+                     window, groups, write_raw, centers, voxel, thres, thres_sq_cut, counts, partial);
+  const int64_t R3 = (int64_t)R * RR;
+  hipLaunchKernelGGL(occupancy_groupmax_kernel, dim3((unsigned)((R3 + 255) / 256)), dim3(256), 0, st, partial, groups, R3, out);
+  return check_launch("occupancy fused kernels");
 }

@@ -121,6 +121,21 @@ int coma_occupancy_splat(const float* q, int S, int H, int R, const double* cent
 int coma_occupancy_reduce(float* counts, const uint8_t* select, int H, int64_t R3, float* rowsum,
                           float* out, void* stream);
 
+/* K5 + K6 fused (SURVEY.md 8d structure B): zero grid -> splat all S samples -> normalise -> max over humans, the per-vertex
+ * grid written once.  replaces: utils/coma_occupancy.py:272-312 for the usual "register every sample, aggregate, reduce" order;
+ * afterwards counts holds the normalised grid exactly as return_aggregated_spatial_grids leaves it (write_raw = 0) or the raw
+ * counts the reference exports before reducing (write_raw = 1; the max is over the normalised values either way), rowsum the
+ * hit totals.
+ * thres_sq_cut : the smallest double x with sqrt(x) >= thres (host: step ulps from thres*thres), so that the kernel's
+ *                (dx^2+dy^2)+dz^2 < thres_sq_cut is bit-for-bit the reference's sqrt(...) < thres;
+ * window       : candidate cells per axis, >= the number of voxel centres an open interval of length 2*thres (+ the 0.01-voxel
+ *                margins) can contain: ceil(2*scale_tolerance) + 2;
+ * workspace    : coma_occupancy_fused_workspace_bytes(S, H, R) bytes of device scratch.  R*R % 4 == 0, R*R <= 20480. */
+size_t coma_occupancy_fused_workspace_bytes(int S, int H, int R);
+int coma_occupancy_fused(const float* q, int S, int H, int R, const double* centers, double voxel, double thres,
+                         double thres_sq_cut, int window, const uint8_t* select, int write_raw, float* counts, float* rowsum,
+                         float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* K7  nearest-vertex index map (first minimum wins ties).
  * replaces: utils/coma.py:87-91 (argmin over f64 squared distances).
  * points f64 [P,3], verts f64 [V,3] -> idx i64 [P]; bit-exact. */

@@ -151,11 +151,20 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
                       proximity_settings=dict(spatial_grid_size=hp["spatial_grid_size"], spatial_grid_thres=hp["spatial_grid_thres"]),
                       principle_vec=hp["principle_vec"], sub_principle_vec=hp["sub_principle_vec"], rel_dist_method=hp["rel_dist_method"],
                       normal_gaussian_sigma=hp["normal_gaussian_sigma"], eps=hp["eps"], device=device)
-        coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **common) if visualize_type == "occupancy" else ComA(**common)
-        if skip_done and os.path.exists(save_pth):
+        # multi-GPU: contact / orientation shard SAMPLES (one SUM all-reduce of the state at the end); occupancy
+        # shards human-vertex ROWS -- every rank reads all samples but keeps only its rows of the [H, R^3] grid, so the only
+        # collective is a MAX all-reduce of the [R,R,R] field (a SUM over sample shards would move the whole grid: 88 GB at cfg 5)
+        occ_rows = visualize_type == "occupancy" and world > 1
+        row_lo, row_hi = shard_slice(H, rank, world) if occ_rows else (0, H)
+        field_dev = None
+        if visualize_type == "occupancy":
+            coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **dict(common, human_res=row_hi - row_lo))
+        else:
+            coma = ComA(**common)
+        if skip_done and os.path.exists(save_pth) and not occ_rows:
             coma.load(save_pth)
         else:
-            lo, hi = shard_slice(len(inputs), rank, world)
+            lo, hi = (0, len(inputs)) if occ_rows else shard_slice(len(inputs), rank, world)
             for pth in inputs[lo:hi]:
                 _, _, _, view_id, mask_id, prompt, id_ext = pth.split("/")[-7:]
                 params = f"{human_params_dir}/{sc_str}/{c_str}/{asset_id}/{view_id}/{mask_id}/{prompt.replace('total:', '')}/{id_ext}"
@@ -167,18 +176,18 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
                     camera_pth=f"{camera_dir}/{sc_str}/{c_str}/{asset_id}/{view_id}.pickle", human_params_pth=params, device=device)
                 if x is None:
                     continue
-                coma.register_sample_to_cache(human_verts=x["human_verts"], human_normals=x["human_vertex_normals"],
+                coma.register_sample_to_cache(human_verts=x["human_verts"][row_lo:row_hi], human_normals=x["human_vertex_normals"][row_lo:row_hi],
                                               obj_verts=x["obj_verts"], obj_normals=x["obj_vertex_normals"])
             coma.aggregate_all_samples()
-            if world > 1:
-                if visualize_type == "occupancy":
-                    # rows are complete sums only after a SUM over ranks (samples were sharded, not rows)
-                    dist.all_reduce(coma.spatial_occupancy_grids)
-                    cnt = torch.tensor([coma.used_count], device=device)
-                    dist.all_reduce(cnt)
-                    coma.used_count = int(cnt.item())
-                else:
-                    coma.all_reduce()
+            if occ_rows:
+                from coma_amd.dist import occupancy_rows_reduce
+                full, field_dev = occupancy_rows_reduce(coma, H)
+                if rank == 0:          # the exported object carries the complete raw per-vertex grid, as a single process would
+                    used, used_count = coma.used, coma.used_count
+                    coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **common)
+                    coma.spatial_occupancy_grids, coma.used, coma.used_count = full, used, used_count
+            elif world > 1:
+                coma.all_reduce()
             if rank == 0:
                 os.makedirs(save_dir, exist_ok=True)
                 coma.export(save_pth=save_pth)
@@ -196,7 +205,7 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
                 s = coma.compute_nonphysical_response_sphere(n_bin=1e6, nonphysical_type="human", as_numpy=True)["human"][:, 0]
                 np.save(f"{out}/orientational_tendency.npy", (s - s.min()) / (s.max() - s.min()))
             elif visualize_type == "occupancy":
-                field = coma.return_aggregated_spatial_grids(human_indices=None).cpu().numpy()
+                field = (field_dev if field_dev is not None else coma.return_aggregated_spatial_grids(human_indices=None)).cpu().numpy()
                 field /= field.max()
                 np.save(f"{out}/occupancy.npy", dict(prob_field=0.7 * field, spatial_grid_metadata=coma.spatial_grid_metadata))
             done.append((scam, save_pth, out))

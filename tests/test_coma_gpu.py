@@ -360,6 +360,56 @@ def test_occupancy_r128_properties(dev, hip_lib):
     assert torch.equal(occ.spatial_occupancy_grids, 2 * once)
 
 
+@pytest.mark.parametrize("R,H,S,sel", [(30, 96, 5, None), (30, 40, 6, [0, 3, 17, 39]), (8, 16, 4, None), (128, 24, 3, [1, 2, 20])])
+def test_occupancy_fused_pass_matches_oracle(R, H, S, sel, dev, hip_lib):
+    """The reference's own order -- register, aggregate, return_aggregated_spatial_grids -- takes the fused pass (splat +
+    row sums + max, grid written once); counts bit-exact, field bit-exact (same f32 division), NaN rows included."""
+    rng = np.random.default_rng(100 + R + H)
+    occ = _occ(H, R, dev)
+    m = orc.OccupancyOracle(H, R, 3.0)
+    for s in range(S):
+        hv = rng.uniform(-1.3, 1.3, size=(H, 3))
+        if sel is None:
+            hv[5] = [7.0, 7.0, 7.0]                    # never inside the grid: 0/0 -> NaN row poisons the full max
+        occ.register_sample_to_cache(human_verts=hv, human_normals=np.zeros_like(hv), obj_verts=np.zeros((3, 3)), obj_normals=np.ones((3, 3)))
+        m.aggregate_sample(hv, np.zeros((3, 3)))
+    occ.aggregate_all_samples()
+    assert occ._pending and occ._pristine                # staged, nothing splatted yet
+    raw = m.occ.copy()
+    field = _np(occ.return_aggregated_spatial_grids(human_indices=sel))
+    assert not occ._pending and occ._needs_norm
+    with np.errstate(invalid="ignore", divide="ignore"):
+        norm = raw / raw.reshape(H, -1).sum(-1)[:, None, None, None]
+    ref = np.max(norm if sel is None else norm[sel], axis=0)
+    assert np.array_equal(field, ref, equal_nan=True)
+    assert (sel is None) == bool(np.isnan(ref).any())
+    assert np.array_equal(_np(occ.spatial_occupancy_grids), norm, equal_nan=True)     # lazily normalised in place, as the reference leaves it
+
+
+def test_occupancy_export_then_reduce_and_many_samples(dev, hip_lib):
+    """export() between aggregate and reduce (src/coma/extract_coma.py order) sees RAW counts and the reduce after it re-uses the
+    field of the same fused pass; S > 2048 exercises the chunked sample list of the fused kernel."""
+    H, R, S = 6, 30, 2100
+    rng = np.random.default_rng(9)
+    occ = _occ(H, R, dev)
+    m = orc.OccupancyOracle(H, R, 3.0)
+    q = rng.uniform(-1.25, 1.25, size=(S, H, 3))
+    for s in range(S):
+        m.aggregate_sample(q[s], np.zeros((1, 3)))
+    occ.accumulate_device(torch.from_numpy(q.astype(np.float32)).to(dev))
+    occ.used_count = S
+    exp = occ.export()
+    assert np.array_equal(exp["spatial_occupancy_grids"], m.occ)
+    assert occ._field_all is not None
+    field = _np(occ.return_aggregated_spatial_grids())
+    assert np.array_equal(field, m.aggregated_grid(), equal_nan=True)
+    # and the unfused route (eager splat + reducer) gives the same bits
+    occ2 = _occ(H, R, dev)
+    occ2.accumulate_device(torch.from_numpy(q.astype(np.float32)).to(dev), lazy=False)
+    assert np.array_equal(_np(occ2.spatial_occupancy_grids), exp["spatial_occupancy_grids"])
+    assert np.array_equal(_np(occ2.return_aggregated_spatial_grids()), field, equal_nan=True)
+
+
 def test_reference_occupancy_pickle_loads(golden, dev, hip_lib):
     from utils.coma_occupancy import ComA_Occupancy
     occ = ComA_Occupancy(scale_tolerance=3.0, human_res=5, obj_res=2, normal_res=0, spatial_res=6, device=dev)

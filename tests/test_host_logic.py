@@ -164,6 +164,69 @@ def test_two_rank_all_reduce_over_gloo(tmp_path):
         assert p.returncode == 0 and f"RANK_OK {r}" in out, out
 
 
+_OCC_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from coma_amd import dist as cdist
+from oracle import coma_oracle as orc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+H, R = 11, 6                                   # 11 rows over 2 ranks: 6 + 5 (ragged shards)
+oracle = orc.OccupancyOracle(H, R, 3.0)
+rng = np.random.default_rng(3)
+for _ in range(5):
+    hv = rng.uniform(-1.0, 1.0, size=(H, 3))
+    hv[4] = [9.0, 9.0, 9.0]                     # vertex 4 never enters the grid -> its row is 0/0 = NaN after normalising
+    oracle.aggregate_sample(hv, np.zeros((1, 3)))
+lo, hi = cdist.shard_slice(H, rank, world)
+
+
+class Shard:                                    # the device object's contract, on CPU tensors (the kernels need a GPU)
+    def __init__(self):
+        self.spatial_occupancy_grids = torch.from_numpy(oracle.occ[lo:hi].copy())
+        self.spatial_grid = torch.zeros(3, R, R, R)
+    def normalize_prob_grid_for_spatials(self):
+        g = self.spatial_occupancy_grids
+        g /= g.reshape(g.shape[0], -1).sum(-1)[:, None, None, None]
+    def return_aggregated_spatial_grids(self, human_indices=None):
+        self.normalize_prob_grid_for_spatials()
+        g = self.spatial_occupancy_grids if human_indices is None else self.spatial_occupancy_grids[list(human_indices)]
+        return torch.max(g, dim=0).values
+
+
+for sel in (None, [0, 1, 2, 9], [6, 7]):        # all rows (NaN row poisons the field), rows from both shards, rows of one shard only
+    full, field = cdist.occupancy_rows_reduce(Shard(), H, human_indices=sel)
+    ref_counts = oracle.occ.copy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        norm = ref_counts / ref_counts.reshape(H, -1).sum(-1)[:, None, None, None]
+    ref = np.max(norm if sel is None else norm[sel], axis=0)     # np.max propagates NaN like torch.max
+    assert np.array_equal(field.numpy(), ref, equal_nan=True), sel
+    assert (sel is None) == bool(np.isnan(ref).any())
+    if rank == 0:
+        assert np.array_equal(full.numpy(), oracle.occ)             # raw counts of every row, in order
+    else:
+        assert full is None
+dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def test_row_sharded_occupancy_reduce_over_gloo(tmp_path):
+    """SURVEY.md 8e-3 as src/coma/extract_coma.py runs it with WORLD_SIZE > 1: rows sharded, raw rows gathered to rank 0 for the
+    export, local normalise + max, NaN-propagating MAX all-reduce of the [R,R,R] field."""
+    script = tmp_path / "wocc.py"
+    script.write_text(_OCC_WORKER)
+    port = 31500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, out
+
+
 def test_presets_match_reference_tables():
     import json
     from constants.coma.qual import QUAL_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT as Q
