@@ -19,7 +19,24 @@ try:  # easydict is optional in this image; the reference treats EasyDict exactl
     from easydict import EasyDict  # type: ignore
 except Exception:  # pragma: no cover
     class EasyDict(dict):
-        pass
+        """attribute-style dict; pickles under the name `easydict.EasyDict` so that files written here open with the real package"""
+        __module__ = "easydict"
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k) from None
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    import sys as _sys
+    import types as _types
+    if "easydict" not in _sys.modules:           # lets pickle resolve easydict.EasyDict when reading such files back here
+        _m = _types.ModuleType("easydict")
+        _m.EasyDict = EasyDict
+        _sys.modules["easydict"] = _m
 
 _CONTAINERS = (dict, EasyDict, np.ndarray, torch.Tensor, list)
 _T_FLOAT = (torch.float64, torch.float32, torch.float16, torch.bfloat16)

@@ -199,7 +199,13 @@ class AdaptiveMaskInpaintPipeline:
                                use_graph=use_graph)
         sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                             set_alpha_to_one=False)
-        return cls(vae, unet, sch, device=dev)
+        tok = enc = None
+        if os.path.isdir(os.path.join(weights_dir, "text_encoder")) and os.path.isdir(os.path.join(weights_dir, "tokenizer")):
+            # the checkpoint's own CLIP text tower (transformers; third party, as in the reference :26, :459-482)
+            from transformers import CLIPTextModel, CLIPTokenizer
+            tok = CLIPTokenizer.from_pretrained(os.path.join(weights_dir, "tokenizer"))
+            enc = CLIPTextModel.from_pretrained(os.path.join(weights_dir, "text_encoder"), torch_dtype=torch.float16).to(dev).eval()
+        return cls(vae, unet, sch, text_encoder=enc, tokenizer=tok, device=dev)
 
     def to(self, device):
         return self

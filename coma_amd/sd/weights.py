@@ -163,9 +163,29 @@ def load_safetensors(path, device="cpu", dtype=torch.float16):
     return {k: v.to(dtype).to(device) for k, v in load_file(path).items()}
 
 
+_LEGACY_VAE_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+
+
+def remap_legacy_attention(state):
+    """Older diffusers VAE checkpoints (e.g. the Oct-2022 `runwayml/stable-diffusion-inpainting` export) name the mid-block
+    attention `query / key / value / proj_attn`, sometimes as 1x1 convolutions [C,C,1,1]; diffusers converts them on load
+    (deprecated-attention path), which the reference relies on.  Same conversion here: rename, squeeze the 1x1 dims."""
+    out = {}
+    for k, v in state.items():
+        parts = k.split(".")
+        if "attentions" in parts and len(parts) >= 2 and parts[-2] in _LEGACY_VAE_ATTN:
+            parts[-2] = _LEGACY_VAE_ATTN[parts[-2]]
+            k = ".".join(parts)
+            if v.dim() == 4 and v.shape[-2:] == (1, 1):
+                v = v.reshape(v.shape[0], v.shape[1])
+        out[k] = v
+    return out
+
+
 def check_state(state, shapes, what="model"):
     """A checkpoint must carry exactly the tensors of the architecture the kernels were laid out for (diffusers' key
     names); a wrong family (e.g. a text-to-image UNet with a 4-channel conv_in) is reported before anything is launched."""
+    state = remap_legacy_attention(state)
     missing = sorted(k for k in shapes if k not in state)
     wrong = sorted(f"{k}: {tuple(state[k].shape)} != {tuple(shapes[k])}" for k in shapes if k in state and tuple(state[k].shape) != tuple(shapes[k]))
     if missing or wrong:

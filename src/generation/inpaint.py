@@ -8,9 +8,10 @@ CLI surface and host behaviour of the reference's ``src/generation/inpaint.py``:
   * per item: device generator seeded with ``inpaint_id`` (:308-309), skip-if-exists (:294-297), PNG output (:352).
 The pipeline is :class:`coma_amd.sd.pipeline.AdaptiveMaskInpaintPipeline` (HIP kernels).  Model weights, the CLIP text
 encoder and PointRend are third-party assets that cannot be provisioned offline: ``--weights_dir`` points at a
-diffusers-format checkpoint directory when one exists, otherwise seeded random weights are used (pipeline smoke /
-throughput runs) and prompts are embedded by a deterministic hash encoder; ``--mask_model synthetic`` selects the
-built-in stand-in for PointRend.
+diffusers-format checkpoint directory when one exists (its tokenizer/ + text_encoder/ then embed the prompts); otherwise
+seeded random weights are used (pipeline smoke / throughput runs) and prompts are embedded by a deterministic hash
+encoder.  ``--mask_model auto`` (default) builds the PointRend / SAM plug-in of ``--adaptive_mask_model_type``
+(coma_amd/sd/predictors.py; needs detectron2 / segment-anything), ``--mask_model synthetic`` the dependency-free stand-in.
 """
 import argparse
 import hashlib
@@ -126,22 +127,45 @@ class HashTextEncoder:
         return torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(seed))
 
 
-def set_pipeline(ldm_model_key, adaptive_mask_model_type, default_ddim_steps, weights_dir=None, mask_model="synthetic", device="cuda"):
+def set_pipeline(ldm_model_key, adaptive_mask_model_type, default_ddim_steps, weights_dir=None, mask_model="auto", device="cuda",
+                 default_pointrend_threshold=DEFAULT_POINTREND_THRESHOLD, use_visualizer=False, enable_sam_multitask_output=False):
+    """src/generation/inpaint.py:45-134 of the reference: pipeline + the mask plug-in picked by `adaptive_mask_model_type`
+    (PointRend / SAM family, coma_amd.sd.predictors) + the dilate / provoke schedules.  `mask_model="synthetic"` swaps in the
+    dependency-free stand-in; "auto" needs detectron2 (and segment-anything for the SAM types) and says so if they are missing."""
     from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
+    from coma_amd.sd.predictors import build_adaptive_mask_model
     assert ldm_model_key in HF_MODEL_KEYS
     if weights_dir:
         pipeline = AdaptiveMaskInpaintPipeline.from_pretrained(weights_dir, batch_size=1, device=device)
+        if pipeline.text_encoder is None:
+            raise FileNotFoundError(f"{weights_dir} has no text_encoder/ + tokenizer/: with a real checkpoint the prompts must go "
+                                    "through its CLIP text tower (the hash encoder is only for the random-weight path)")
     else:
         pipeline = AdaptiveMaskInpaintPipeline.from_random(batch_size=1, device=device)
     pipeline.scheduler.set_timesteps(default_ddim_steps)
-    if mask_model != "synthetic":
-        raise NotImplementedError("PointRend / SAM weights cannot be provisioned offline; register your own callable instead")
-    pipeline.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
+    if mask_model == "synthetic":
+        pipeline.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
+    elif mask_model == "auto":
+        pipeline.register_adaptive_mask_model(build_adaptive_mask_model(adaptive_mask_model_type, default_pointrend_threshold, use_visualizer,
+                                                                       enable_sam_multitask_output, device=device))
+    else:
+        raise ValueError(f"--mask_model {mask_model!r}: expected 'auto' or 'synthetic'")
     pipeline.register_adaptive_mask_settings(default_adaptive_mask_settings(default_ddim_steps, adaptive_mask_model_type))
     return pipeline
 
 
+def prime_mask_model(model, adaptive_mask_model_type, asset_seg, default_mask):
+    """Per-item state of the SAM plug-ins (reference :325-337): presumed asset mask, reset / preset person box."""
+    if adaptive_mask_model_type in ("ps_ae", "s_db_ae", "s_pdb_ae", "s_ab_ae") and hasattr(model, "set_presumed_asset_mask"):
+        model.set_presumed_asset_mask(asset_seg)
+        if adaptive_mask_model_type != "ps_ae":
+            model.reset_initial_human_bbox()
+        if adaptive_mask_model_type == "s_db_ae":
+            model.set_initial_human_bbox(default_mask)
+
+
 def inpaint_human(args):
+    import numpy as np
     import torch
     from PIL import Image
     renders = prepare_asset_render_pths(args.asset_render_dir, args.supercategories, args.categories)
@@ -150,8 +174,12 @@ def inpaint_human(args):
     items = build_work_list(renders, args.asset_mask_dir, args.asset_seg_dir, args.prompts_dir, args.save_dir, args.num_img_per_combination,
                             args.negative_prompt, defaults, use_visualizer=args.use_visualizer)
     items = slice_for_process(items, args.parallel_idx, args.parallel_num)
-    pipeline = set_pipeline(args.ldm_model_key, args.adaptive_mask_model_type, args.default_ddim_steps, args.weights_dir, args.mask_model)
-    encode = HashTextEncoder()
+    pipeline = set_pipeline(args.ldm_model_key, args.adaptive_mask_model_type, args.default_ddim_steps, args.weights_dir, args.mask_model,
+                            default_pointrend_threshold=args.default_pointrend_threshold, use_visualizer=args.use_visualizer,
+                            enable_sam_multitask_output=args.enable_sam_multitask_output)
+    # a real checkpoint brings its CLIP text tower (prompts are tokenised and encoded as in the reference); only the
+    # random-weight path embeds prompts with the deterministic hash encoder
+    encode = None if pipeline.text_encoder is not None else HashTextEncoder()
     for it in items:
         os.makedirs(it["result_save_dir"], exist_ok=True)
         if os.path.exists(it["result_save_pth"]) and args.skip_done:
@@ -160,13 +188,17 @@ def inpaint_human(args):
             continue
         init_image = Image.open(it["asset_render_pth"]).convert("RGB")
         default_mask = Image.open(it["asset_mask_pth"]).convert("L")
+        if os.path.exists(it["asset_seg_pth"]):
+            prime_mask_model(pipeline.adaptive_mask_model, args.adaptive_mask_model_type, np.array(Image.open(it["asset_seg_pth"]).convert("L")) > 0,
+                             np.asarray(default_mask) > 0)
         generator = torch.Generator(device="cuda")
         generator.manual_seed(it["inpaint_id"])
-        result = pipeline(prompt_embeds=encode(it["input_prompt"]), negative_prompt_embeds=encode(it["input_negprompt"]),
-                          image=init_image, default_mask_image=default_mask, guidance_scale=it["cfg_scale"], strength=it["strength"],
+        text = dict(prompt=it["input_prompt"], negative_prompt=it["input_negprompt"]) if encode is None else \
+            dict(prompt_embeds=encode(it["input_prompt"]), negative_prompt_embeds=encode(it["input_negprompt"]))
+        result = pipeline(image=init_image, default_mask_image=default_mask, guidance_scale=it["cfg_scale"], strength=it["strength"],
                           use_adaptive_mask=args.adaptive_mask_model_type != "baseline", generator=generator,
                           num_inference_steps=it["ddim_steps"], enforce_full_mask_ratio=it["enforce_full_mask_ratio"],
-                          visualization_save_dir=it["visualization_save_dir"], human_detection_thres=it["human_detection_thres"]).images[0]
+                          visualization_save_dir=it["visualization_save_dir"], human_detection_thres=it["human_detection_thres"], **text).images[0]
         result.save(it["result_save_pth"])
 
 
@@ -200,7 +232,9 @@ def build_parser():
     p.add_argument("--parallel_idx", type=int, default=0)
     # additions (not in the reference): offline asset provisioning
     p.add_argument("--weights_dir", type=str, default=None, help="diffusers-format checkpoint dir; default: seeded random weights")
-    p.add_argument("--mask_model", type=str, default="synthetic")
+    p.add_argument("--mask_model", type=str, default="auto", choices=["auto", "synthetic"],
+                   help="auto: the PointRend / SAM plug-in selected by --adaptive_mask_model_type (needs detectron2 / segment-anything); "
+                        "synthetic: dependency-free stand-in")
     return p
 
 

@@ -113,6 +113,54 @@ def main():
         except Exception as e:   # noqa: BLE001
             errs.append(type(e).__name__)
     out["g16_errors"] = np.array(errs)
+    # G19: the mask plug-in family (PointRendPredictor, SAMHumanPredictor*, utils/adaptive_mask_inpainting.py:1182-1454) run for
+    # real on a short frame sequence, with the two third-party networks replaced by the deterministic stand-ins of
+    # tests/fake_seg_backends.py (the classes' own logic -- category filter, merging, box policies, asset exclusion -- is what
+    # is being pinned).  detectron2 / segment_anything are stubbed by the import hook above.
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import fake_seg_backends as fb
+
+    class _Inst:
+        def __init__(self, masks, scores, classes):
+            self.pred_masks, self.scores, self.pred_classes = torch.as_tensor(masks), torch.as_tensor(scores), torch.as_tensor(classes)
+
+    def detectron_like(image):
+        return {"instances": _Inst(*fb.fake_pointrend(image))}
+
+    r.sam_model_registry = {"vit_h": lambda checkpoint=None: _Dummy()}
+    r.SamPredictor = lambda sam: None
+    frames = [fb.scene(0), fb.scene(1, n_person=2), fb.scene(2, person=False), fb.scene(3), fb.scene(4, n_person=2), fb.scene(5, person=False),
+              fb.scene(6)]
+    out["g19_frames"] = np.stack([f[0] for f in frames])
+    out["g19_asset_mask"] = frames[0][1]
+    cases = [("p_merge", r.PointRendPredictor, dict(merge_mode="merge"), False), ("p_maxconf", r.PointRendPredictor, dict(merge_mode="max-confidence"), False),
+             ("ps", r.SAMHumanPredictor, dict(), False), ("ps_multi", r.SAMHumanPredictor, dict(is_sam_multitask_output=True), False),
+             ("ps_ae", r.SAMHumanPredictorWithAssetExclusion, dict(), True),
+             ("s_db_ae", r.SAMHumanPredictorWithDefaultBboxAssetExclusion, dict(), True),
+             ("s_ab_ae", r.SAMHumanPredictorAccumulativeBboxAssetExclusion, dict(is_sam_multitask_output=True), True)]
+    for tag, cls, kw, has_asset in cases:
+        pred = cls(pointrend_thres=0.2, device="cpu", use_visualizer=False, **kw)
+        pred.pointrend_seg_model = detectron_like
+        if cls is not r.PointRendPredictor:
+            pred.sam_seg_model = fb.FakeSam()
+        if has_asset:
+            pred.set_presumed_asset_mask(frames[0][1])
+        masks, assets, kinds = [], [], []
+        for k, (img, _) in enumerate(frames):
+            if tag == "p_maxconf" and k in (2, 5):
+                continue                         # np.argmax of an empty score list raises in the reference; not a usable case
+            res = pred(img)
+            if isinstance(res, tuple):          # SAMHumanPredictor's "nobody found" branch returns (mask, vis) -- :1278-1282
+                kinds.append("tuple")
+                res = {"mask": res[0], "asset_mask": None}
+            else:
+                kinds.append("dict")
+            masks.append(res["mask"])
+            assets.append(np.zeros_like(res["mask"]) if res["asset_mask"] is None else res["asset_mask"])
+            kinds[-1] += ":none" if res["asset_mask"] is None else ":asset"
+        out[f"g19_{tag}_masks"], out[f"g19_{tag}_assets"], out[f"g19_{tag}_kinds"] = np.stack(masks), np.stack(assets), np.array(kinds)
+        if hasattr(pred, "initial_human_bbox") and pred.initial_human_bbox is not None:
+            out[f"g19_{tag}_final_bbox"] = np.asarray(pred.initial_human_bbox)
     np.savez_compressed(os.path.join(HERE, "inpaint_golden.npz"), **out)
     print("wrote inpaint_golden.npz", {k: getattr(v, "shape", None) for k, v in out.items()}, errs)
 

@@ -159,3 +159,69 @@ def test_extract_coma_cli_end_to_end(tmp_path, hip_lib):
     assert np.allclose(got, exp, atol=2e-3)
     meta = json.load(open(save_pth.replace(".pickle", ".json")))
     assert meta["H"] == H and meta["O"] == O and len(meta["input_human_pths"]) == 3
+
+
+def test_downsample_writers_schema_and_index_map(tmp_path, hip_lib):
+    """src/coma/downsample_{human,objects}.py: the reference's pickle schema (downsample_human.py:67-77,
+    downsample_objects.py:46-60) from a mesh + sampled points, index map = first-minimum nearest vertex (oracle)."""
+    import pickle, types
+    from oracle import coma_oracle as orc
+    from src.coma import downsample_human as dh, downsample_objects as do
+    rng = np.random.default_rng(0)
+    # a closed triangulated box surface with a few hundred vertices
+    g = np.linspace(-0.5, 0.5, 9)
+    verts, faces = [], []
+    def quad_grid(fix_axis, val):
+        base = len(verts)
+        for a in g:
+            for b in g:
+                p = [0.0, 0.0, 0.0]
+                ax = [i for i in range(3) if i != fix_axis]
+                p[fix_axis], p[ax[0]], p[ax[1]] = val, a, b
+                verts.append(p)
+        n = len(g)
+        for i in range(n - 1):
+            for j in range(n - 1):
+                q = base + i * n + j
+                tri = [[q, q + 1, q + n + 1], [q, q + n + 1, q + n]]
+                faces.extend(tri if val > 0 else [t[::-1] for t in tri])
+    for axis in range(3):
+        quad_grid(axis, 0.5)
+        quad_grid(axis, -0.5)
+    verts, faces = np.array(verts), np.array(faces)
+    with open(tmp_path / "star.pickle", "wb") as h:
+        pickle.dump({"vertices": verts.astype(np.float32), "faces": faces}, h)
+    args = types.SimpleNamespace(mesh_pth=str(tmp_path / "star.pickle"), points_pth=None, simplify_method="uniform", seed=5, skip_done=False,
+                                 save_dir=str(tmp_path / "mesh"), num_human_downsample_points=100)
+    pth = dh.downsample_smplx(args, device="cuda:0")
+    assert pth.endswith("smplx_star_downsampled_100.pickle")
+    d = pickle.load(open(pth, "rb"))
+    assert set(d) == {"vertices", "faces", "V", "F", "N", "N_raw", "downsample_indices", "downsampled_pcd_points_raw", "downsampled_pcd_normal_raw"}
+    assert d["V"] == len(verts) and d["F"] == len(faces) and d["N_raw"] == 100 and d["N"] == len(d["downsample_indices"]) <= 100
+    ref_idx = orc.nearest_vertex(d["downsampled_pcd_points_raw"], verts.astype(np.float32).astype(np.float64))
+    assert d["downsample_indices"] == [int(i) for i in ref_idx]
+    assert np.allclose(np.linalg.norm(d["downsampled_pcd_normal_raw"], axis=1), 1.0)
+    args.num_human_downsample_points = 10 ** 6                       # >= V: every vertex, FULL file name
+    assert dh.downsample_smplx(args, device="cuda:0").endswith("smplx_star_downsampled_FULL.pickle")
+    # object writer from an OBJ file + supplied points (two of them with a zero normal -> dropped from the raw set only)
+    with open(tmp_path / "box.obj", "w") as h:
+        h.writelines(f"v {x} {y} {z}\n" for x, y, z in verts)
+        h.writelines(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in faces)
+    pts = rng.uniform(-0.5, 0.5, size=(40, 3))
+    nrm = rng.normal(size=(40, 3))
+    nrm[[3, 17]] = 0.0
+    np.savez(tmp_path / "pts.npz", points=pts, normals=nrm)
+    a = types.SimpleNamespace(supercategory="BEHAVE", category="backpack", asset_id="behave_asset", obj_pth=str(tmp_path / "box.obj"),
+                              asset_downsample_dir=str(tmp_path / "ads"), num_object_downsample_points_list=[40], simplify_method="poisson_disk",
+                              points_pth=str(tmp_path / "pts.npz"), skip_done=False, debug=False, seed=1)
+    out = do.main(a)
+    assert out == [str(tmp_path / "ads" / "BEHAVE" / "backpack" / "behave_asset_40.pickle")]
+    o = pickle.load(open(out[0], "rb"))
+    assert set(o) == {"supercategory", "category", "asset_id", "V", "F", "N", "N_raw", "downsample_indices", "downsampled_pcd_points_raw",
+                      "downsampled_pcd_normal_raw", "obj_vertices_original", "obj_faces_original", "obj_vertex_normals_original"}
+    assert o["N"] == 40 and o["N_raw"] == 38 and len(o["downsampled_pcd_points_raw"]) == 38
+    assert o["downsample_indices"] == [int(i) for i in orc.nearest_vertex(pts, verts)]
+    # without supplied points the third-party sampler is refused, not silently replaced
+    a.points_pth = None
+    with pytest.raises(NotImplementedError):
+        do.main(a)
