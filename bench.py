@@ -35,25 +35,33 @@ def flop_per_pair(N):
     return 100 + 26 * N
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The NumPy oracle (a port of the reference's torch-CPU path, same dtype flow) on the host cores, config 1
-    shape (H=1000, O=180, N=250).  Bounded sample; NumPy elementwise kernels run on one thread."""
+def cpu_baseline(seconds_budget=12.0):
+    """SURVEY.md 8d, cfg 1 (H=1000, O=180, N=250) on the host cores, two ports of the reference's CPU path with its dtype flow:
+    `value` = the torch-CPU restatement on ALL host threads (what the reference itself runs with device="cpu"), and under
+    `single_thread_numpy` the NumPy oracle the parity tests use (one thread).  Bounded samples."""
     from oracle import coma_oracle as orc
+    from oracle import coma_oracle_torch as ot
     from tests.synth import cfg1_samples
     H, O, N = 1000, 180, 250
     samples = cfg1_samples(9, seed=0, H=H, O=O)
-    m = orc.ComAOracle(H, O, N, 0.07, 0.03, sigma=0.25, eps=1e-10)
-    m.aggregate_sample(**samples[0])           # warm-up
-    done, t0 = 0, time.perf_counter()
-    for s in samples[1:]:
-        m.aggregate_sample(**s)
-        done += 1
-        if time.perf_counter() - t0 > seconds_budget:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": done * H * O / dt, "unit": "vertex-pair contacts/s", "cores": 1, "kind": "port",
-            "sample": f"{done} samples of config 1 (H=1000,O=180,N=250) through oracle/coma_oracle.py (NumPy, f64 "
-                      f"intermediates as in the reference), {dt:.1f} s; host has {os.cpu_count()} logical cores"}
+
+    def run(m):
+        m.aggregate_sample(**samples[0])           # warm-up
+        done, t0 = 0, time.perf_counter()
+        for s in samples[1:]:
+            m.aggregate_sample(**s)
+            done += 1
+            if time.perf_counter() - t0 > seconds_budget:
+                break
+        return done, time.perf_counter() - t0
+    nt = torch.get_num_threads()
+    d_t, t_t = run(ot.ComATorch(H, O, N, 0.07, 0.03, sigma=0.25, eps=1e-10))
+    d_n, t_n = run(orc.ComAOracle(H, O, N, 0.07, 0.03, sigma=0.25, eps=1e-10))
+    return {"value": d_t * H * O / t_t, "unit": "vertex-pair contacts/s", "cores": nt, "kind": "port",
+            "sample": f"{d_t} samples of config 1 (H=1000,O=180,N=250) through oracle/coma_oracle_torch.py (torch CPU, {nt} threads, f64 "
+                      f"scores added into f32 grids as in utils/coma.py:279-323), {t_t:.1f} s; host has {os.cpu_count()} logical cores",
+            "single_thread_numpy": {"value": d_n * H * O / t_n, "unit": "vertex-pair contacts/s", "cores": 1, "kind": "port",
+                                    "sample": f"{d_n} samples through oracle/coma_oracle.py (NumPy), {t_n:.1f} s"}}
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA

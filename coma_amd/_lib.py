@@ -46,7 +46,7 @@ SIGNATURES = {
     "sd_groupnorm_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "sd_groupnorm_colstats_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sd_layernorm_f16": (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp]),
-    "sd_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "sd_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sd_softmax_f16": (_i, [_vp, _i64, _i, _i, _f, _vp]),
     "sd_cfg_ddim_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp]),
     "sd_timestep_embedding_f16": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -100,6 +100,12 @@ def ptr(t: torch.Tensor | None, dtype=None, name="tensor"):
 
 
 def stream_ptr(device=None):
+    """Current stream of `device`, and that device made current for the launch that follows: the C ABI launches under HIP's
+    current device, so a tensor on cuda:1 with cuda:0 current would otherwise meet a stream of another device."""
+    if device is not None:
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

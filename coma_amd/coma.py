@@ -138,9 +138,11 @@ class ComA:
         hv = np.stack([_as_f32(s["human_verts"], H, "human_verts") for s in samples])
         hn = np.stack([_as_f32(s["human_normals"], H, "human_normals") for s in samples])
         first = samples[0]
+        def host(a):          # tensors of any device -> NumPy (the reference takes both through to_np_torch_recursive)
+            return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
         shared_obj = all((s["obj_verts"] is first["obj_verts"] and s["obj_normals"] is first["obj_normals"])
-                         or (np.array_equal(np.asarray(s["obj_verts"]), np.asarray(first["obj_verts"]))
-                             and np.array_equal(np.asarray(s["obj_normals"]), np.asarray(first["obj_normals"])))
+                         or (np.array_equal(host(s["obj_verts"]), host(first["obj_verts"]))
+                             and np.array_equal(host(s["obj_normals"]), host(first["obj_normals"])))
                          for s in samples[1:])
         if shared_obj:
             ov = _as_f32(first["obj_verts"], O, "obj_verts")

@@ -135,10 +135,12 @@ class ComA_Occupancy:
         if not samples:
             return
         assert list(self.selected_obj_idxs) == [0], "only object point 0 is supported (as shipped in the reference)"
+        def host(a):          # tensors of any device -> NumPy (the reference takes both through to_np_torch_recursive)
+            return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
         qs = []
         for s in samples:
-            obj_vert = np.asarray(s["obj_verts"])[0]
-            obj_normal = np.asarray(s["obj_normals"])[0]
+            obj_vert = host(s["obj_verts"])[0]
+            obj_normal = host(s["obj_normals"])[0]
             # the reference asserts that the object point and its normal never change across samples
             if self.debug_obj_vert is None:
                 self.debug_obj_vert = obj_vert
@@ -148,7 +150,7 @@ class ComA_Occupancy:
                 self.debug_obj_normal = obj_normal
             else:
                 assert np.allclose(self.debug_obj_normal, obj_normal)
-            hv = np.asarray(s["human_verts"])
+            hv = host(s["human_verts"])
             assert hv.shape[0] == self.human_res
             qs.append((hv - obj_vert[None]).astype(np.float32))      # subtract in the input dtype, then f32
         q = torch.from_numpy(np.ascontiguousarray(np.stack(qs))).to(self.device)

@@ -65,7 +65,7 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((row 
 // this kernel (exp2, max, convert) -- spends nothing on the copy.
 //   K  stage: KP panels of [64 keys][64 halves] (panel p = head dims 64p .. 64p+63), rows of 128 B, swizzled
 //   V^T stage: [DV rows][64 keys], rows of 128 B, swizzled
-template <int KS, int DVT, int QT, int ONES>
+template <int KS, int DVT, int QT, int ONES, bool VPERM = false>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
   constexpr int KP = (KS * 16 + 63) / 64;
   constexpr int DV = DVT * 32;
@@ -248,10 +248,18 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
 #pragma unroll
       for (int t = 0; t < DVT; ++t) {
         const int row = t * 32 + ql;
-        const _Float16* vr = &Vs[row * 64 + 4 * hh];
-        const half4 lo = *reinterpret_cast<const half4*>(vr + swz64(row, 2 * st) * 8);
-        const half4 hi = *reinterpret_cast<const half4*>(vr + swz64(row, 2 * st + 1) * 8);
-        const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        half8 vf;
+        if constexpr (VPERM) {
+          // keys stored as (0-3, 8-11 | 4-7, 12-15) per 16: chunk 2*st + hh IS this lane's operand -- one b128 read, and the 16
+          // lanes of a read group hit 16 distinct bank slots (the two b64 reads below collide two-way: a group of 32 lanes
+          // shares hh and can only reach half of the 8-byte slots)
+          vf = *reinterpret_cast<const half8*>(&Vs[row * 64 + swz64(row, 2 * st + hh) * 8]);
+        } else {
+          const _Float16* vr = &Vs[row * 64 + 4 * hh];
+          const half4 lo = *reinterpret_cast<const half4*>(vr + swz64(row, 2 * st) * 8);
+          const half4 hi = *reinterpret_cast<const half4*>(vr + swz64(row, 2 * st + 1) * 8);
+          vf = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[qt][st], o[qt][t], 0, 0, 0);
       }
@@ -296,12 +304,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
 using namespace sd;
 
 extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq,
-                                int lk, int d, int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
+                                int lk, int d, int ldq, int ldk, int ldv, int ldo, float scale, int vt_perm16, void* stream) {
   if (!q || !k || !vt || !out) return fail(COMA_E_INVALID, "sd_attention_f16: null pointer");
   if (batch <= 0 || heads <= 0 || lq <= 0 || lk <= 0) return fail(COMA_E_INVALID, "sd_attention_f16: bad sizes");
   if (d % 8 || d <= 0 || d > 160) return fail(COMA_E_INVALID, "sd_attention_f16: head dim %d unsupported (multiple of 8, <= 160)", d);
   if (ldq < heads * d || ldk < heads * d || ldo < heads * d || ldv < ((lk + 7) & ~7) || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
     return fail(COMA_E_INVALID, "sd_attention_f16: bad leading dimensions");
+  if (vt_perm16 && (ldv % 16 || ldv < ((lk + 15) & ~15))) return fail(COMA_E_INVALID, "sd_attention_f16: vt_perm16 needs ldv a multiple of 16 covering lk");
   if ((long long)lk * ldk * 2 >= 0x80000000LL || (long long)d * ldv * 2 >= 0x80000000LL)
     return fail(COMA_E_INVALID, "sd_attention_f16: K / V^T slice of one (batch, head) exceeds 2 GiB");
   AttnArgs a;
@@ -309,15 +318,21 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.scale_log2 = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  const bool two = lq >= 1024;                 // 64 queries per wave once there are enough blocks to fill the chip
+  const bool two = lq >= 1024 && d == 40;      // 64 queries per wave once there are enough blocks to fill the chip
   dim3 grid((unsigned)((lq + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)heads, (unsigned)batch);
-  if (d == 40 && two) hipLaunchKernelGGL((attention_kernel<3, 2, 2, 40>), grid, dim3(256), 0, s, a);
-  else if (d == 40) hipLaunchKernelGGL((attention_kernel<3, 2, 1, 40>), grid, dim3(256), 0, s, a);
-  else if (d <= 48) hipLaunchKernelGGL((attention_kernel<3, 2, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
-  else if (d <= 64) hipLaunchKernelGGL((attention_kernel<4, 2, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
-  else if (d <= 80) hipLaunchKernelGGL((attention_kernel<5, 3, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
-  else if (d <= 96) hipLaunchKernelGGL((attention_kernel<6, 3, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
-  else if (d <= 128) hipLaunchKernelGGL((attention_kernel<8, 4, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((attention_kernel<10, 5, 1, -1>), (grid.x = (lq + 127) / 128, grid), dim3(256), 0, s, a);
+#define SD_ATTN_LAUNCH(KS, DVT, QT, ONES)                                                                       \
+  do {                                                                                                          \
+    if (vt_perm16) hipLaunchKernelGGL((attention_kernel<KS, DVT, QT, ONES, true>), grid, dim3(256), 0, s, a);  \
+    else hipLaunchKernelGGL((attention_kernel<KS, DVT, QT, ONES, false>), grid, dim3(256), 0, s, a);           \
+  } while (0)
+  if (d == 40 && two) SD_ATTN_LAUNCH(3, 2, 2, 40);
+  else if (d == 40) SD_ATTN_LAUNCH(3, 2, 1, 40);
+  else if (d <= 48) SD_ATTN_LAUNCH(3, 2, 1, -1);
+  else if (d <= 64) SD_ATTN_LAUNCH(4, 2, 1, -1);
+  else if (d <= 80) SD_ATTN_LAUNCH(5, 3, 1, -1);
+  else if (d <= 96) SD_ATTN_LAUNCH(6, 3, 1, -1);
+  else if (d <= 128) SD_ATTN_LAUNCH(8, 4, 1, -1);
+  else SD_ATTN_LAUNCH(10, 5, 1, -1);
+#undef SD_ATTN_LAUNCH
   return check_launch("attention_kernel");
 }

@@ -48,6 +48,7 @@ struct GemmArgs {
   int in_h, in_w, out_h, out_w;
   int taps, stride, upsample, pad;
   int M, N, K;
+  int n_valid;                // rows of W that exist (N is rounded up to 16 with SD_EPI_PERM16_N)
   int rows_per_batch;
   const _Float16* w;
   const _Float16* bias;       // [N] (or [M] with EPI_BIAS_ROWS)
@@ -487,7 +488,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     const int r = (wave * B_LD + j) * RPI + l_row;
-    const int n = min(n0 + r, g.N - 1);
+    int nn = n0 + r;
+    if (g.epi & SD_EPI_PERM16_N) nn = (nn & ~12) | ((nn & 4) << 1) | ((nn & 8) >> 1);   // output column j <- W row with bits 2, 3 of j swapped
+    const int n = min(nn, g.n_valid - 1);
     b_off[j] = (unsigned)(n * g.K) * 2u + swz<BK>(r, l_slot) * 16;
   }
   // buffer resources and scalar offsets must live in SGPRs: pin them with readfirstlane (every input is wave-uniform,
@@ -693,6 +696,12 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a source tensor (%lld B) or the weights (%lld B) exceed 2 GiB per launch; split the batch",
                 a_bytes, w_bytes);
   g.M = (int)M; g.N = d->n; g.K = d->taps * (d->c0 + d->c1);
+  g.n_valid = d->n;
+  if (d->epi & SD_EPI_PERM16_N) {
+    g.N = (d->n + 15) & ~15;            // whole 16-column groups: positions past n hold clamped (finite) rows the consumer masks
+    if ((d->ldo > 0 ? d->ldo : d->n) < g.N) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: SD_EPI_PERM16_N needs ldo >= n rounded up to 16");
+    if ((d->epi & SD_EPI_GEGLU) || d->res || d->bias_bn || d->colstats) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: SD_EPI_PERM16_N takes no GEGLU / residual / per-sample bias / colstats");
+  }
   g.w = (const _Float16*)d->w; g.bias = (const _Float16*)d->bias; g.bias_bn = (const _Float16*)d->bias_bn;
   g.res = (const _Float16*)d->res; g.ldr = d->ldr > 0 ? d->ldr : d->n;
   g.out = (_Float16*)d->out; g.epi = d->epi;
@@ -705,26 +714,26 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const bool k64 = d->c0 % 64 == 0 && d->c1 % 64 == 0;
   const bool deep = g.K >= 2048 && k64;
   // 256 x 320 tile: N a multiple of 320 (every layer of the SD UNet), enough rows to fill the chip with 1 block / CU
-  const bool big = !geglu && nz == 1 && k64 && d->n % 320 == 0 && (long long)((g.M + 255) / 256) * (d->n / 320) >= 192 && !(d->epi & ((1 << 20) | (1 << 21)));
+  const bool big = !geglu && nz == 1 && k64 && g.N % 320 == 0 && (long long)((g.M + 255) / 256) * (g.N / 320) >= 192 && !(d->epi & ((1 << 20) | (1 << 21)));
   // GEGLU (needs an even number of MFMA column tiles per wave): 256 x 256, 8 waves, wave tile 64 x 128
-  const bool big_geglu = geglu && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 16 && !(d->epi & (1 << 20));
+  const bool big_geglu = geglu && nz == 1 && k64 && g.N % 256 == 0 && g.M >= 256 * 16 && !(d->epi & (1 << 20));
   // VAE widths (128 / 256 / 512 channels at up to 512 x 512 pixels): 256 x 256 and 256 x 128 tiles, 8 waves
-  const bool big256 = !geglu && !big && nz == 1 && k64 && d->n % 256 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
-  const bool big128 = !geglu && !big && !big256 && nz == 1 && k64 && d->n % 128 == 0 && g.M >= 256 * 256 && !(d->epi & (1 << 20));
+  const bool big256 = !geglu && !big && nz == 1 && k64 && g.N % 256 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
+  const bool big128 = !geglu && !big && !big256 && nz == 1 && k64 && g.N % 128 == 0 && g.M >= 256 * 256 && !(d->epi & (1 << 20));
   // 512 x 128, 8 waves (wave tile 64 x 128), BK = 32, 3 stages: the 128-channel 3x3 convs of the VAE at 512 x 512
   // (K = 1152: +17 % over 256 x 128; slower than it at K = 2304)
   const bool tall128 = big128 && g.K <= 1152 && !(d->epi & (1 << 20));
   // 128 x 320, 4 waves (wave tile 64 x 160): mid-size M where 256-row tiles would leave CUs idle
-  const bool mid = !big && !big256 && !big128 && !geglu && nz == 1 && d->n % 320 == 0 && g.M >= 128 * 64 &&
-                   (d->n <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20));
+  const bool mid = !big && !big256 && !big128 && !geglu && nz == 1 && g.N % 320 == 0 && g.M >= 128 * 64 &&
+                   (g.N <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20));
   // 128 x 320 with EIGHT waves (wave tile 32 x 160, two waves per SIMD) instead of four: the partner wave covers each
   // wave's LDS-read / DMA-issue latency, which the 4-wave tile leaves exposed (knob 23 selects the 4-wave form)
   const bool mid8 = mid && k64 && g.K >= 256 && !(d->epi & (1 << 23));
-  const bool wide = d->n % 128 == 0 || d->n > 256;
+  const bool wide = g.N % 128 == 0 || g.N > 256;
   const int bm = tall128 ? 512 : ((big || big_geglu || big256 || big128) ? 256 : 128);
   const int bn = (big || mid) ? 320 : ((big_geglu || big256) ? 256 : ((wide || big128) ? 128 : 64));
   const int bk = ((mid && !mid8) || tall128) ? 32 : ((big || big_geglu || big256 || big128 || deep || mid8) ? 64 : 32);
-  const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((d->n + bn - 1) / bn);
+  const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((g.N + bn - 1) / bn);
   // split-K when the tile grid cannot fill the chip: as many splits as keep every block resident at once (2 per CU,
   // 512 in total -- a partial second round costs more than it buys), at least 384 of K per split
   g.ksplit = 1;
@@ -733,14 +742,14 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (dbg_on) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dbg_stamps)) == hipSuccess) g.dbg = (unsigned long long*)p; }
   g.partial = (float*)d->workspace;
   g.colstats = (float*)d->colstats;
-  if (g.colstats && (geglu || nz != 1 || g.M % 32 || d->n % 8 || (d->epi & SD_EPI_BIAS_ROWS) || g.ldo % 8 || (g.res && g.ldr % 8) ||
+  if (g.colstats && (geglu || nz != 1 || g.M % 32 || g.N % 8 || (d->epi & SD_EPI_BIAS_ROWS) || g.ldo % 8 || (g.res && g.ldr % 8) ||
                      (g.bias_bn && (g.res || g.rows_per_batch % 32 || g.ldbb % 8)) || (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL ||
                      (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: colstats needs M %% 32 == 0, N %% 8 == 0, 16-byte aligned rows, < 2 GiB tensors, no GEGLU / batching");
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
-  if (!g.colstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && d->n % 8 == 0 && g.ldo % 8 == 0) {
+  if (!g.colstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)(512 / blocks);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;

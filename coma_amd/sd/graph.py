@@ -88,9 +88,9 @@ class LaunchGraph:
         self.add(lambda: ops.layernorm(x, gamma, beta, out, rows=rows, c=c), tag=f"layernorm rows={rows} C={c}")
         return out
 
-    def attention(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
+    def attention(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, vt_perm16=False):
         self.add(lambda: ops.attention(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv,
-                                       ldo=ldo, scale=d ** -0.5),
+                                       ldo=ldo, scale=d ** -0.5, vt_perm16=vt_perm16),
                  flops=4 * batch * heads * lq * lk * d, tag=f"attention B={batch} h={heads} lq={lq} lk={lk} d={d}")
         return out
 

@@ -8,7 +8,7 @@ import torch
 
 from .. import _lib
 
-EPI_NONE, EPI_GEGLU, EPI_SILU, EPI_BIAS_ROWS = 0, 1, 2, 4
+EPI_NONE, EPI_GEGLU, EPI_SILU, EPI_BIAS_ROWS, EPI_PERM16_N = 0, 1, 2, 4, 8
 F16 = torch.float16
 
 
@@ -84,11 +84,23 @@ def layernorm(x, gamma, beta, out, *, rows, c, eps=1e-5):
     return out
 
 
-def attention(q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale):
+def attention(q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, vt_perm16=False):
     rc = _lib.lib().sd_attention_f16(_p(q, "q"), _p(k, "k"), _p(vt, "vt"), _p(out, "out"), batch, heads, lq, lk, d, ldq, ldk,
-                                     ldv, ldo, scale, _stream(out))
+                                     ldv, ldo, scale, 1 if vt_perm16 else 0, _stream(out))
     _lib.check(rc, "sd_attention_f16")
     return out
+
+
+def perm16_columns(x):
+    """[..., n] -> [..., roundup16(n)] with every group of 16 columns in the order (0-3, 8-11, 4-7, 12-15): what SD_EPI_PERM16_N
+    produces and sd_attention_f16(vt_perm16=1) reads (pad columns zero).  Host / test helper."""
+    n = x.shape[-1]
+    n16 = (n + 15) // 16 * 16
+    y = torch.zeros(*x.shape[:-1], n16, dtype=x.dtype, device=x.device)
+    y[..., :n] = x
+    j = torch.arange(n16, device=x.device)
+    src = (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)
+    return y[..., src].contiguous()
 
 
 def softmax_(x, *, rows, n, ld, scale):

@@ -166,12 +166,12 @@ class HipUNet2DConditionModel:
         wqk = torch.cat([s[t + ".attn1.to_q.weight"], s[t + ".attn1.to_k.weight"]]).contiguous()
         qk = g.buf(M, 2 * C)
         g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
-        ldv = (L + 7) // 8 * 8
-        vt = g.buf(B, C, ldv, zero=True)
+        ldv = (L + 15) // 16 * 16
+        vt = g.buf(B, C, ldv, zero=True)         # V^T with the keys of every 16 in the order the attention kernel's MFMA operand wants
         g.conv(s[t + ".attn1.to_v.weight"], n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C,
-               stride_out=C * ldv)
+               stride_out=C * ldv, epi=ops.EPI_PERM16_N)
         a = g.buf(M, C)
-        g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C)
+        g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C, vt_perm16=True)
         h1 = g.buf(M, C)
         g.conv(a, s[t + ".attn1.to_out.0.weight"], h1, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[t + ".attn1.to_out.0.bias"],
                res=h)
@@ -189,12 +189,12 @@ class HipUNet2DConditionModel:
         Lk, cd = self.ctx_len, self.ctx_dim
         k2 = self.gc.buf(B * Lk, C)
         self.gc.conv(self.ctx, s[t + ".attn2.to_k.weight"], k2, batch=B * Lk, in_h=1, in_w=1, c0=cd, n=C)
-        ldv2 = (Lk + 7) // 8 * 8
+        ldv2 = (Lk + 15) // 16 * 16
         vt2 = self.gc.buf(B, C, ldv2, zero=True)
         self.gc.conv(s[t + ".attn2.to_v.weight"], self.ctx, vt2, batch=C, in_h=1, in_w=1, c0=cd, n=Lk, ldo=ldv2, nbatch_z=B,
-                     stride_w=Lk * cd, stride_out=C * ldv2)
+                     stride_w=Lk * cd, stride_out=C * ldv2, epi=ops.EPI_PERM16_N)
         a2 = g.buf(M, C)
-        g.attention(q2, k2, vt2, a2, batch=B, heads=heads, lq=L, lk=Lk, d=d, ldq=C, ldk=C, ldv=ldv2, ldo=C)
+        g.attention(q2, k2, vt2, a2, batch=B, heads=heads, lq=L, lk=Lk, d=d, ldq=C, ldk=C, ldv=ldv2, ldo=C, vt_perm16=True)
         h2 = g.buf(M, C)
         g.conv(a2, s[t + ".attn2.to_out.0.weight"], h2, batch=M, in_h=1, in_w=1, c0=C, n=C,
                bias=s[t + ".attn2.to_out.0.bias"], res=h1)

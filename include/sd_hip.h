@@ -28,6 +28,10 @@ extern "C" {
 #define SD_EPI_GEGLU 1      /* out[:, j] = v_j * gelu(g_j); weight rows pre-interleaved per 64 columns: [32 v | 32 g] */
 #define SD_EPI_SILU 2       /* out = silu(acc + bias) */
 #define SD_EPI_BIAS_ROWS 4  /* bias indexed by output row instead of column (A = weights, W = activations) */
+#define SD_EPI_PERM16_N 8   /* output column j holds the product with W row kappa(j) = j with bits 2 and 3 swapped, i.e. every group of
+                               16 columns is stored in the order (0-3, 8-11, 4-7, 12-15): the V^T layout sd_attention_f16 reads with one
+                               16-byte LDS load per MFMA operand (vt_perm16 = 1).  n is rounded up to 16 columns (ldo must cover them);
+                               columns whose source row is >= n hold a clamped finite row */
 /* bits 20..27 select kernel variants for tuning runs (scripts/time_gemm.py): 20 = generic 128x128 tiles only, 21 = 128x320
  * tile, 22 = tile DMA in one burst, 23 = 4-wave 128x320 tile, 24..27 = forced split-K factor.  Results are identical. */
 #define SD_EPI_TUNING_MASK 0x0ff00000
@@ -91,13 +95,16 @@ int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* 
  *   q   : [batch, lq, ldq]   head h at columns [h*d, (h+1)*d)          (ldq >= heads*d)
  *   k   : [batch, lk, ldk]   same column convention
  *   vt  : [batch, heads*d, ldv]  V TRANSPOSED: row h*d+i holds component i of every key (ldv >= lk rounded up to 8, a
- *         multiple of 8); the pad columns lk..ldv-1 must hold finite values (they meet zero softmax weights)
+ *         multiple of 8); the pad columns lk..ldv-1 must hold finite values (they meet zero softmax weights).
+ *         vt_perm16 = 1: the keys of every group of 16 are stored in the order (0-3, 8-11, 4-7, 12-15) (SD_EPI_PERM16_N of the
+ *         producing GEMM), ldv a multiple of 16 -- the kernel then fetches each V^T MFMA operand with ONE conflict-free 16-byte
+ *         LDS read instead of two 8-byte ones that collide two-way
  *   out : [batch, lq, ldo]
  * out = softmax(q k^T * scale) v per (batch, head).  d: any multiple of 8 up to 160.  The K and V^T slices of one
  * (batch, head) must stay below 2 GiB (32-bit LDS-DMA offsets); violations return an error, nothing is launched.
  * replaces: diffusers Attention (xformers / AttnProcessor2_0 scaled_dot_product_attention) in the UNet. */
 int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk,
-                     int d, int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
+                     int d, int ldq, int ldk, int ldv, int ldo, float scale, int vt_perm16, void* stream);
 
 /* Row softmax in place over fp16 [rows, n] with scale (VAE mid-block attention, un-fused). */
 int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream);

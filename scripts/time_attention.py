@@ -12,13 +12,18 @@ for (B, H, lq, lk, d) in [(16, 8, 4096, 4096, 40), (16, 8, 1024, 1024, 80), (16,
     ldv = (lk + 7) // 8 * 8
     vt = torch.randn(B, C, ldv, device=dev).half()
     out = torch.empty(B, lq, C, device=dev, dtype=torch.float16)
-    for _ in range(2):
-        ops.attention(q, k, vt, out, batch=B, heads=H, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=ldv, ldo=C, scale=d ** -0.5)
-    torch.cuda.synchronize()
-    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(10):
-        ops.attention(q, k, vt, out, batch=B, heads=H, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=ldv, ldo=C, scale=d ** -0.5)
-    e.record(); torch.cuda.synchronize()
-    ms = a.elapsed_time(e) / 10
-    print(f"attention B={B} H={H} lq={lq} lk={lk} d={d}: {ms*1e3:8.1f} us  {4*B*H*lq*lk*d/ms/1e9:7.1f} TF/s")
+    ldv = (lk + 15) // 16 * 16
+    vt = torch.randn(B, C, ldv, device=dev).half()
+    row = []
+    for perm in (False, True):
+        for _ in range(2):
+            ops.attention(q, k, vt, out, batch=B, heads=H, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=ldv, ldo=C, scale=d ** -0.5, vt_perm16=perm)
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            ops.attention(q, k, vt, out, batch=B, heads=H, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=ldv, ldo=C, scale=d ** -0.5, vt_perm16=perm)
+        e.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(e) / 10
+        row.append(f"{'perm16' if perm else 'plain '} {ms*1e3:8.1f} us {4*B*H*lq*lk*d/ms/1e9:7.1f} TF/s")
+    print(f"attention B={B} H={H} lq={lq} lk={lk} d={d}: " + " | ".join(row))

@@ -124,3 +124,20 @@ def test_optimisation_app_targets(golden, tricky):
             assert np.array_equal(ori, golden[f"{tag}_orientation_o{o_ref}_t{ti}"], equal_nan=True)
             assert np.array_equal(sel[0], golden[f"{tag}_selected_o{o_ref}_t{ti}"])
             assert np.array_equal(obj, golden[f"{tag}_objects_o{o_ref}_t{ti}"])
+
+
+def test_torch_cpu_port_agrees_with_the_pinned_numpy_oracle():
+    """oracle/coma_oracle_torch.py (bench.py's all-threads CPU baseline) against the NumPy oracle, which G1-G7 pin to the reference."""
+    from oracle import coma_oracle as orc
+    from oracle import coma_oracle_torch as ot
+    from tests.synth import make_samples
+    H, O, N = 40, 12, 250
+    a = orc.ComAOracle(H, O, N, 0.07, 0.03, sigma=0.25, eps=1e-10)
+    b = ot.ComATorch(H, O, N, 0.07, 0.03, sigma=0.25, eps=1e-10)
+    for smp in make_samples(H, O, 3, seed=3, thres=0.03):
+        a.aggregate_sample(**smp)
+        b.aggregate_sample(**smp)
+    assert np.array_equal(a.cnt, b.cnt.numpy()) and np.array_equal(a.den, b.den.numpy())
+    assert orc.max_rel_err(b.nom.numpy(), a.nom) <= 1e-5
+    assert orc.max_rel_err(b.P_h_wrt_o.numpy(), a.P_h_wrt_o) <= 1e-4 and orc.max_rel_err(b.P_o_wrt_h.numpy(), a.P_o_wrt_h) <= 1e-4
+    assert np.allclose(ot.fibonacci_sphere(250).numpy(), orc.fibonacci_sphere(250), rtol=0, atol=1e-15)

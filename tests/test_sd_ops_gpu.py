@@ -147,7 +147,31 @@ def test_attention(ops, heads, d, lq, lk):
     out = torch.empty(B, lq, C, dtype=F16, device=DEV)
     ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), out, batch=B, heads=heads, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=ldv, ldo=C,
                   scale=d**-0.5)
-    close(out, so.attention_ref(q, k, v, heads, d**-0.5), tol=4e-3)
+    ref = so.attention_ref(q, k, v, heads, d**-0.5)
+    close(out, ref, tol=4e-3)
+    # the key-permuted V^T layout (one 16-byte LDS read per MFMA operand) must give the same result
+    vp = ops.perm16_columns(v.transpose(1, 2).contiguous())
+    out2 = torch.empty(B, lq, C, dtype=F16, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), vp.to(DEV), out2, batch=B, heads=heads, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=vp.shape[-1], ldo=C,
+                  scale=d**-0.5, vt_perm16=True)
+    close(out2, ref, tol=4e-3)
+
+
+@pytest.mark.parametrize("L,C", [(200, 320), (77, 320), (64, 1280)])
+def test_v_transposed_projection_in_the_permuted_layout(ops, L, C):
+    """SD_EPI_PERM16_N: the batched V^T projection writes every group of 16 keys in the order (0-3, 8-11, 4-7, 12-15), rounded up
+    to whole groups; real keys land where ops.perm16_columns puts them, pad positions hold finite values."""
+    B = 2
+    x, wv = rnd(B, L, C, seed=1), rnd(C, C, seed=2, scale=C**-0.5)
+    ldv = (L + 15) // 16 * 16
+    out = torch.zeros(B, C, ldv, dtype=F16, device=DEV)
+    ops.conv_gemm(wv.to(DEV), x.to(DEV), out, batch=C, in_h=1, in_w=1, c0=C, n=L, epi=ops.EPI_PERM16_N, ldo=ldv, nbatch_z=B,
+                  stride_w=L * C, stride_out=C * ldv)
+    ref = ops.perm16_columns(torch.einsum("ck,blk->bcl", wv.float(), x.float()))
+    j = torch.arange(ldv)
+    real = ((j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)) < L          # positions whose source key exists
+    close(out[:, :, real], ref[:, :, real])
+    assert bool(torch.isfinite(out.float()).all())
 
 
 def test_attention_peaked_scores_force_the_rescale_path(ops):
