@@ -63,7 +63,13 @@ struct GemmArgs {
   int ksplit;                 // >1: blockIdx.z selects a K range and fp32 partials go to `partial`
   float* partial;             // [ksplit][M][N] fp32
   long long sa, sw, so, sr;   // per-blockIdx.z strides in elements (batched mode, ksplit == 1)
+  long long sln;              // ... of ln_stats, in floats
   unsigned long long* dbg;    // nullptr unless SD_GEMM_DBG is set
+  // LayerNorm folded into this GEMM (see sd_conv_gemm_desc): out = rstd * (acc - mean * colsum) + bias, statistics per A row
+  // (or per output column with SD_EPI_BIAS_ROWS: the normalised tensor is then the W operand)
+  const float* ln_stats;      // [rows][2] = (mean, rstd)
+  const float* ln_colsum;     // [N] (or [M] with SD_EPI_BIAS_ROWS): sum_k (gamma o W)[n, k]
+  float* rowstats;            // producer side: [M][N/32][2] per-row (sum, sum of squares) of every stored 32-column tile
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmArgs& g, int slot) {
@@ -85,8 +91,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (x < 0.0f ? e : 2.0f - e);
 }
 
-// Shared epilogue math: v = acc (+bias)(+per-batch bias) -> SiLU -> (+residual)
-__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int row, int col, const _Float16* resp) {
+__device__ __forceinline__ int kappa16(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
+
+// Shared epilogue math: v = acc (folded LayerNorm)(+bias)(+per-batch bias) -> SiLU -> (+residual)
+__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int row, int col, const _Float16* resp, const float* lnst) {
+  if (lnst) {
+    const bool by_col = (g.epi & SD_EPI_BIAS_ROWS) != 0;
+    const int si = by_col ? ((g.epi & SD_EPI_PERM16_N) ? min(kappa16(col), g.n_valid - 1) : col) : row;
+    v = lnst[2 * si + 1] * (v - lnst[2 * si] * g.ln_colsum[by_col ? row : col]);
+  }
   if (g.bias) v += (float)g.bias[(g.epi & SD_EPI_BIAS_ROWS) ? row : col];
   if (g.bias_bn) v += (float)g.bias_bn[(long long)(row / g.rows_per_batch) * g.ldbb + col];
   if (g.epi & SD_EPI_SILU) v = silu(v);
@@ -113,7 +126,9 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // Epilogue shared by every kernel of the family: acc[2][TN] (MFMA C layout, see below) -> bias / per-sample bias / SiLU /
 // residual / GEGLU / GroupNorm column statistics -> fp16 output (or fp32 split-K slab), staged through LDS per wave.
-template <int WM, int WN, int TN, int TM>
+// LNX = true: the variant for GEMMs that fold a LayerNorm (ln_stats) or leave row statistics for one (rowstats); it carries no
+// GroupNorm column statistics, and vice versa -- the two sets of live registers never have to fit next to the accumulators together.
+template <int WM, int WN, int TN, int TM, bool LNX>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)[TM][TN], _Float16* lds, const int m0, const int n0,
                                               const int wave, const int lane, const long long z, const bool split) {
   constexpr int EP_STRIDE = 32 + 4;                 // floats per staged row (one 32x32 MFMA tile per wave at a time)
@@ -147,8 +162,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
   }
   _Float16* outp = g.out + z * g.so;
   const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
+  const float* lnst = g.ln_stats ? g.ln_stats + z * g.sln : nullptr;
   const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
-  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS) &&
+  // (a per-row bias is only vectorised in the LNX variant, where V^T = Wv . LN(x)^T needs it; elsewhere it takes the generic path)
+  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && ((LNX && TN <= 2) || !(g.epi & SD_EPI_BIAS_ROWS)) &&
                       (!g.bias_bn || (g.rows_per_batch % 32 == 0 && g.ldbb % 8 == 0));
   // read-back role: 32 rows x 4 chunks of 8 columns = 128 items, two per lane; the column chunk is fixed per lane
   const int cl = (lane & 3) * 8;
@@ -171,12 +188,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int mbase = m0 + wr * (TM * 32) + i * 32;
+          float ln_mu = 0.0f, ln_r = 1.0f;                       // folded LayerNorm: this lane's row of the tile
+          if (LNX && g.ln_stats) {
+            const int rr = min(mbase + lrow, g.M - 1);
+            ln_mu = lnst[2 * rr];
+            ln_r = lnst[2 * rr + 1];
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              o[e] = (acc[i][2 * p][4 * q + e] + bv[q][e]) * gelu_erf(acc[i][2 * p + 1][4 * q + e] + bg[q][e]);
+            for (int e = 0; e < 4; ++e) {
+              float av = acc[i][2 * p][4 * q + e], ag = acc[i][2 * p + 1][4 * q + e];
+              if (LNX && g.ln_stats) {
+                const int c = ncol0 + 8 * q + 4 * hh + e;
+                av = ln_r * (av - ln_mu * g.ln_colsum[c]);
+                ag = ln_r * (ag - ln_mu * g.ln_colsum[c + 32]);
+              }
+              o[e] = (av + bv[q][e]) * gelu_erf(ag + bg[q][e]);
+            }
             *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
           }
           __builtin_amdgcn_wave_barrier();
@@ -246,7 +276,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
     for (int j = 0; j < TN; ++j) {
       half8 bcol = {0, 0, 0, 0, 0, 0, 0, 0};                        // kept packed: registers are scarce next to 32 * TN accumulators
       const bool oob = colbase + j * 32 + 8 > g.N;                // column chunk of this lane beyond N: loads give 0, stores are dropped
-      if (g.bias && !oob) bcol = *reinterpret_cast<const half8*>(g.bias + colbase + j * 32);
+      const bool row_bias = LNX && TN <= 2 && (g.epi & SD_EPI_BIAS_ROWS);   // (batched V^T projections only ever pick the 128-wide tiles)
+      if (g.bias && !oob && !row_bias) bcol = *reinterpret_cast<const half8*>(g.bias + colbase + j * 32);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int t = TM * j + i;
@@ -267,8 +298,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
           const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
           const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
           float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+          if (LNX && g.ln_stats && row_bias) {
+            // the normalised tensor is the W operand (V^T = Wv . LN(x)^T): statistics per output column (= key; with
+            // SD_EPI_PERM16_N column j holds key kappa(j): the 8 columns of this lane are two runs of 4 keys), colsum per row
+            const int rr = min(rowbase + 16 * k + 32 * i, g.M - 1);
+            const float srow = g.ln_colsum[rr];
+            const int c0 = colbase + j * 32;
+            int k0 = c0, k1 = c0 + 4;
+            if (g.epi & SD_EPI_PERM16_N) { k0 = (c0 & ~15) + ((c0 & 8) ? 4 : 0); k1 = k0 + 8; }
+            float2 stc[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              stc[e] = *reinterpret_cast<const float2*>(lnst + 2 * min(k0 + e, g.n_valid - 1));
+              stc[4 + e] = *reinterpret_cast<const float2*>(lnst + 2 * min(k1 + e, g.n_valid - 1));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = stc[e].y * (v[e] - stc[e].x * srow);
+          } else if (LNX && g.ln_stats) {                         // folded LayerNorm of the A operand
+            const int rr = min(rowbase + 16 * k + 32 * i, g.M - 1);
+            const float2 st = *reinterpret_cast<const float2*>(lnst + 2 * rr);
+            const float4 s0 = oob ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32);
+            const float4 s1 = oob ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32 + 4);
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = st.y * (v[e] - st.x * sc[e]);
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)bcol[e];
+          if (row_bias && g.bias) {
+            const float br = (float)g.bias[min(rowbase + 16 * k + 32 * i, g.M - 1)];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += br;
+          }
           if (g.bias_bn) {
             const half8 tb = __builtin_bit_cast(half8, pf[t][0]);
 #pragma unroll
@@ -287,7 +348,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rsrc, oob ? (int)0x80000000 : voff_out[k], soff_out, 0);
-          if (g.colstats && !oob && m0 + wr * (TM * 32) + i * 32 + rl < g.M) {
+          if (LNX && g.rowstats) {
+            // statistics of the consumer's LayerNorm: (sum, sum of squares) of this row over the 32 columns of the tile, from
+            // the stored (fp16-rounded) values; the four lanes of a row fold by two quad permutes, lane & 3 == 0 writes
+            float rs = 0.0f, rq = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)o[e];
+              rs += f;
+              rq += f * f;
+            }
+            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0xb1, 0xf, 0xf, false));
+            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x4e, 0xf, 0xf, false));
+            const int row = rowbase + 16 * k + 32 * i;
+            if ((lane & 3) == 0 && row < g.M && colbase + j * 32 < g.N)
+              *reinterpret_cast<float2*>(g.rowstats + ((long long)row * (g.N >> 5) + ((colbase + j * 32) >> 5)) * 2) = make_float2(rs, rq);
+          }
+          if (!LNX && g.colstats && !oob && m0 + wr * (TM * 32) + i * 32 + rl < g.M) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float f = (float)o[e];     // statistics of the stored (fp16-rounded) tensor, as a GroupNorm pass would see it
@@ -296,7 +375,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
             }
           }
         }
-        if (g.colstats) {
+        if (!LNX && g.colstats) {
           // fold the 16 lanes that share a column chunk (lane & 3 fixed), fixed order -> reproducible: lanes +4, +8, +12 of
           // the 16-lane row by two DPP row rotations (VALU speed), then the four rows by two cross-lane exchanges
 #pragma unroll
@@ -382,7 +461,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
         } else {
           for (int e = 0; e < 8; ++e)
             if (col + e < g.N)
-              outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp);
+              outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp, lnst);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -400,7 +479,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
 //        cycles per wave instruction and NOT overlapped with MFMA issue, the limiter of the 128 x 128 tile (0.5 DMA per
 //        MFMA) -- drops to 0.225 DMA per MFMA.
 //   <WM=2, WN=1/2, ...> 64-wide fallbacks for small N.
-template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false, int TM = 2>
+template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false, int TM = 2, bool LNX = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per block
   constexpr int BM_ = WM * TM * 32, BN = WN * TN * 32;
@@ -489,7 +568,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   for (int j = 0; j < B_LD; ++j) {
     const int r = (wave * B_LD + j) * RPI + l_row;
     int nn = n0 + r;
-    if (g.epi & SD_EPI_PERM16_N) nn = (nn & ~12) | ((nn & 4) << 1) | ((nn & 8) >> 1);   // output column j <- W row with bits 2, 3 of j swapped
+    if (g.epi & SD_EPI_PERM16_N) nn = kappa16(nn);   // output column j <- W row with bits 2, 3 of j swapped
     const int n = min(nn, g.n_valid - 1);
     b_off[j] = (unsigned)(n * g.K) * 2u + swz<BK>(r, l_slot) * 16;
   }
@@ -629,7 +708,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   }
   dbg_stamp(g, 2);
 
-  gemm_epilogue<WM, WN, TN, TM>(g, acc, lds, m0, n0, wave, lane, z, split);
+  gemm_epilogue<WM, WN, TN, TM, LNX>(g, acc, lds, m0, n0, wave, lane, z, split);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   dbg_stamp(g, 3);
 }
@@ -651,7 +730,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
   half8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (_Float16)epilogue_value(g, v[j], row, col0 + j, g.res);
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)epilogue_value(g, v[j], row, col0 + j, g.res, g.ln_stats);
   *reinterpret_cast<half8*>(g.out + (long long)row * g.ldo + col0) = o;
 }
 
@@ -742,6 +821,13 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (dbg_on) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dbg_stamps)) == hipSuccess) g.dbg = (unsigned long long*)p; }
   g.partial = (float*)d->workspace;
   g.colstats = (float*)d->colstats;
+  g.ln_stats = d->ln_stats; g.ln_colsum = d->ln_colsum; g.rowstats = d->rowstats; g.sln = d->stride_ln_stats;
+  if ((g.ln_stats == nullptr) != (g.ln_colsum == nullptr)) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: ln_stats and ln_colsum come together");
+  if (g.ln_stats && (d->bias_bn || d->colstats || d->c1 > 0 || d->taps != 1))
+    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a folded LayerNorm needs a single-source 1x1 / linear GEMM without per-sample bias / colstats");
+  if (g.rowstats && (geglu || nz != 1 || d->n % 32 || (d->epi & (SD_EPI_BIAS_ROWS | SD_EPI_PERM16_N)) || d->bias_bn || g.ldo % 8 || (g.res && g.ldr % 8) ||
+                     (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL || (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
+    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: rowstats needs N %% 32 == 0, 16-byte aligned rows, < 2 GiB tensors, no GEGLU / batching / row bias");
   if (g.colstats && (geglu || nz != 1 || g.M % 32 || g.N % 8 || (d->epi & SD_EPI_BIAS_ROWS) || g.ldo % 8 || (g.res && g.ldr % 8) ||
                      (g.bias_bn && (g.res || g.rows_per_batch % 32 || g.ldbb % 8)) || (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL ||
                      (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
@@ -749,7 +835,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
-  if (!g.colstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
+  if (!g.colstats && !g.rowstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)(512 / blocks);
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;
@@ -763,19 +849,26 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   dim3 grid((unsigned)lin_blocks, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
   hipStream_t st = (hipStream_t)stream;
   const bool spread = !(d->epi & (1 << 22));   // tuning knob: DMA issued in one burst instead of spread over the K steps
-  if (big && spread) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2, true>), grid, dim3(512), 0, st, g);
-  else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2, true>), grid, dim3(256), 0, st, g);
-  else if (big) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2>), grid, dim3(512), 0, st, g);
-  else if ((big_geglu || big256) && spread) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2, true>), grid, dim3(512), 0, st, g);
-  else if (big_geglu || big256) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 4, 64, 2>), grid, dim3(512), 0, st, g);
-  else if (tall128) hipLaunchKernelGGL((conv_gemm_kernel<8, 1, 4, 32, 3>), grid, dim3(512), 0, st, g);
-  else if (big128) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 2, 64, 2>), grid, dim3(512), 0, st, g);
-  else if (mid8) hipLaunchKernelGGL((conv_gemm_kernel<4, 2, 5, 64, 2, true, 1>), grid, dim3(512), 0, st, g);
-  else if (mid) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 5, 32, 3>), grid, dim3(256), 0, st, g);
-  else if (wide && deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 64, 2>), grid, dim3(256), 0, st, g);
-  else if (wide) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 2, 32, 4>), grid, dim3(256), 0, st, g);
-  else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 64, 2>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((conv_gemm_kernel<2, 2, 1, 32, 4>), grid, dim3(256), 0, st, g);
+#define GEMM_LAUNCH(WM_, WN_, TN_, BK_, ST_, SP_, TM_, THREADS_)                                                                  \
+  do {                                                                                                                           \
+    if (lnx) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, true>), grid, dim3(THREADS_), 0, st, g);    \
+    else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, false>), grid, dim3(THREADS_), 0, st, g);       \
+  } while (0)
+  const bool lnx = g.ln_stats != nullptr || g.rowstats != nullptr;
+  if (big && spread) GEMM_LAUNCH(4, 2, 5, 64, 2, true, 2, 512);
+  else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) GEMM_LAUNCH(2, 2, 2, 64, 2, true, 2, 256);
+  else if (big) GEMM_LAUNCH(4, 2, 5, 64, 2, false, 2, 512);
+  else if ((big_geglu || big256) && spread) GEMM_LAUNCH(4, 2, 4, 64, 2, true, 2, 512);
+  else if (big_geglu || big256) GEMM_LAUNCH(4, 2, 4, 64, 2, false, 2, 512);
+  else if (tall128) GEMM_LAUNCH(8, 1, 4, 32, 3, false, 2, 512);
+  else if (big128) GEMM_LAUNCH(4, 2, 2, 64, 2, false, 2, 512);
+  else if (mid8) GEMM_LAUNCH(4, 2, 5, 64, 2, true, 1, 512);
+  else if (mid) GEMM_LAUNCH(2, 2, 5, 32, 3, false, 2, 256);
+  else if (wide && deep) GEMM_LAUNCH(2, 2, 2, 64, 2, false, 2, 256);
+  else if (wide) GEMM_LAUNCH(2, 2, 2, 32, 4, false, 2, 256);
+  else if (deep) GEMM_LAUNCH(2, 2, 1, 64, 2, false, 2, 256);
+  else GEMM_LAUNCH(2, 2, 1, 32, 4, false, 2, 256);
+#undef GEMM_LAUNCH
   if (g.ksplit > 1) {
     const long long n8 = (long long)g.M * (g.N / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, g);

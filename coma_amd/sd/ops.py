@@ -19,7 +19,8 @@ class ConvGemmDesc(C.Structure):
                 ("w", C.c_void_p), ("bias", C.c_void_p), ("bias_bn", C.c_void_p), ("ldbb", C.c_int), ("res", C.c_void_p), ("ldr", C.c_int),
                 ("out", C.c_void_p), ("ldo", C.c_int), ("epi", C.c_int), ("nbatch_z", C.c_int),
                 ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colstats", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colstats", C.c_void_p),
+                ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("stride_ln_stats", C.c_int64), ("rowstats", C.c_void_p)]
 
 
 def _p(t, name="tensor", dtype=F16):
@@ -34,7 +35,7 @@ def _stream(t):
 
 def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a1=None, c1=0, taps=1, stride=1, upsample=0,
               pad=1, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, epi=EPI_NONE, nbatch_z=1, stride_a=0, stride_w=0,
-              stride_out=0, stride_res=0, workspace=None, colstats=None):
+              stride_out=0, stride_res=0, workspace=None, colstats=None, ln_stats=None, ln_colsum=None, stride_ln_stats=0, rowstats=None):
     d = ConvGemmDesc()
     d.a0, d.a1, d.c0, d.c1 = _p(a0, "a0"), _p(a1, "a1"), c0, c1
     d.batch, d.in_h, d.in_w = batch, in_h, in_w
@@ -49,6 +50,11 @@ def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a
         d.workspace, d.workspace_bytes = _p(workspace, "workspace", torch.float32), workspace.numel() * 4
     if colstats is not None:
         d.colstats = _p(colstats, "colstats", torch.float32)
+    if ln_stats is not None:
+        d.ln_stats, d.ln_colsum = _p(ln_stats, "ln_stats", torch.float32), _p(ln_colsum, "ln_colsum", torch.float32)
+        d.stride_ln_stats = stride_ln_stats
+    if rowstats is not None:
+        d.rowstats = _p(rowstats, "rowstats", torch.float32)
     _lib.check(_lib.lib().sd_conv_gemm_f16(C.byref(d), _stream(out)), "sd_conv_gemm_f16")
     return out
 
@@ -77,6 +83,12 @@ def groupnorm_colstats(x0, gamma, beta, out, stats, colstats0, *, batch, hw, c0,
 
 def gn_scratch_floats(batch, hw, groups=32, channels=2560):
     return batch * channels * 2 + batch * groups * 2 * ((hw + 63) // 64)
+
+
+def ln_rowstats_finalize(partial, stats, *, rows, c, eps=1e-5):
+    _lib.check(_lib.lib().sd_ln_rowstats_finalize(_p(partial, "partial", torch.float32), rows, c // 32, c, eps, _p(stats, "stats", torch.float32),
+                                                  _stream(stats)), "sd_ln_rowstats_finalize")
+    return stats
 
 
 def layernorm(x, gamma, beta, out, *, rows, c, eps=1e-5):

@@ -12,7 +12,10 @@ concatenation -> GroupNorm/SiLU -> conv_out.  Fusions done here, none of which c
   * Q and K projections are one GEMM; V is produced transposed by swapping the GEMM operands (what the
     attention kernel wants), so there is no transpose or head-split copy anywhere;
   * nearest-x2 upsampling and stride-2 downsampling are index arithmetic inside the conv's operand gather;
-  * cross-attention K/V of the text context are computed once per prompt, not once per step.
+  * cross-attention K/V of the text context are computed once per prompt, not once per step;
+  * (fold_layernorm=True, off by default) the three LayerNorms of a transformer block folded algebraically into the GEMMs that
+    consume them, row statistics from the producing GEMM's epilogue: exact and tested, but measured 0.67 ms SLOWER per forward
+    on MI355X than the LayerNorm kernel (profiles/r02_notes.md) -- the epilogue loads it adds cost more than the pass it removes.
 """
 from __future__ import annotations
 
@@ -20,7 +23,7 @@ import torch
 
 from . import ops
 from .graph import F16, LaunchGraph
-from .weights import UNET_CFG, conv_weight, geglu_interleave, pad_vec
+from .weights import UNET_CFG, conv_weight, geglu_interleave, ln_fold, pad_vec
 
 
 class _Cfg(dict):
@@ -29,7 +32,7 @@ class _Cfg(dict):
 
 class HipUNet2DConditionModel:
     def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
-                 cfg_shared_prefix=False):
+                 cfg_shared_prefix=False, fold_layernorm=False):
         """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
         (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
         Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
@@ -41,6 +44,8 @@ class HipUNet2DConditionModel:
         self.heads = cfg["heads"]
         self.ctx_dim = cfg["cross_attention_dim"]
         self.use_graph = use_graph
+        self.fold_layernorm = fold_layernorm
+        self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
         self.dtype = F16
@@ -156,25 +161,38 @@ class HipUNet2DConditionModel:
         g, s, B, heads = self.g, self.s, self._B, self.heads
         L, M, d = H * W, B * H * W, C // heads
         t = p + ".transformer_blocks.0"
+        # The three LayerNorms are folded into the GEMMs that consume them (weights.ln_fold): their inputs' row statistics
+        # come out of the producing GEMM's epilogue, (mean, rstd) from a tiny finalise launch, and the normalised tensors are
+        # never written.  Tiny feature maps keep the LayerNorm kernel: their producers want split-K, which has no statistics.
+        fold = self.fold_layernorm and M >= self.fold_min_rows
         gn = g.buf(M, C)
         g.groupnorm(x, s[p + ".norm.weight"], s[p + ".norm.bias"], gn, batch=B, hw=L, c0=C, eps=1e-6, silu=False)
         h = g.buf(M, C)
-        g.conv(gn, conv_weight(s[p + ".proj_in.weight"]), h, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".proj_in.bias"])
+        g.conv(gn, conv_weight(s[p + ".proj_in.weight"]), h, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".proj_in.bias"], rowstats=fold)
         # ---- self attention
-        n1 = g.buf(M, C)
-        g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
         wqk = torch.cat([s[t + ".attn1.to_q.weight"], s[t + ".attn1.to_k.weight"]]).contiguous()
+        wv = s[t + ".attn1.to_v.weight"]
         qk = g.buf(M, 2 * C)
-        g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
         ldv = (L + 15) // 16 * 16
         vt = g.buf(B, C, ldv, zero=True)         # V^T with the keys of every 16 in the order the attention kernel's MFMA operand wants
-        g.conv(s[t + ".attn1.to_v.weight"], n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C,
-               stride_out=C * ldv, epi=ops.EPI_PERM16_N)
+        if fold:
+            st = g.ln_stats(h, rows=M, c=C)
+            wqk_f, sqk, tqk = ln_fold(wqk, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
+            g.conv(h, wqk_f, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C, bias=tqk, ln_stats=st, ln_colsum=sqk)
+            wv_f, sv, tv = ln_fold(wv, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
+            g.conv(wv_f, h, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv, bias=tv,
+                   epi=ops.EPI_PERM16_N | ops.EPI_BIAS_ROWS, ln_stats=st, ln_colsum=sv, stride_ln_stats=2 * L)   # statistics per key
+        else:
+            n1 = g.buf(M, C)
+            g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
+            g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
+            g.conv(wv, n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
+                   epi=ops.EPI_PERM16_N)
         a = g.buf(M, C)
         g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C, vt_perm16=True)
         h1 = g.buf(M, C)
         g.conv(a, s[t + ".attn1.to_out.0.weight"], h1, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[t + ".attn1.to_out.0.bias"],
-               res=h)
+               res=h, rowstats=fold)
         if B != self.batch:
             # end of the shared CFG prefix: from the first cross-attention on the two halves differ
             B = self._B = self.batch
@@ -182,10 +200,14 @@ class HipUNet2DConditionModel:
             h1 = g.dup(h1, g.buf(M, C))
             x = g.dup(x, g.buf(M, C))
         # ---- cross attention (K, V^T of the context live in the per-prompt graph)
-        n2 = g.buf(M, C)
-        g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)
         q2 = g.buf(M, C)
-        g.conv(n2, s[t + ".attn2.to_q.weight"], q2, batch=M, in_h=1, in_w=1, c0=C, n=C)
+        if fold:
+            wq2_f, sq2, tq2 = ln_fold(s[t + ".attn2.to_q.weight"], s[t + ".norm2.weight"], s[t + ".norm2.bias"])
+            g.conv(h1, wq2_f, q2, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=tq2, ln_stats=g.ln_stats(h1, rows=M, c=C), ln_colsum=sq2)
+        else:
+            n2 = g.buf(M, C)
+            g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)
+            g.conv(n2, s[t + ".attn2.to_q.weight"], q2, batch=M, in_h=1, in_w=1, c0=C, n=C)
         Lk, cd = self.ctx_len, self.ctx_dim
         k2 = self.gc.buf(B * Lk, C)
         self.gc.conv(self.ctx, s[t + ".attn2.to_k.weight"], k2, batch=B * Lk, in_h=1, in_w=1, c0=cd, n=C)
@@ -197,13 +219,18 @@ class HipUNet2DConditionModel:
         g.attention(q2, k2, vt2, a2, batch=B, heads=heads, lq=L, lk=Lk, d=d, ldq=C, ldk=C, ldv=ldv2, ldo=C, vt_perm16=True)
         h2 = g.buf(M, C)
         g.conv(a2, s[t + ".attn2.to_out.0.weight"], h2, batch=M, in_h=1, in_w=1, c0=C, n=C,
-               bias=s[t + ".attn2.to_out.0.bias"], res=h1)
+               bias=s[t + ".attn2.to_out.0.bias"], res=h1, rowstats=fold)
         # ---- feed-forward (GEGLU)
-        n3 = g.buf(M, C)
-        g.layernorm(h2, s[t + ".norm3.weight"], s[t + ".norm3.bias"], n3, rows=M, c=C)
         wff, bff = geglu_interleave(s[t + ".ff.net.0.proj.weight"], s[t + ".ff.net.0.proj.bias"])
         f = g.buf(M, 4 * C)
-        g.conv(n3, wff, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=bff, epi=ops.EPI_GEGLU)
+        if fold:
+            wff_f, sff, tff = ln_fold(wff, s[t + ".norm3.weight"], s[t + ".norm3.bias"], bff)
+            g.conv(h2, wff_f, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=tff, epi=ops.EPI_GEGLU, ln_stats=g.ln_stats(h2, rows=M, c=C),
+                   ln_colsum=sff)
+        else:
+            n3 = g.buf(M, C)
+            g.layernorm(h2, s[t + ".norm3.weight"], s[t + ".norm3.bias"], n3, rows=M, c=C)
+            g.conv(n3, wff, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=bff, epi=ops.EPI_GEGLU)
         h3 = g.buf(M, C)
         g.conv(f, s[t + ".ff.net.2.weight"], h3, batch=M, in_h=1, in_w=1, c0=4 * C, n=C, bias=s[t + ".ff.net.2.bias"], res=h2)
         out = g.buf(M, C)

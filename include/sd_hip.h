@@ -66,6 +66,16 @@ typedef struct sd_conv_gemm_desc {
   size_t workspace_bytes;
   float* colstats;      /* optional fp32 [M/32][2][n]: per 32-row block, column sums and sums of squares of the stored output
                            (the GroupNorm statistics of the consumer, sd_groupnorm_colstats_f16 colstats0/1); needs M % 32 == 0 */
+  /* LayerNorm folded into the GEMM that consumes it (BasicTransformerBlock norm1/2/3 -> to_q/to_k/to_v/ff.net.0): with
+   * w' = gamma o w, colsum[n] = sum_k w'[n,k] (fp32, of the fp16-rounded w'), bias' = w . beta + bias,
+   *   out[m,n] = rstd[m] * (sum_k x[m,k] w'[n,k] - mean[m] * colsum[n]) + bias'[n]  ==  LayerNorm(x)[m,:] . w[n,:] + bias[n]
+   * so the normalised tensor is never written or re-read.  With SD_EPI_BIAS_ROWS (the normalised tensor is the W operand:
+   * V^T = Wv . LN(x)^T) the statistics are indexed by output column and colsum by output row. */
+  const float* ln_stats;   /* fp32 [rows][2] = (mean, rstd) per row of the normalised operand (sd_ln_rowstats_finalize), or NULL */
+  const float* ln_colsum;  /* fp32 [n] (or [M] with SD_EPI_BIAS_ROWS) */
+  int64_t stride_ln_stats; /* floats between the ln_stats of consecutive z problems (nbatch_z > 1) */
+  float* rowstats;         /* optional fp32 [M][n/32][2]: per row and 32-column tile the sum and sum of squares of the stored output --
+                              the raw material of the consumer's LayerNorm statistics; n % 32 == 0, no split-K */
 } sd_conv_gemm_desc;
 
 int sd_conv_gemm_f16(const sd_conv_gemm_desc* desc, void* stream);
@@ -86,6 +96,10 @@ int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, 
 int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                               const void* gamma, const void* beta, int silu, void* out, float* stats, const float* colstats0,
                               const float* colstats1, void* stream);
+
+/* (mean, rstd) of every row from the producer's per-tile partial sums: partial fp32 [rows][parts][2] (sd_conv_gemm_desc.rowstats,
+ * parts = c / 32) -> stats fp32 [rows][2].  replaces the statistics half of nn.LayerNorm(c, eps) in BasicTransformerBlock. */
+int sd_ln_rowstats_finalize(const float* partial, int64_t rows, int parts, int c, float eps, float* stats, void* stream);
 
 /* LayerNorm over the last dim of fp16 [rows, c].  replaces: nn.LayerNorm(C) in BasicTransformerBlock. */
 int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* gamma, const void* beta, void* out,

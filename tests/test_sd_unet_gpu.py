@@ -107,10 +107,36 @@ def test_unet_benchmark_shape_matches_fp32_reference(setup):
     t = torch.full((B,), 621.0)
     unet = UNet(state, batch=B, height=hw, width=hw, device=DEV, use_graph=True)
     out = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0].clone()
+    del unet
+    folded = UNet(state, batch=B, height=hw, width=hw, device=DEV, use_graph=True, fold_layernorm=True)      # the optional LayerNorm fold, same bar
+    out_f = folded(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0].clone()
+    del folded
+    torch.cuda.empty_cache()
     ref = torch.cat([so.unet_ref(state, sample[i:i + 4], t[i:i + 4], ctx[i:i + 4], weights.UNET_CFG) for i in range(0, B, 4)])
     rel, cos = _metrics(out, ref)
     assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    rel, cos = _metrics(out_f, ref)
+    assert rel <= 2e-2 and cos >= 0.999, ("folded", rel, cos)
     # per-sample: no sample may hide behind the batch average (a wrong tile shows up as one bad image)
     for i in range(B):
         r, c = _metrics(out[i], ref[i])
         assert r <= 3e-2 and c >= 0.999, (i, r, c)
+
+
+def test_layernorm_fold_equals_the_unfused_graph(setup):
+    """The folded LayerNorms (row statistics from the producers' epilogues, algebraic fold into QK / V^T / q / GEGLU) against the
+    graph that runs the LayerNorm kernel, at a size the fp32 oracle also checks: equal up to fp16 rounding, both within tolerance."""
+    state, sample, ctx, t, ref, UNet = setup
+    outs = []
+    for fold in (False, True):
+        unet = UNet(state, batch=2, height=16, width=16, device=DEV, use_graph=True, fold_layernorm=fold)
+        unet.fold_min_rows = 0
+        unet.g = type(unet.g)(unet.device); unet.gc = type(unet.gc)(unet.device)      # rebuild with the threshold lifted
+        unet.x_in = unet.g.buf(2, 256, 64, zero=True); unet.timesteps = unet.g.buf(2, dtype=torch.float32, zero=True)
+        unet.ctx = unet.g.buf(2, 77, unet.ctx_dim, zero=True); unet._B = 2
+        unet._build()
+        assert any("ln_stats" in tag for tag, _ in unet.g.tags) == fold and any("layernorm" in tag for tag, _ in unet.g.tags) != fold
+        outs.append(unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0].clone())
+        rel, cos = _metrics(outs[-1], ref)
+        assert rel <= 2e-2 and cos >= 0.999, (fold, rel, cos)
+    assert float((outs[0] - outs[1]).abs().max()) <= 2e-2 * float(outs[0].abs().max())
