@@ -69,7 +69,7 @@ struct GemmArgs {
   // (or per output column with SD_EPI_BIAS_ROWS: the normalised tensor is then the W operand)
   const float* ln_stats;      // [rows][2] = (mean, rstd)
   const float* ln_colsum;     // [N] (or [M] with SD_EPI_BIAS_ROWS): sum_k (gamma o W)[n, k]
-  float* rowstats;            // producer side: [M][N/32][2] per-row (sum, sum of squares) of every stored 32-column tile
+  float* rowstats;            // producer side: [N/32][M][2] per-row (sum, sum of squares) of every stored 32-column tile
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmArgs& g, int slot) {
@@ -176,15 +176,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
       for (int p = 0; p < TN / 2; ++p) {
         const int ncol0 = n0 + wc * (TN * 32) + p * 64;        // permuted value columns [ncol0, +32), gates [+32, +64)
         const int ocol0 = (ncol0 >> 1);
+        // bias (and, with a folded LayerNorm, the column sums) of this lane's 16 value / 16 gate columns: 8-byte / 16-byte loads
         float bv[4][4], bg[4][4];
+        float4 sv[4], sg[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+          const int c = ncol0 + 8 * q + 4 * hh;
+          half4 hv = {0, 0, 0, 0}, hg = {0, 0, 0, 0};
+          if (g.bias) { hv = *reinterpret_cast<const half4*>(g.bias + c); hg = *reinterpret_cast<const half4*>(g.bias + c + 32); }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = ncol0 + 8 * q + 4 * hh + e;
-            bv[q][e] = g.bias ? (float)g.bias[c] : 0.0f;
-            bg[q][e] = g.bias ? (float)g.bias[c + 32] : 0.0f;
-          }
+          for (int e = 0; e < 4; ++e) { bv[q][e] = (float)hv[e]; bg[q][e] = (float)hg[e]; }
+          if (LNX && g.ln_stats) { sv[q] = *reinterpret_cast<const float4*>(g.ln_colsum + c); sg[q] = *reinterpret_cast<const float4*>(g.ln_colsum + c + 32); }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int mbase = m0 + wr * (TM * 32) + i * 32;
@@ -201,9 +204,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
             for (int e = 0; e < 4; ++e) {
               float av = acc[i][2 * p][4 * q + e], ag = acc[i][2 * p + 1][4 * q + e];
               if (LNX && g.ln_stats) {
-                const int c = ncol0 + 8 * q + 4 * hh + e;
-                av = ln_r * (av - ln_mu * g.ln_colsum[c]);
-                ag = ln_r * (ag - ln_mu * g.ln_colsum[c + 32]);
+                const float cv = e == 0 ? sv[q].x : e == 1 ? sv[q].y : e == 2 ? sv[q].z : sv[q].w;
+                const float cg = e == 0 ? sg[q].x : e == 1 ? sg[q].y : e == 2 ? sg[q].z : sg[q].w;
+                av = ln_r * (av - ln_mu * cv);
+                ag = ln_r * (ag - ln_mu * cg);
               }
               o[e] = (av + bv[q][e]) * gelu_erf(ag + bg[q][e]);
             }
@@ -233,7 +237,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
   // 32-bit row offset per lane for the whole epilogue, the tile position in the scalar offset, rows >= M dropped by the
   // range check -- no 64-bit address arithmetic and few live registers next to the 32 * TN accumulators.
   constexpr int NT = TM * TN;                           // 32 x 32 tiles of this wave, j-major (column tile), i-minor
-  constexpr int DEPTH = NT <= 4 ? NT : (TN >= 5 ? 2 : 4);
+  constexpr int DEPTH = NT <= 4 ? NT : (TN >= 5 ? (LNX && TM >= 2 ? 1 : 2) : 4);
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   auto rsrc_of = [](const void* p, long long bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -257,6 +261,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
       voff_out[k] = ((rowbase + 16 * k) * g.ldo + colbase) * 2;
       voff_pre[k] = ((rowbase + 16 * k) * ld_pre + colbase) * 2;
     }
+    float2 lnrow[TM][2];                                         // folded LayerNorm: (mean, rstd) of this lane's rows (j-invariant)
+    if (LNX && lnst && !(g.epi & SD_EPI_BIAS_ROWS)) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) lnrow[i][k] = *reinterpret_cast<const float2*>(lnst + 2 * min(rowbase + 16 * k + 32 * i, g.M - 1));
+    }
     u32x4 pf[NT][2];                                             // residual rows (k = 0, 1) or, in [0], the per-sample bias
     auto prefetch = [&](const int t) {
       const int j = t / TM, i = t % TM;
@@ -278,6 +289,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
       const bool oob = colbase + j * 32 + 8 > g.N;                // column chunk of this lane beyond N: loads give 0, stores are dropped
       const bool row_bias = LNX && TN <= 2 && (g.epi & SD_EPI_BIAS_ROWS);   // (batched V^T projections only ever pick the 128-wide tiles)
       if (g.bias && !oob && !row_bias) bcol = *reinterpret_cast<const half8*>(g.bias + colbase + j * 32);
+      float4 lnc0 = make_float4(0, 0, 0, 0), lnc1 = lnc0;        // column sums of the folded LayerNorm for this column tile
+      if (LNX && lnst && !row_bias && !oob) {
+        lnc0 = *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32);
+        lnc1 = *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32 + 4);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int t = TM * j + i;
@@ -315,11 +331,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = stc[e].y * (v[e] - stc[e].x * srow);
           } else if (LNX && g.ln_stats) {                         // folded LayerNorm of the A operand
-            const int rr = min(rowbase + 16 * k + 32 * i, g.M - 1);
-            const float2 st = *reinterpret_cast<const float2*>(lnst + 2 * rr);
-            const float4 s0 = oob ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32);
-            const float4 s1 = oob ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32 + 4);
-            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float2 st = lnrow[i][k];
+            const float sc[8] = {lnc0.x, lnc0.y, lnc0.z, lnc0.w, lnc1.x, lnc1.y, lnc1.z, lnc1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = st.y * (v[e] - st.x * sc[e]);
           }
@@ -364,7 +377,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
             rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x4e, 0xf, 0xf, false));
             const int row = rowbase + 16 * k + 32 * i;
             if ((lane & 3) == 0 && row < g.M && colbase + j * 32 < g.N)
-              *reinterpret_cast<float2*>(g.rowstats + ((long long)row * (g.N >> 5) + ((colbase + j * 32) >> 5)) * 2) = make_float2(rs, rq);
+              *reinterpret_cast<float2*>(g.rowstats + ((long long)((colbase + j * 32) >> 5) * g.M + row) * 2) = make_float2(rs, rq);
           }
           if (!LNX && g.colstats && !oob && m0 + wr * (TM * 32) + i * 32 + rl < g.M) {
 #pragma unroll

@@ -372,15 +372,21 @@ extern "C" int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale,
 }
 
 namespace sd {
-// (mean, rstd) per row from the [rows][parts][2] partial sums the producing GEMM left behind (fixed summation order)
+// (mean, rstd) per row from the [parts][rows][2] partial sums the producing GEMM left behind (fixed summation order)
 __global__ __launch_bounds__(256) void ln_rowstats_finalize_kernel(const float* __restrict__ partial, long long rows, int parts, float inv_c,
                                                                    float eps, float* __restrict__ stats) {
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
   if (r >= rows) return;
-  const float2* p = reinterpret_cast<const float2*>(partial) + r * parts;
+  const float2* p = reinterpret_cast<const float2*>(partial) + r;      // [parts][rows]: neighbouring threads read neighbouring rows
   float s = 0.0f, q = 0.0f;
-  for (int i = 0; i < parts; ++i) {
-    const float2 v = p[i];
+  int i = 0;
+  for (; i + 4 <= parts; i += 4) {                  // four independent loads in flight, summed in index order
+    const float2 v0 = p[(long long)i * rows], v1 = p[(long long)(i + 1) * rows], v2 = p[(long long)(i + 2) * rows], v3 = p[(long long)(i + 3) * rows];
+    s = (((s + v0.x) + v1.x) + v2.x) + v3.x;
+    q = (((q + v0.y) + v1.y) + v2.y) + v3.y;
+  }
+  for (; i < parts; ++i) {
+    const float2 v = p[(long long)i * rows];
     s += v.x;
     q += v.y;
   }

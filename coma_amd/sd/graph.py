@@ -58,7 +58,7 @@ class LaunchGraph:
             self._colstats[out.data_ptr()] = cs
         # ... and the LayerNorm statistics of a transformer-block consumer from the same epilogue (never with split-K)
         if kw.pop("rowstats", False):
-            rs = torch.zeros(M, n // 32, 2, dtype=torch.float32, device=self.device)
+            rs = torch.zeros(n // 32, M, 2, dtype=torch.float32, device=self.device)
             kw["rowstats"] = rs
             self._rowstats[out.data_ptr()] = rs
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
@@ -73,8 +73,8 @@ class LaunchGraph:
         self.add(lambda: dst.view(2, -1).copy_(src.view(1, -1)), tag=f"dup {src.numel() * 2 >> 20} MiB")
         rs = self._rowstats.get(src.data_ptr())
         if rs is not None:
-            rs2 = torch.zeros(2 * rs.shape[0], *rs.shape[1:], dtype=rs.dtype, device=self.device)
-            self.add(lambda: rs2.view(2, -1).copy_(rs.view(1, -1)), tag="dup rowstats")
+            rs2 = torch.zeros(rs.shape[0], 2 * rs.shape[1], 2, dtype=rs.dtype, device=self.device)      # [parts][rows][2]: rows double
+            self.add(lambda: rs2.view(rs.shape[0], 2, -1).copy_(rs.view(rs.shape[0], 1, -1)), tag="dup rowstats")
             self._rowstats[dst.data_ptr()] = rs2
         cs = self._colstats.get(src.data_ptr())
         if cs is not None:

@@ -74,7 +74,7 @@ typedef struct sd_conv_gemm_desc {
   const float* ln_stats;   /* fp32 [rows][2] = (mean, rstd) per row of the normalised operand (sd_ln_rowstats_finalize), or NULL */
   const float* ln_colsum;  /* fp32 [n] (or [M] with SD_EPI_BIAS_ROWS) */
   int64_t stride_ln_stats; /* floats between the ln_stats of consecutive z problems (nbatch_z > 1) */
-  float* rowstats;         /* optional fp32 [M][n/32][2]: per row and 32-column tile the sum and sum of squares of the stored output --
+  float* rowstats;         /* optional fp32 [n/32][M][2]: per row and 32-column tile the sum and sum of squares of the stored output --
                               the raw material of the consumer's LayerNorm statistics; n % 32 == 0, no split-K */
 } sd_conv_gemm_desc;
 
@@ -97,7 +97,7 @@ int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, in
                               const void* gamma, const void* beta, int silu, void* out, float* stats, const float* colstats0,
                               const float* colstats1, void* stream);
 
-/* (mean, rstd) of every row from the producer's per-tile partial sums: partial fp32 [rows][parts][2] (sd_conv_gemm_desc.rowstats,
+/* (mean, rstd) of every row from the producer's per-tile partial sums: partial fp32 [parts][rows][2] (sd_conv_gemm_desc.rowstats,
  * parts = c / 32) -> stats fp32 [rows][2].  replaces the statistics half of nn.LayerNorm(c, eps) in BasicTransformerBlock. */
 int sd_ln_rowstats_finalize(const float* partial, int64_t rows, int parts, int c, float eps, float* stats, void* stream);
 

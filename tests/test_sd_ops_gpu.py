@@ -396,11 +396,11 @@ def test_row_statistics_from_the_producer_epilogue(ops, M, C):
     K = 320
     x, w, b, r = rnd(M, K, seed=1), rnd(C, K, seed=2, scale=K**-0.5), rnd(C, seed=3), rnd(M, C, seed=4)
     out = torch.empty(M, C, dtype=F16, device=DEV)
-    rs = torch.zeros(M, C // 32, 2, dtype=torch.float32, device=DEV)
+    rs = torch.zeros(C // 32, M, 2, dtype=torch.float32, device=DEV)
     ops.conv_gemm(x.to(DEV), w.to(DEV), out, batch=M, in_h=1, in_w=1, c0=K, n=C, bias=b.to(DEV), res=r.to(DEV), rowstats=rs,
                   workspace=torch.empty(8 << 20, dtype=torch.float32, device=DEV))
     close(out, x.float() @ w.float().T + b.float() + r.float())
-    o = out.float().reshape(M, C // 32, 32)
+    o = out.float().reshape(M, C // 32, 32).transpose(0, 1)
     assert torch.allclose(rs[..., 0], o.sum(-1), rtol=1e-4, atol=1e-3) and torch.allclose(rs[..., 1], (o * o).sum(-1), rtol=1e-4, atol=1e-3)
     st = torch.empty(M, 2, dtype=torch.float32, device=DEV)
     ops.ln_rowstats_finalize(rs, st, rows=M, c=C)
