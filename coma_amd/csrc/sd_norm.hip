@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const _Float16* __restric
 }
 
 // y = silu(x * scale + shift): blockIdx.y = sample, tx = 8-channel chunk, ty = pixel lane -> no integer division
-constexpr int GN_APPLY_PIX = 32;     // pixels per block
+constexpr int GN_APPLY_PIX = 64;     // pixels per block
 __global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
                                                        int c0, int c1, int hw, const float* __restrict__ affine, int silu,
                                                        _Float16* __restrict__ out) {
@@ -241,64 +241,92 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restric
       const float4 v = ap[k];
       sc[2 * k] = v.x; sh[2 * k] = v.y; sc[2 * k + 1] = v.z; sh[2 * k + 1] = v.w;
     }
-    for (int p = p0 + ty; p < p1; p += ny) {
-      const long long pix = (long long)b * hw + p;
-      const half8 v = load8(x0, x1, c0, c1, pix, ch * 8);
-      half8 o;
+    // four pixels per trip: the loads are issued back to back before any of them is used (one load in flight per thread left
+    // the kernel at 3.2 TB/s)
+    for (int p = p0 + ty; p < p1; p += 4 * ny) {
+      half8 v[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float y = fmaf((float)v[j], sc[j], sh[j]);
-        if (silu) y = y / (1.0f + __expf(-y));
-        o[j] = (_Float16)y;
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * ny;
+        v[u] = load8(x0, x1, c0, c1, (long long)b * hw + (pp < p1 ? pp : p), ch * 8);
       }
-      *reinterpret_cast<half8*>(out + pix * C + ch * 8) = o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * ny;
+        if (pp >= p1) break;
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float y = fmaf((float)v[u][j], sc[j], sh[j]);
+          if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+          o[j] = (_Float16)y;
+        }
+        *reinterpret_cast<half8*>(out + ((long long)b * hw + pp) * C + ch * 8) = o;
+      }
     }
   }
 }
 
-// one wave per row; C <= 64*8*4
+// R rows per wave (R = 4 for C <= 512, 2 for C <= 1024, else 1): all loads of the R rows are issued before the first is
+// used, so a wave keeps R x 16 B per lane in flight instead of one (C = 320 fills only 40 of the 64 lanes with one chunk each)
+template <int R, int CH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const _Float16* __restrict__ x, long long rows, int C, float eps,
                                                         const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
                                                         _Float16* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
   const int c8 = C / 8;
-  half8 v[4];
-  float s = 0.0f;
+  half8 v[R][CH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ch = lane + i * 64;
-    if (ch < c8) {
-      v[i] = *reinterpret_cast<const half8*>(x + row * C + ch * 8);
+  for (int r = 0; r < R; ++r) {
+    const long long row = row0 + r < rows ? row0 + r : row0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    for (int i = 0; i < CH; ++i) {
+      const int ch = lane + i * 64;
+      if (ch < c8) v[r][i] = *reinterpret_cast<const half8*>(x + row * C + ch * 8);
     }
   }
-  const float mean = wave_sum(s) / C;
-  float q = 0.0f;
+  half8 ga[CH], be[CH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ch = lane + i * 64;
+  for (int i = 0; i < CH; ++i) {
+    const int ch = lane + i * 64;
     if (ch < c8) {
+      ga[i] = *reinterpret_cast<const half8*>(gamma + ch * 8);
+      be[i] = *reinterpret_cast<const half8*>(beta + ch * 8);
+    }
+  }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float d = (float)v[i][j] - mean;
-        q += d * d;
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r >= rows) break;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+      if (lane + i * 64 < c8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)v[r][i][j];
       }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    const float mean = wave_sum(s) / C;
+    float q = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ch = lane + i * 64;
-    if (ch < c8) {
-      half8 ga = *reinterpret_cast<const half8*>(gamma + ch * 8);
-      half8 be = *reinterpret_cast<const half8*>(beta + ch * 8);
-      half8 o;
+    for (int i = 0; i < CH; ++i)
+      if (lane + i * 64 < c8) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)v[i][j] - mean) * rstd * (float)ga[j] + (float)be[j]);
-      *reinterpret_cast<half8*>(out + row * C + ch * 8) = o;
+        for (int j = 0; j < 8; ++j) {
+          const float d = (float)v[r][i][j] - mean;
+          q += d * d;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int ch = lane + i * 64;
+      if (ch < c8) {
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)(((float)v[r][i][j] - mean) * rstd * (float)ga[i][j] + (float)be[i][j]);
+        *reinterpret_cast<half8*>(out + (row0 + r) * C + ch * 8) = o;
+      }
     }
   }
 }
@@ -359,8 +387,13 @@ extern "C" int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, c
                                 void* out, void* stream) {
   if (!x || !gamma || !beta || !out) return fail(COMA_E_INVALID, "sd_layernorm_f16: null pointer");
   if (rows <= 0 || c <= 0 || c % 8 || c > 2048) return fail(COMA_E_INVALID, "sd_layernorm_f16: bad shape c=%d", c);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const _Float16*)x, (long long)rows, c, eps, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)out);
+#define SD_LN_LAUNCH(R_, CH_)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_kernel<R_, CH_>), dim3((unsigned)((rows + 4 * R_ - 1) / (4 * R_))), dim3(256), 0, (hipStream_t)stream, \
+                     (const _Float16*)x, (long long)rows, c, eps, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)out)
+  if (c <= 512) SD_LN_LAUNCH(4, 1);
+  else if (c <= 1024) SD_LN_LAUNCH(2, 2);
+  else SD_LN_LAUNCH(1, 4);
+#undef SD_LN_LAUNCH
   return check_launch("layernorm_kernel");
 }
 
