@@ -596,11 +596,23 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   const int lim_h = g.upsample ? 2 * g.in_h : g.in_h;
   const int lim_w = g.upsample ? 2 * g.in_w : g.in_w;
 
-  // running position of the NEXT tile to load: tap index and channel offset inside the concatenation
-  int ld_tap = __builtin_amdgcn_readfirstlane((kt0 * BK) / ctot);
-  int ld_ci = kt0 * BK - ld_tap * ctot;
+  // running position of the NEXT tile to load: tap index and channel offset inside the concatenation.
+  // 3x3 convolutions walk K TAP-MINOR (for every 64-channel chunk the nine taps back to back): the nine tiles then touch
+  // the same (pixel, channel-chunk) lines shifted by one pixel -- ~50 KB per workgroup that stays in L2 -- where the
+  // tap-major order re-fetched the whole 164 KB activation tile of the workgroup per tap (working set of an XCD 5 MB > L2:
+  // rocprofv3 showed 9x the activation bytes on the fabric).  The sum over K is the same set of products in another order.
+  const bool tapminor = g.taps == 9 && !g.upsample && !(g.epi & (1 << 28));
+  int ld_tap, ld_ci;
+  if (tapminor) {
+    ld_tap = __builtin_amdgcn_readfirstlane(kt0 % 9);
+    ld_ci = __builtin_amdgcn_readfirstlane((kt0 / 9) * BK);
+  } else {
+    ld_tap = __builtin_amdgcn_readfirstlane((kt0 * BK) / ctot);
+    ld_ci = kt0 * BK - ld_tap * ctot;
+  }
   int ld_src = -1;                    // 0: a0, 1: a1
   unsigned a_off[A_LD];
+  unsigned a_base[A_LD];              // tap-minor: byte offset of tap (0,0) in the current source (may wrap below zero)
   auto repoint = [&]() {
     const int ky = g.taps == 9 ? ld_tap / 3 : 0;
     const int kx = g.taps == 9 ? ld_tap - ky * 3 : 0;
@@ -611,10 +623,43 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
       int iy = (a_yx[j] >> 16) + ky, ix = (int)(short)(a_yx[j] & 0xffff) + kx;
       const bool ok = iy >= 0 && iy < lim_h && ix >= 0 && ix < lim_w;
       if (g.upsample) { iy >>= 1; ix >>= 1; }
-      a_off[j] = ok ? (unsigned)((a_n[j] * g.in_h + iy) * g.in_w + ix) * (unsigned)csrc2 + a_koff[j] : OOB;
+      a_off[j] = ok ? (unsigned)(((a_n[j] & 0xffff) * g.in_h + iy) * g.in_w + ix) * (unsigned)csrc2 + a_koff[j] : OOB;
     }
   };
-  repoint();
+  // tap-minor: per row the nine validity bits ride in the upper half of a_n; a tile's offsets are base + one scalar delta
+  auto retap = [&]() {
+    const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
+    const int csrc2 = (ld_src ? g.c1 : g.c0) * 2;
+    const unsigned sdelta = (unsigned)__builtin_amdgcn_readfirstlane((ky * g.in_w + kx) * csrc2);
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) a_off[j] = ((a_n[j] >> (16 + ld_tap)) & 1) ? a_base[j] + sdelta : OOB;
+  };
+  auto rebase = [&]() {
+    ld_src = __builtin_amdgcn_readfirstlane(ld_ci >= g.c0 ? 1 : 0);
+    const int csrc2 = (ld_src ? g.c1 : g.c0) * 2;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int y0 = a_yx[j] >> 16, x0 = (int)(short)(a_yx[j] & 0xffff);
+      a_base[j] = (unsigned)((((a_n[j] & 0xffff) * g.in_h + y0) * g.in_w + x0) * csrc2) + a_koff[j];
+    }
+    retap();
+  };
+  if (tapminor) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int y0 = a_yx[j] >> 16, x0 = (int)(short)(a_yx[j] & 0xffff);
+      unsigned mask = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = y0 + t / 3, ix = x0 + t % 3;
+        mask |= (iy >= 0 && iy < g.in_h && ix >= 0 && ix < g.in_w) ? (1u << t) : 0u;      // rows >= M carry y0 = -16384: all clear
+      }
+      a_n[j] |= (int)(mask << 16);
+    }
+    rebase();
+  } else {
+    repoint();
+  }
 
   // LDS-DMA of the tile at (ld_tap, ld_ci) into stage `buf`: instruction `idx` of this wave's LPT (A first, then W)
   auto issue_one = [&](int buf, auto idx_c) {
@@ -644,6 +689,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     }
   };
   auto advance_tile = [&]() {
+    if (tapminor) {
+      ld_tap = __builtin_amdgcn_readfirstlane(ld_tap + 1);
+      if (ld_tap == 9) {
+        ld_tap = 0;
+        ld_ci = __builtin_amdgcn_readfirstlane(ld_ci + BK);
+        if ((ld_ci >= g.c0) != (ld_src == 1)) { rebase(); return; }
+      }
+      retap();
+      return;
+    }
     ld_ci = __builtin_amdgcn_readfirstlane(ld_ci + BK);
     if (ld_ci >= ctot) { ld_ci = 0; ld_tap = __builtin_amdgcn_readfirstlane(ld_tap + 1); repoint(); }
     else if ((ld_ci >= g.c0) != (ld_src == 1)) repoint();
@@ -781,6 +836,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   g.rows_per_batch = d->out_h * d->out_w;
   long long M = (long long)d->batch * g.rows_per_batch;
   if (M > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: M too large");
+  if (d->taps == 9 && d->batch > 65535) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a 3x3 convolution takes at most 65535 samples per launch");
   // the LDS-DMA addresses rows with 32-bit byte offsets from the tensor base (bit 31 marks zero padding)
   const long long a_bytes = (long long)d->batch * d->in_h * d->in_w * (d->c0 > d->c1 ? d->c0 : d->c1) * 2;
   const long long w_bytes = (long long)d->n * d->taps * (d->c0 + d->c1) * 2;
@@ -845,6 +901,9 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
                      (g.bias_bn && (g.res || g.rows_per_batch % 32 || g.ldbb % 8)) || (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL ||
                      (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: colstats needs M %% 32 == 0, N %% 8 == 0, 16-byte aligned rows, < 2 GiB tensors, no GEGLU / batching");
+  // tap-minor K order only where it measured faster: the 256 x 320 tile with a single N tile (+7 % at 64x64, C = 320; elsewhere the
+  // second N tile re-reads A from L2 anyway and the order is neutral to -10 %, profiles/r02_notes.md)
+  if (!(big && gy == 1)) g.epi |= (1 << 28);
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;

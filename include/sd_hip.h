@@ -33,8 +33,8 @@ extern "C" {
                                16-byte LDS load per MFMA operand (vt_perm16 = 1).  n is rounded up to 16 columns (ldo must cover them);
                                columns whose source row is >= n hold a clamped finite row */
 /* bits 20..27 select kernel variants for tuning runs (scripts/time_gemm.py): 20 = generic 128x128 tiles only, 21 = 128x320
- * tile, 22 = tile DMA in one burst, 23 = 4-wave 128x320 tile, 24..27 = forced split-K factor.  Results are identical. */
-#define SD_EPI_TUNING_MASK 0x0ff00000
+ * tile, 22 = tile DMA in one burst, 23 = 4-wave 128x320 tile, 24..27 = forced split-K factor, 28 = tap-major K order for 3x3.  Results are identical. */
+#define SD_EPI_TUNING_MASK 0x1ff00000
 
 /* out[m, n] = sum_k A[m, k] * W[n, k] (+ epilogue) with A gathered from one or two NHWC sources:
  *   m = (b, oy, ox), k = (tap, ci);  taps = 9: 3x3, zero pad 1;  taps = 1: 1x1 / linear
