@@ -147,7 +147,7 @@ def bench_inpaint(args, dev, world, rank):
                          "achieved": g_fl / g_ms / 1e9, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, "launches": len(gemm),
                          "avg_launch_ms": g_ms / len(gemm), "flops_per_forward": g_fl, "traffic": UNET_GEMM_PMC_TRAFFIC_BYTES if B == 8 else None,
-                         "traffic_source": "profiles/r01_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
+                         "traffic_source": "profiles/r02_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
                                            "the launches of eager UNet forwards at batch 16 (fabric-side requests of the 8 L2s: "
                                            "weights are pulled once per XCD and mostly hit the Infinity Cache)",
                          "unet_forward_ms_eager_sum": tot_ms,
@@ -217,7 +217,7 @@ def bench_contact(args, dev, world, rank):
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                      "kernel_ms": kern_ms, "flop_per_pair": flop_per_pair(N), "algorithmic_hbm_bytes": alg_bytes,
                      "traffic": CONTACT_PMC_TRAFFIC_BYTES if (S, H, O, N) == (64, 10475, 180, 250) else None,
-                     "traffic_source": "profiles/r01_contact_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
+                     "traffic_source": "profiles/r02_contact_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
     }
 
 
@@ -304,10 +304,12 @@ def bench_occupancy(args, dev, world, rank):
                          "algorithmic_bytes": alg, "traffic": None}}
 
 
-# HBM bytes per contact_accumulate_kernel launch from the committed rocprofv3 PMC pass (profiles/r01_contact_pmc.txt):
-# FETCH_SIZE 1.91553e6 KiB (x2: gfx950 reports half of a coalesced stream) + WRITE_SIZE 3.71135e6 KiB
-UNET_GEMM_PMC_TRAFFIC_BYTES = int(185.78e6)
-CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91553e6 + 3.71135e6) * 1024)
+# HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
+# FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
+#   profiles/r02_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
+#   profiles/r02_contact_pmc.txt         FETCH_SIZE 1.91551e6 KiB, WRITE_SIZE 3.71066e6 KiB per contact_accumulate launch
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(159.64e6)
+CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91551e6 + 3.71066e6) * 1024)
 
 
 def main():
