@@ -868,8 +868,10 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   // VAE widths (128 / 256 / 512 channels at up to 512 x 512 pixels): 256 x 256 and 256 x 128 tiles, 8 waves
   const bool big256 = !geglu && !big && nz == 1 && k64 && g.N % 256 == 0 && g.M >= 256 * 128 && !(d->epi & (1 << 20));
   const bool big128 = !geglu && !big && !big256 && nz == 1 && k64 && g.N % 128 == 0 && g.M >= 256 * 256 && !(d->epi & (1 << 20));
-  // 512 x 128, 8 waves (wave tile 64 x 128), BK = 32, 3 stages: the 128-channel 3x3 convs of the VAE at 512 x 512
-  // (K = 1152: +17 % over 256 x 128; slower than it at K = 2304)
+  // 256 x 128 with FOUR waves (wave tile 64 x 128), BK = 32, 3 stages = 72 KiB of LDS, so that two independent blocks share a CU
+  // (one block's epilogue and barriers run under the other's K loop): the 128-channel 3x3 convs of the VAE at 512 x 512
+  // (K = 1152, where the output pass is a quarter of the launch).  800 TF/s isolated, the same as 512 x 128 with 8 waves (789) and
+  // +15 % over 128 x 128; at K >= 2304 and for N >= 256 the 8-wave tiles win by 10-15 % (profiles/r02_notes.md section 10)
   const bool tall128 = big128 && g.K <= 1152 && !(d->epi & (1 << 20));
   // 128 x 320, 4 waves (wave tile 64 x 160): mid-size M where 256-row tiles would leave CUs idle
   const bool mid = !big && !big256 && !big128 && !geglu && nz == 1 && g.N % 320 == 0 && g.M >= 128 * 64 &&
@@ -878,7 +880,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   // wave's LDS-read / DMA-issue latency, which the 4-wave tile leaves exposed (knob 23 selects the 4-wave form)
   const bool mid8 = mid && k64 && g.K >= 256 && !(d->epi & (1 << 23));
   const bool wide = g.N % 128 == 0 || g.N > 256;
-  const int bm = tall128 ? 512 : ((big || big_geglu || big256 || big128) ? 256 : 128);
+  const int bm = ((big || big_geglu || big256 || big128) ? 256 : 128);
   const int bn = (big || mid) ? 320 : ((big_geglu || big256) ? 256 : ((wide || big128) ? 128 : 64));
   const int bk = ((mid && !mid8) || tall128) ? 32 : ((big || big_geglu || big256 || big128 || deep || mid8) ? 64 : 32);
   const unsigned gx = (unsigned)((g.M + bm - 1) / bm), gy = (unsigned)((g.N + bn - 1) / bn);
@@ -901,9 +903,11 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
                      (g.bias_bn && (g.res || g.rows_per_batch % 32 || g.ldbb % 8)) || (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL ||
                      (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: colstats needs M %% 32 == 0, N %% 8 == 0, 16-byte aligned rows, < 2 GiB tensors, no GEGLU / batching");
-  // tap-minor K order only where it measured faster: the 256 x 320 tile with a single N tile (+7 % at 64x64, C = 320; elsewhere the
-  // second N tile re-reads A from L2 anyway and the order is neutral to -10 %, profiles/r02_notes.md)
-  if (!(big && gy == 1)) g.epi |= (1 << 28);
+  // tap-minor K order only where it measured faster: the 320-column tiles with a single N tile (+7 % at 64x64, C = 320; elsewhere the
+  // second N tile re-reads A from L2 anyway and the order is neutral to -10 %, profiles/r02_notes.md).  The 8-wave 128 x 320 tile
+  // follows the same rule so that a half-batch launch of such a layer (the shared CFG prefix) accumulates in the same order as the
+  // full-batch one and stays bit-identical to it.
+  if (!((big || mid8) && gy == 1)) g.epi |= (1 << 28);
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
@@ -932,7 +936,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   else if (big) GEMM_LAUNCH(4, 2, 5, 64, 2, false, 2, 512);
   else if ((big_geglu || big256) && spread) GEMM_LAUNCH(4, 2, 4, 64, 2, true, 2, 512);
   else if (big_geglu || big256) GEMM_LAUNCH(4, 2, 4, 64, 2, false, 2, 512);
-  else if (tall128) GEMM_LAUNCH(8, 1, 4, 32, 3, false, 2, 512);
+  else if (tall128) GEMM_LAUNCH(4, 1, 4, 32, 3, false, 2, 256);
   else if (big128) GEMM_LAUNCH(4, 2, 2, 64, 2, false, 2, 512);
   else if (mid8) GEMM_LAUNCH(4, 2, 5, 64, 2, true, 1, 512);
   else if (mid) GEMM_LAUNCH(2, 2, 5, 32, 3, false, 2, 256);

@@ -139,16 +139,34 @@ def default_adaptive_mask_settings(num_inference_steps=50, adaptive_mask_model_t
 
 class SyntheticHumanMaskPredictor:
     """Deterministic stand-in for PointRend (weights cannot be provisioned offline): thresholds the luminance of the
-    decoded x0 image inside an ellipse.  Same plugin contract as PointRendPredictor.__call__ (:1225-1236)."""
+    decoded x0 image inside an ellipse.  Same plugin contract as PointRendPredictor.__call__ (:1225-1236).
+
+    ``accepts_device_tensor``: a plug-in that sets this attribute is handed the decoded image as a uint8 [H,W,3] tensor on
+    the pipeline's device (no D2H copy) and may return its mask as a device tensor; plug-ins without it (the reference's
+    PointRend / SAM predictors) get the uint8 HWC NumPy array of the reference's contract.  Both paths of this class
+    produce the same mask bit for bit (integer arithmetic; the mean is an exact integer sum / N in f64)."""
     use_visualizer = False
+    accepts_device_tensor = True
     _ellipses = {}
 
-    def __call__(self, image_u8):
-        H, W = image_u8.shape[:2]
+    def _ellipse(self, H, W):
         ell = self._ellipses.get((H, W))
         if ell is None:
             yy, xx = np.mgrid[0:H, 0:W]
             ell = self._ellipses[(H, W)] = ((yy - H / 2) / (H * 0.3)) ** 2 + ((xx - W / 2) / (W * 0.18)) ** 2 <= 1.0
+        return ell
+
+    def __call__(self, image_u8):
+        H, W = image_u8.shape[:2]
+        if isinstance(image_u8, torch.Tensor):
+            key = (H, W, str(image_u8.device))
+            ell = self._ellipses.get(key)
+            if ell is None:
+                ell = self._ellipses[key] = torch.from_numpy(self._ellipse(H, W)).to(image_u8.device)
+            s3 = image_u8.to(torch.int32).sum(-1)
+            thr = s3.sum(dtype=torch.int64).to(torch.float64) / float(H * W) - 120.0
+            return {"mask": (ell & (s3.to(torch.float64) > thr)).to(torch.uint8), "vis": None, "asset_mask": None}
+        ell = self._ellipse(H, W)
         s3 = image_u8[..., 0].astype(np.uint16) + image_u8[..., 1] + image_u8[..., 2]    # 3 x luminance, integer
         thr = s3.mean(dtype=np.float64) - 120.0                      # lum > mean(lum) - 40
         return {"mask": (ell & (s3 > thr)).view(np.uint8), "vis": None, "asset_mask": None}
@@ -246,14 +264,17 @@ class AdaptiveMaskInpaintPipeline:
         ops.vae_sample(mom, 64, noise, float(self.vae.config.scaling_factor), B * n, lat32=lat32, lat16=lat16)
         return lat32, lat16
 
-    def decode_to_npuint8_image(self, latents_nhwc_f32, all_images=False):
-        """latents fp32 [B,hw,4] -> uint8 HWC numpy (truncating cast, as `(x*255).astype(np.uint8)` at :1114);
-        image 0 only (the reference's contract) unless all_images."""
+    def decode_to_u8_image(self, latents_nhwc_f32):
+        """latents fp32 [B,hw,4] -> uint8 [B,H,W,3] on the device (truncating cast, as `(x*255).astype(np.uint8)` at :1114)."""
         img = self._decode(latents_nhwc_f32)
         H, W = self.vae.dec.out_h, self.vae.dec.out_w
         u8 = torch.empty(self.vae.batch, H * W, 3, dtype=torch.uint8, device=self.device)
         ops.image_to_u8(img, u8, batch=self.vae.batch, hw=H * W, ld=64, round_mode=0)
-        arr = u8.reshape(self.vae.batch, H, W, 3).cpu().numpy()
+        return u8.reshape(self.vae.batch, H, W, 3)
+
+    def decode_to_npuint8_image(self, latents_nhwc_f32, all_images=False):
+        """The reference's helper (:1111-1115): uint8 HWC NumPy, image 0 only unless all_images."""
+        arr = self.decode_to_u8_image(latents_nhwc_f32).cpu().numpy()
         return arr if all_images else arr[0]
 
     def _decode(self, latents_nhwc_f32):
@@ -333,7 +354,7 @@ class AdaptiveMaskInpaintPipeline:
         ops.cfg_ddim_step(None, 0, lat, None, mask_lat, masked_lat, self.unet.x_in, batch=B, hw=hw, guidance=guidance_scale,
                           alpha_t=1.0, alpha_prev=1.0)
         # 10. denoising loop
-        mask_image_np = None
+        adapted = False
         for i, t in enumerate(timesteps.tolist()):
             self.unet.timesteps.fill_(float(t))
             eps = self.unet.forward_static()
@@ -347,7 +368,10 @@ class AdaptiveMaskInpaintPipeline:
                 # step first (latents + x0), adapt the mask from the decoded x0, then assemble the next input
                 ops.cfg_ddim_step(eps, 64, lat, x0, None, None, None, batch=B, hw=hw, guidance=guidance_scale, alpha_t=a_t,
                                   alpha_prev=a_p)
-                pred_orig_images = self.decode_to_npuint8_image(x0, all_images=True)
+                on_device = bool(getattr(self.adaptive_mask_model, "accepts_device_tensor", False))
+                pred_orig_images = self.decode_to_u8_image(x0)
+                if not on_device:
+                    pred_orig_images = pred_orig_images.cpu().numpy()
                 if adapt:
                     if enforce_full_mask_ratio > 0.0:
                         use_default = t < self.scheduler.config.num_train_timesteps * enforce_full_mask_ratio
@@ -357,11 +381,19 @@ class AdaptiveMaskInpaintPipeline:
                         raise NotImplementedError
                     segs = []
                     for b in range(B):
-                        seg = np.ascontiguousarray(self.adaptive_mask_model(pred_orig_images[b])["mask"]).astype(np.uint8)
-                        small = seg.sum() < 512 * 512 * human_detection_thres
-                        segs.append(None if (use_default or small) else torch.from_numpy(seg).to(dev))
+                        seg = self.adaptive_mask_model(pred_orig_images[b])["mask"]
+                        if isinstance(seg, torch.Tensor):
+                            seg = seg.to(device=dev, dtype=torch.uint8).contiguous()
+                        else:
+                            seg = torch.from_numpy(np.ascontiguousarray(seg).astype(np.uint8)).to(dev)
+                        segs.append(seg)
+                    if use_default:
+                        segs = [None] * B
+                    else:
+                        areas = torch.stack([sg.sum(dtype=torch.int64) for sg in segs]).tolist()       # one sync for the batch
+                        segs = [None if a < 512 * 512 * human_detection_thres else sg for a, sg in zip(areas, segs)]
                     masked_lat = set_mask(segs, int(self.adaptive_mask_settings.dilate_scheduler(i)))
-                    mask_image_np = mask_full[0].cpu().numpy().astype(np.float32)
+                    adapted = True
                 ops.cfg_ddim_step(None, 0, lat, None, mask_lat, masked_lat, self.unet.x_in, batch=B, hw=hw,
                                   guidance=guidance_scale, alpha_t=1.0, alpha_prev=1.0)
             if callback is not None and i % callback_steps == 0:
@@ -385,7 +417,7 @@ class AdaptiveMaskInpaintPipeline:
                     images = arr.cpu().numpy().astype(np.float32) / 255.0
                 else:
                     images = [PIL.Image.fromarray(a) for a in arr.cpu().numpy()]
-        self.last_mask_image_np = mask_image_np
+        self.last_mask_image_np = mask_full[0].cpu().numpy().astype(np.float32) if adapted else None
         if not return_dict:
             return images, None
         return _Output(images=images, nsfw_content_detected=None)

@@ -294,7 +294,7 @@ def test_argument_errors_are_reported_not_launched(ops):
 @pytest.mark.parametrize("M,N,K,taps,hw,epi", [
     (32768, 320, 640, 1, None, 0),          # 256 x 320 tile
     (32768, 512, 576, 9, 4096, 0),          # 256 x 256 tile (3x3, 64 channels)
-    (65536, 128, 1152, 9, 4096, 0),         # 512 x 128 tile
+    (65536, 128, 1152, 9, 4096, 0),         # 4-wave 256 x 128 tile (two blocks per CU)
     (65536, 128, 2304, 9, 4096, 0),         # 256 x 128 tile
     (8192, 640, 640, 1, None, 0),           # 128 x 320 tile, 3 stages
     (4096, 1280, 2560, 1, None, 0),         # 128 x 128, BK = 64
@@ -338,19 +338,23 @@ def test_gemm_race_screen(ops, M, N, K, taps, hw, epi):
 # stride-2 / nearest-x2 gathers are all exercised on the big tiles here, not only on the 128-wide fallbacks.
 BIG_CONV = [
     # B, H, W, c0, c1, n, stride, up      tile family selected by sd_conv_gemm_f16
-    (8, 64, 64, 320, 0, 320, 1, 0),       # 256 x 320 (SPREAD), M = 32768: UNet 64x64 ResNet conv
-    (8, 64, 64, 320, 320, 320, 1, 0),     # 256 x 320, two concatenated sources (up-block skip)
-    (8, 32, 32, 320, 0, 640, 1, 1),       # 256 x 320, nearest-x2 upsampled source (M = 32768)
-    (32, 64, 64, 320, 0, 320, 2, 0),      # 256 x 320, stride-2 down-sampler at M = 32768
-    (16, 64, 64, 320, 0, 320, 2, 0),      # stride 2 down-sampler, M = 16384 -> 128 x 320 mid tile
-    (8, 32, 32, 320, 0, 640, 1, 0),       # 128 x 320 mid tile (M = 8192), 3 stages
+    (16, 64, 64, 320, 0, 320, 1, 0),      # 256 x 320 (SPREAD), M = 65536, single N tile -> tap-minor K order: UNet 64x64 ResNet conv
+    (16, 64, 64, 320, 320, 320, 1, 0),    # 256 x 320, two concatenated sources (up-block skip), tap-minor
+    (6, 100, 110, 320, 0, 320, 1, 0),     # 256 x 320, ragged M = 66000, non-square image, tap-minor
+    (16, 32, 32, 640, 0, 640, 1, 1),      # 256 x 320, nearest-x2 upsampled source (M = 65536, two N tiles: tap-major)
+    (64, 64, 64, 320, 0, 320, 2, 0),      # 256 x 320, stride-2 down-sampler at M = 65536
+    (8, 64, 64, 320, 0, 320, 1, 0),       # 8-wave 128 x 320, M = 32768, tap-minor (the half-batch CFG prefix)
+    (8, 64, 64, 320, 320, 320, 1, 0),     # 8-wave 128 x 320, two sources
+    (32, 64, 64, 320, 0, 320, 2, 0),      # 8-wave 128 x 320, stride-2 down-sampler at M = 32768
+    (16, 64, 64, 320, 0, 320, 2, 0),      # stride 2 down-sampler, M = 16384
+    (8, 32, 32, 320, 0, 640, 1, 0),       # 128 x 320 (M = 8192), two N tiles
     (8, 32, 32, 640, 320, 640, 1, 0),     # 128 x 320, two sources
     (2, 128, 128, 256, 0, 256, 1, 0),     # 256 x 256 (VAE 256-channel conv), M = 32768
     (2, 64, 64, 512, 0, 512, 1, 1),       # 256 x 256 with upsample (VAE up-block)
-    (1, 256, 256, 128, 0, 128, 1, 0),     # 512 x 128 tall tile (K = 1152), M = 65536
+    (1, 256, 256, 128, 0, 128, 1, 0),     # 4-wave 256 x 128 tile (K = 1152), M = 65536
     (1, 256, 256, 256, 0, 128, 1, 0),     # 256 x 128 (K = 2304), M = 65536
-    (1, 250, 250, 128, 0, 128, 1, 0),     # 512 x 128, ragged M (62500 rows: last tile partly beyond M)
-    (3, 100, 110, 320, 0, 320, 1, 0),     # 256 x 320, ragged M = 33000, non-square image
+    (1, 250, 250, 128, 0, 128, 1, 0),     # 4-wave 256 x 128, ragged M (62500 rows: last tile partly beyond M)
+    (3, 100, 110, 320, 0, 320, 1, 0),     # 8-wave 128 x 320, ragged M = 33000, non-square image
 ]
 
 

@@ -101,6 +101,21 @@ def test_adaptive_loop_full_resolution(hip_lib):
     b = run()
     assert torch.equal(a, b), "same generator seed -> identical image"
 
+    class HostContract(SyntheticHumanMaskPredictor):
+        """The reference's plug-in contract (uint8 HWC NumPy in, NumPy mask out, :1225-1236)."""
+        accepts_device_tensor = False
+        seen = []
+
+        def __call__(self, image_u8):
+            assert isinstance(image_u8, np.ndarray) and image_u8.dtype == np.uint8 and image_u8.shape == (512, 512, 3)
+            HostContract.seen.append(1)
+            return super().__call__(image_u8)
+
+    pipe.register_adaptive_mask_model(HostContract())
+    c = run()
+    assert HostContract.seen and torch.equal(a, c), "device-tensor and NumPy plug-in paths must give the same image"
+    assert np.array_equal(m, pipe.last_mask_image_np)
+
 
 def test_from_pretrained_reads_a_diffusers_layout_checkpoint(tmp_path, hip_lib):
     """Write the SD-1.5-inpainting tensors under diffusers' key names as safetensors, load them through

@@ -60,7 +60,7 @@ def vae512(hip_lib):
 
 def test_decoder_512_matches_fp32_reference(vae512):
     """The benchmark's resolution: 64x64 latent -> 512x512 image.  Here M runs up to 262144 rows, so the 256 x 256,
-    256 x 128 and 512 x 128 tile families and the 4096-token mid-block attention are what is being compared."""
+    8-wave and 4-wave 256 x 128 tile families and the 4096-token mid-block attention are what is being compared."""
     state, cfg, vae = vae512
     z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5)).half().float()
     out = vae.decode(z.to(DEV), return_dict=False)[0]
