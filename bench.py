@@ -132,6 +132,7 @@ def bench_inpaint(args, dev, world, rank):
         tot_ms = sum(ms for _, _, ms in prof)
         g_fl, g_ms = sum(f for f, _ in gemm), sum(m for _, m in gemm)
         flops_img = (pipe.unet.g.flops * 50 + pipe.vae.dec.g.flops + pipe.vae.enc.g.flops) / B
+        vendor = vendor_gemm_reference(dev)
         value = world * B * args.steps / dt
         res = {
             "metric": "HOI images/sec (50-step SD-1.5 inpaint, 512x512, fixed mask, CFG; BASELINE metric part 1)",
@@ -151,11 +152,32 @@ def bench_inpaint(args, dev, world, rank):
                                            "the launches of eager UNet forwards at batch 16 (fabric-side requests of the 8 L2s: "
                                            "weights are pulled once per XCD and mostly hit the Infinity Cache)",
                          "unet_forward_ms_eager_sum": tot_ms,
+                         "vendor_gemm": vendor,
                          "attention": {"achieved": sum(f for f, _ in attn) / sum(m for _, m in attn) / 1e9, "unit": "TFLOP/s"}},
         }
     del pipe
     torch.cuda.empty_cache()
     return res
+
+
+def vendor_gemm_reference(dev, n=8192, seconds=1.0):
+    """What the 1400 W package cap leaves of the nominal MFMA peak on THIS box: torch.matmul (hipBLASLt) on N(0,1) fp16 operands,
+    n^3, timed for about a second after a warm-up.  A reference point next to `roofline.achieved`; never part of
+    the product path or of the timed region."""
+    a = torch.randn(n, n, device=dev).half()
+    b = torch.randn(n, n, device=dev).half()
+    for _ in range(20):
+        torch.matmul(a, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            torch.matmul(a, b)
+        torch.cuda.synchronize()
+        reps += 20
+    dt = (time.perf_counter() - t0) / reps
+    return {"achieved": 2 * n ** 3 / dt / 1e12, "unit": "TFLOP/s", "what": f"torch.matmul (hipBLASLt) {n}^3 fp16, N(0,1) operands, same process"}
 
 
 def bench_contact(args, dev, world, rank):

@@ -77,18 +77,24 @@ __device__ __forceinline__ void dbg_stamp(const GemmArgs& g, int slot) {
 }
 
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
-// x * Phi(x) = 0.5 x erfc(-x / sqrt 2) with erfc from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, relative in the
-// negative tail because erfc is formed directly): erfc(a) = t (a1 + t (a2 + ...)) exp(-a^2), t = 1 / (1 + p a), a >= 0
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float a = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
-  const float ex = __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
-  float q = fmaf(1.061405429f, t, -1.453152027f);
-  q = fmaf(q, t, 1.421413741f);
-  q = fmaf(q, t, -0.284496736f);
-  q = fmaf(q, t, 0.254829592f);
-  const float e = q * t * ex;
-  return 0.5f * x * (x < 0.0f ? e : 2.0f - e);
+// GELU (exact erf form, diffusers' GEGLU) without transcendentals: x * Phi(x), Phi(x) = 0.5 + xc * R(u) with xc = clamp(x, +-5),
+// u = 2 xc^2 / 25 - 1 in [-1, 1] and R a degree-12 Chebyshev fit of (Phi(sqrt t) - 0.5) / sqrt t (coefficients <= 0.15 in
+// magnitude: Horner in u is well conditioned in fp32).  |Phi error| <= 4e-7, |gelu error| <= 2e-6 for |x| <= 6 and <= 4e-7 |x|
+// beyond (1 - Phi(5) = 2.9e-7): 1/30 of an fp16 ulp at |gelu| = 0.06.  Two values per instruction (v_pk_fma_f32): 17 packed
+// operations per pair against 32 scalar ones + 4 quarter-rate transcendentals for the Abramowitz-Stegun erfc form used before
+// (|error| 4e-7, relative in the negative tail) -- the VALU time of the GEGLU epilogue is not hidden behind anything, it was
+// a third of the kernel (profiles/r02_notes.md section 11).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -5.0f, 5.0f), __builtin_amdgcn_fmed3f(x.y, -5.0f, 5.0f)};
+  const f32x2 u = __builtin_elementwise_fma(xc * xc, (f32x2){0.08f, 0.08f}, (f32x2){-1.0f, -1.0f});
+  constexpr float c[13] = {1.413638145e-01f, -7.029590756e-02f, 5.151792988e-02f, -4.045128077e-02f, 3.147675842e-02f,
+                           -2.321312763e-02f, 1.623608917e-02f, -1.130712498e-02f, 6.766527425e-03f, -2.526916796e-03f,
+                           1.374596148e-03f, -1.676730928e-03f, 7.353763795e-04f};
+  f32x2 r = {c[12], c[12]};
+#pragma unroll
+  for (int k = 11; k >= 0; --k) r = __builtin_elementwise_fma(r, u, (f32x2){c[k], c[k]});
+  return x * __builtin_elementwise_fma(xc, r, (f32x2){0.5f, 0.5f});
 }
 
 __device__ __forceinline__ int kappa16(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
@@ -171,62 +177,77 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
   const int cl = (lane & 3) * 8;
   if (geglu) {
     if constexpr (TN % 2 == 0) {
-      // tile pairs (2p, 2p+1) = (32 value columns, their 32 gate columns): weight rows interleaved at prep time
+      // tile pairs (2p, 2p+1) = (32 value columns, their 32 gate columns): weight rows interleaved at prep time.  The wave's whole
+      // output (TM*32 rows x P*32 columns) is staged ONCE, as fp16, and read back as 16-byte chunks of full 64 / 128-byte row
+      // segments: two LDS synchronisation points per wave instead of two per 32 x 32 tile (the per-tile form spent 13 k of a
+      // 32 k-cycle workgroup in this epilogue, nearly all of it waiting on LDS round trips -- profiles/r02_notes.md section 11)
+      constexpr int P = TN / 2, GST = P * 32 + 8;          // staged row: P*32 halves + 16 bytes of padding
+      _Float16* const gs = lds + wave * (TM * 32 * GST);
+      const int ncolw = n0 + wc * (TN * 32);
+      half4 hbv[P][4], hbg[P][4];
 #pragma unroll
-      for (int p = 0; p < TN / 2; ++p) {
-        const int ncol0 = n0 + wc * (TN * 32) + p * 64;        // permuted value columns [ncol0, +32), gates [+32, +64)
-        const int ocol0 = (ncol0 >> 1);
-        // bias (and, with a folded LayerNorm, the column sums) of this lane's 16 value / 16 gate columns: 8-byte / 16-byte loads
-        float bv[4][4], bg[4][4];
-        float4 sv[4], sg[4];
+      for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c = ncol0 + 8 * q + 4 * hh;
-          half4 hv = {0, 0, 0, 0}, hg = {0, 0, 0, 0};
-          if (g.bias) { hv = *reinterpret_cast<const half4*>(g.bias + c); hg = *reinterpret_cast<const half4*>(g.bias + c + 32); }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { bv[q][e] = (float)hv[e]; bg[q][e] = (float)hg[e]; }
-          if (LNX && g.ln_stats) { sv[q] = *reinterpret_cast<const float4*>(g.ln_colsum + c); sg[q] = *reinterpret_cast<const float4*>(g.ln_colsum + c + 32); }
+          const int c = ncolw + p * 64 + 8 * q + 4 * hh;
+          hbv[p][q] = half4{0, 0, 0, 0};
+          hbg[p][q] = half4{0, 0, 0, 0};
+          if (g.bias) { hbv[p][q] = *reinterpret_cast<const half4*>(g.bias + c); hbg[p][q] = *reinterpret_cast<const half4*>(g.bias + c + 32); }
         }
+      float ln_mu[TM], ln_r[TM];                             // folded LayerNorm: this lane's row of each tile
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int mbase = m0 + wr * (TM * 32) + i * 32;
-          float ln_mu = 0.0f, ln_r = 1.0f;                       // folded LayerNorm: this lane's row of the tile
+      for (int i = 0; i < TM; ++i) {
+        ln_mu[i] = 0.0f;
+        ln_r[i] = 1.0f;
+        if (LNX && g.ln_stats) {
+          const int rr = min(m0 + wr * (TM * 32) + i * 32 + lrow, g.M - 1);
+          ln_mu[i] = lnst[2 * rr];
+          ln_r[i] = lnst[2 * rr + 1];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 sv = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
           if (LNX && g.ln_stats) {
-            const int rr = min(mbase + lrow, g.M - 1);
-            ln_mu = lnst[2 * rr];
-            ln_r = lnst[2 * rr + 1];
+            const int c = ncolw + p * 64 + 8 * q + 4 * hh;
+            sv = *reinterpret_cast<const float4*>(g.ln_colsum + c);
+            sg = *reinterpret_cast<const float4*>(g.ln_colsum + c + 32);
           }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float o[4];
+          for (int i = 0; i < TM; ++i) {
+            half4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float av = acc[i][2 * p][4 * q + e], ag = acc[i][2 * p + 1][4 * q + e];
+            for (int e = 0; e < 4; e += 2) {
+              f32x2 av = {acc[i][2 * p][4 * q + e], acc[i][2 * p][4 * q + e + 1]};
+              f32x2 ag = {acc[i][2 * p + 1][4 * q + e], acc[i][2 * p + 1][4 * q + e + 1]};
               if (LNX && g.ln_stats) {
-                const float cv = e == 0 ? sv[q].x : e == 1 ? sv[q].y : e == 2 ? sv[q].z : sv[q].w;
-                const float cg = e == 0 ? sg[q].x : e == 1 ? sg[q].y : e == 2 ? sg[q].z : sg[q].w;
-                av = ln_r * (av - ln_mu * cv);
-                ag = ln_r * (ag - ln_mu * cg);
+                const f32x2 cv = e == 0 ? (f32x2){sv.x, sv.y} : (f32x2){sv.z, sv.w};
+                const f32x2 cg = e == 0 ? (f32x2){sg.x, sg.y} : (f32x2){sg.z, sg.w};
+                av = ln_r[i] * (av - ln_mu[i] * cv);
+                ag = ln_r[i] * (ag - ln_mu[i] * cg);
               }
-              o[e] = (av + bv[q][e]) * gelu_erf(ag + bg[q][e]);
+              const f32x2 r = (av + (f32x2){(float)hbv[p][q][e], (float)hbv[p][q][e + 1]}) *
+                              gelu_erf2(ag + (f32x2){(float)hbg[p][q][e], (float)hbg[p][q][e + 1]});
+              o[e] = (_Float16)r.x;
+              o[e + 1] = (_Float16)r.y;
             }
-            *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<half4*>(gs + (i * 32 + lrow) * GST + p * 32 + 8 * q + 4 * hh) = o;
           }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int rl = (lane + 64 * k) >> 2;
-            const int row = mbase + rl;
-            const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
-            const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
-            half8 o = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w, (_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
-            if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocol0 + cl) = o;
-          }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int CH = P * 4;                              // 16-byte chunks per staged row
+      const int ocolw = ncolw >> 1;
+#pragma unroll
+      for (int k = 0; k < TM * 32 * CH / 64; ++k) {
+        const int it = lane + 64 * k;
+        const int rl = it / CH, c = it % CH;
+        const int row = m0 + wr * (TM * 32) + rl;
+        const half8 o = *reinterpret_cast<const half8*>(gs + rl * GST + c * 8);
+        if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocolw + c * 8) = o;
       }
     }
     return;
@@ -508,6 +529,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(1024))) _Float16 lds[(TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES) / 2];
   _Float16* const As0 = lds;
   _Float16* const Bs0 = lds + STAGES * BM_ * BK;
+  static_assert(TN % 2 != 0 || NW * TM * 32 * (TN / 2 * 32 + 8) * 2 <= (int)sizeof(lds), "GEGLU staging must fit the tile buffers");
 
   dbg_stamp(g, 0);
   const int tid = threadIdx.x;

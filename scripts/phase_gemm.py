@@ -47,8 +47,14 @@ def run(M, N, K, taps=1, hw=None, epi=0, res=True, knob=0):
     span = s[:, 3].max() - s[:, 0].min()
     pro, loop, epi_c = (s[:, 1] - s[:, 0]), (s[:, 2] - s[:, 1]), (s[:, 3] - s[:, 2])
     tf = 2 * M * N * K / us / 1e6
+    # how phase-locked are the workgroups?  fraction of resident blocks that sit in their epilogue, sampled over the launch
+    ts = np.linspace(s[:, 0].min(), s[:, 3].max(), 400)
+    act = ((s[:, 0][None] <= ts[:, None]) & (ts[:, None] < s[:, 3][None]))
+    inep = ((s[:, 2][None] <= ts[:, None]) & (ts[:, None] < s[:, 3][None]))
+    frac = inep.sum(1) / np.maximum(act.sum(1), 1)
+    lock = f"in-epilogue share of resident blocks: mean {frac.mean():.2f} p90 {np.quantile(frac, 0.9):.2f} max {frac.max():.2f}"
     print(f"M={M:6d} N={N:5d} K={K:6d} t={taps} epi={epi} | {us:7.1f} us {tf:6.0f} TF | blocks {len(s):4d} span {span / 1e3:6.1f} kcyc clk {span / us / 1e3:4.2f} GHz | "
-          f"prologue {np.median(pro) / 1e3:5.1f}k  loop {np.median(loop) / 1e3:6.1f}k  epilogue {np.median(epi_c) / 1e3:5.1f}k (max {epi_c.max() / 1e3:5.1f}k)")
+          f"prologue {np.median(pro) / 1e3:5.1f}k  loop {np.median(loop) / 1e3:6.1f}k  epilogue {np.median(epi_c) / 1e3:5.1f}k (max {epi_c.max() / 1e3:5.1f}k) | {lock}")
 
 
 SH = [(65536, 320, 320, 1, None, 0), (65536, 320, 1280, 1, None, 0), (65536, 320, 2880, 9, 4096, 0), (65536, 640, 5760, 9, 4096, 0),
@@ -57,4 +63,6 @@ SH = [(65536, 320, 320, 1, None, 0), (65536, 320, 1280, 1, None, 0), (65536, 320
       (65536, 2560, 320, 1, None, 1), (16384, 5120, 640, 1, None, 1), (4096, 10240, 1280, 1, None, 1)]
 knob = sum(1 << int(b) for b in sys.argv[1].split("+")) if len(sys.argv) > 1 else 0
 for sh in SH:
+    if os.environ.get("GEGLU_ONLY") and not sh[5]:
+        continue
     run(*sh, knob=knob)

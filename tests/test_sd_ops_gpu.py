@@ -90,6 +90,29 @@ def test_conv1x1_two_sources_and_silu(ops):
     close(out, so.conv_ref(torch.cat([x0, x1], -1), w, batch=B, h=H, w_=W, bias=b, silu=True))
 
 
+def test_geglu_gelu_is_the_erf_form_to_fp16_resolution(ops):
+    """The epilogue's GELU (polynomial Phi, no transcendentals) against erf in float64 over the whole fp16 range of gate values:
+    value column = 1 (bias only), gate = the swept number -> the output IS gelu(gate).  |error| <= 3e-6 + half an fp16 ulp."""
+    import math
+    from coma_amd.sd.weights import geglu_interleave
+    rows, k, inner = 8192, 64, 64
+    gvals = torch.cat([torch.linspace(-9, 9, rows - 64), torch.tensor([-60000.0, -1000.0, -100.0, -20.0, 20.0, 100.0, 1000.0, 60000.0] * 8)]).half().float()
+    x = torch.zeros(rows, k); x[:, 0] = gvals
+    w = torch.zeros(2 * inner, k); w[inner:, 0] = 1.0          # diffusers layout: first half values, second half gates
+    b = torch.zeros(2 * inner); b[:inner] = 1.0
+    wi, bi = geglu_interleave(w, b)
+    out = torch.empty(rows, inner, dtype=F16, device=DEV)
+    ops.linear(x.half().to(DEV), wi.half().to(DEV), out, rows=rows, k=k, n=2 * inner, bias=bi.half().to(DEV), epi=ops.EPI_GEGLU)
+    got = out.double().cpu()
+    g = gvals.double()
+    ref = (0.5 * g * (1.0 + torch.erf(g / math.sqrt(2.0))))[:, None].expand(-1, inner)
+    ulp = torch.maximum(ref.abs(), torch.tensor(6.1e-5, dtype=torch.float64)) * 2.0 ** -11
+    lim = 3e-6 + 4e-7 * g.abs()[:, None] + ulp
+    bad = (got - ref).abs() > lim
+    assert not bad.any(), (gvals[bad.any(1)][:5], (got - ref).abs().max())
+    assert torch.isfinite(got).all()
+
+
 def test_geglu_epilogue(ops):
     from coma_amd.sd.weights import geglu_interleave
     rows, k, inner = 200, 320, 1280                      # proj: k -> 2*inner
