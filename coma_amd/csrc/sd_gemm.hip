@@ -896,8 +896,13 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   // +15 % over 128 x 128; at K >= 2304 and for N >= 256 the 8-wave tiles win by 10-15 % (profiles/r02_notes.md section 10)
   const bool tall128 = big128 && g.K <= 1152 && !(d->epi & (1 << 20));
   // 128 x 320, 4 waves (wave tile 64 x 160): mid-size M where 256-row tiles would leave CUs idle
-  const bool mid = !big && !big256 && !big128 && !geglu && nz == 1 && g.N % 320 == 0 && g.M >= 128 * 64 &&
-                   (g.N <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20));
+  // ... and, split in two along K, for the deep 3x3 convs at 16 x 16 (M = 4096, N = 1280, K >= 11520): 32 x 4 tiles x 2 splits = one
+  // block per CU, where 128 x 128 tiles leave 320 blocks for 512 slots (+4 % at K = 11520, +15 % at K = 23040, profiles/r02_notes.md 12)
+  const bool midsk = !big && !geglu && nz == 1 && k64 && g.N % 320 == 0 && g.N >= 1280 && g.M >= 4096 && g.M < 128 * 64 && g.K >= 8192 &&
+                     !d->colstats && !d->rowstats && d->workspace && d->workspace_bytes >= (size_t)2 * g.M * g.N * sizeof(float) &&
+                     (long long)((g.M + 127) / 128) * (g.N / 320) * 2 <= 256 && !(d->epi & ((1 << 20) | (1 << 21)));
+  const bool mid = (!big && !big256 && !big128 && !geglu && nz == 1 && g.N % 320 == 0 && (g.M >= 128 * 64 || (d->epi & (1 << 21))) &&
+                    (g.N <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20))) || midsk;
   // 128 x 320 with EIGHT waves (wave tile 32 x 160, two waves per SIMD) instead of four: the partner wave covers each
   // wave's LDS-read / DMA-issue latency, which the 4-wave tile leaves exposed (knob 23 selects the 4-wave form)
   const bool mid8 = mid && k64 && g.K >= 256 && !(d->epi & (1 << 23));
@@ -934,7 +939,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
   if (!g.colstats && !g.rowstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
-    int s = (int)(512 / blocks);
+    int s = (int)((mid8 ? 256 : 512) / blocks);         // the 8-wave 128 x 320 tile is resident once per CU, the others twice
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;
     while (s > 1 && (size_t)s * g.M * g.N * sizeof(float) > d->workspace_bytes) --s;

@@ -46,7 +46,7 @@ def bench(M, N, K, taps=1, epi=0, res=False, reps=20, hw=None):
 
 
 if os.environ.get("SMALL"):
-    SHAPES_OVERRIDE = [(1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64), (4096, 1280, 1280, 1, None), (4096, 1280, 11520, 9, 256),
+    SHAPES_OVERRIDE = [(1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64), (4096, 1280, 1280, 1, None), (4096, 1280, 11520, 9, 256), (4096, 1280, 23040, 9, 256),
                        (4096, 640, 5760, 9, 256), (1024, 1280, 1280, 1, None)]
 if os.environ.get("OVH"):
     SHAPES_OVERRIDE = [(16384, 640, 64, 1, None), (16384, 640, 320, 1, None), (16384, 640, 640, 1, None), (16384, 640, 1280, 1, None),
@@ -62,7 +62,7 @@ SHAPES = [(65536, 320, 320, 1, None), (65536, 320, 2880, 9, 4096), (65536, 320, 
           (16384, 640, 640, 1, None), (16384, 640, 5760, 9, 1024), (16384, 1280, 11520, 9, 1024),
           (4096, 1280, 1280, 1, None), (4096, 1280, 5120, 1, None), (4096, 1280, 11520, 9, 256), (4096, 1280, 23040, 9, 256),
           (1024, 1280, 11520, 9, 64), (1024, 1280, 23040, 9, 64)]
-GEGLU = [] if os.environ.get("ONLY") else [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)]
+GEGLU = [] if (os.environ.get("ONLY") or os.environ.get("SMALL")) else [(65536, 2560, 320), (16384, 5120, 640), (4096, 10240, 1280)]
 knobs = [0] + [sum(1 << int(b) for b in a.split("+")) for a in sys.argv[1:]]
 for (M, N, K, taps, hw) in (SHAPES_OVERRIDE if (os.environ.get('SMALL') or os.environ.get('VAE') or os.environ.get('OVH') or os.environ.get('ONLY')) else SHAPES):
     row = [f"{ms*1e3:7.1f} us {tf:6.1f} TF" for ms, tf in bench_many(M, N, K, knobs, taps=taps, hw=hw, res=not os.environ.get('NORES'))]

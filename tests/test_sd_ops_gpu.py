@@ -378,6 +378,8 @@ BIG_CONV = [
     (1, 256, 256, 256, 0, 128, 1, 0),     # 256 x 128 (K = 2304), M = 65536
     (1, 250, 250, 128, 0, 128, 1, 0),     # 4-wave 256 x 128, ragged M (62500 rows: last tile partly beyond M)
     (3, 100, 110, 320, 0, 320, 1, 0),     # 8-wave 128 x 320, ragged M = 33000, non-square image
+    (16, 16, 16, 1280, 0, 1280, 1, 0),    # 8-wave 128 x 320 split in two along K (M = 4096, K = 11520): UNet 16x16 ResNet conv
+    (16, 16, 16, 1280, 1280, 1280, 1, 0), # same with the skip concatenation (K = 23040)
 ]
 
 
