@@ -7,6 +7,8 @@
 // how the UNet's skip-connection torch.cat is materialised for free.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/sd_hip.h"
 
@@ -143,7 +145,17 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
     const int c = g * cg + tc;
     const float* base = c < c0 ? cs0 + c : cs1 + (c - c0);
     const int cw = c < c0 ? c0 : c1;
-    for (int rb = tr; rb < rbs; rb += per) {
+    // four row blocks per trip: eight independent loads in flight (one per trip left this launch latency-bound: 12 us on average
+    // next to a 20 us apply pass); the sums are still taken in row-block order
+    int rb = tr;
+    for (; rb + 3 * per < rbs; rb += 4 * per) {
+      const float* p = base + ((long long)(b * rbs + rb) * 2) * cw;
+      const long long st = (long long)per * 2 * cw;
+      const float a0 = p[0], b0 = p[cw], a1 = p[st], b1 = p[st + cw], a2 = p[2 * st], b2 = p[2 * st + cw], a3 = p[3 * st], b3 = p[3 * st + cw];
+      s = (((s + a0) + a1) + a2) + a3;
+      q = (((q + b0) + b1) + b2) + b3;
+    }
+    for (; rb < rbs; rb += per) {
       const float* p = base + ((long long)(b * rbs + rb) * 2) * cw;
       s += p[0];
       q += p[cw];
@@ -241,15 +253,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restric
       const float4 v = ap[k];
       sc[2 * k] = v.x; sh[2 * k] = v.y; sc[2 * k + 1] = v.z; sh[2 * k + 1] = v.w;
     }
-    // four pixels per trip: the loads are issued back to back before any of them is used (one load in flight per thread left
-    // the kernel at 3.2 TB/s)
-    for (int p = p0 + ty; p < p1; p += 4 * ny) {
-      half8 v[4];
+    // four pixels per trip, and the NEXT trip's loads are issued before this trip's arithmetic (exp + rcp per element: 8.5 us of
+    // transcendental issue per 65536 x 320 tensor next to the 12.5 us a plain copy of it takes): one trip in flight per thread left
+    // the kernel at 3.2-3.5 TB/s with memory idle during the SiLU arithmetic
+    const int step = 4 * ny;
+    half8 cur[4], nxt[4];
+    auto load4 = [&](half8 (&v)[4], int p) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pp = p + u * ny;
         v[u] = load8(x0, x1, c0, c1, (long long)b * hw + (pp < p1 ? pp : p), ch * 8);
       }
+    };
+    int p = p0 + ty;
+    if (p < p1) load4(cur, p);
+    for (; p < p1; p += step) {
+      const bool more = p + step < p1;
+      if (more) load4(nxt, p + step);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pp = p + u * ny;
@@ -257,11 +277,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restric
         half8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float y = fmaf((float)v[u][j], sc[j], sh[j]);
+          float y = fmaf((float)cur[u][j], sc[j], sh[j]);
           if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
           o[j] = (_Float16)y;
         }
         *reinterpret_cast<half8*>(out + ((long long)b * hw + pp) * C + ch * 8) = o;
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
       }
     }
   }
@@ -331,6 +355,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const _Float16* __restri
   }
 }
 
+// The same arithmetic with a row owned by a GROUP of LPR lanes (LPR = C / 40: 8 / 16 / 32 for the UNet's C = 320 / 640 / 1280), five
+// 16-byte chunks per lane: every lane of the wave carries data (the wave-per-row form above fills 40 of 64 lanes at C = 320),
+// the two reductions take log2(LPR) exchange steps instead of six, and a wave keeps U x 5 loads per lane in flight.
+// 21.3 -> ~13 us at 65536 x 320, where a plain copy of the tensor takes 12.5 us (profiles/r02_notes.md section 13).
+template <int LPR, int U>
+__global__ __launch_bounds__(256) void layernorm_group_kernel(const _Float16* __restrict__ x, long long rows, int C, float eps,
+                                                              const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
+                                                              _Float16* __restrict__ out) {
+  constexpr int CPL = 5, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR, grp = lane / LPR;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (U * RPW) + grp;
+  half8 v[U][CPL];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long row = row0 + u * RPW < rows ? row0 + u * RPW : rows - 1;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) v[u][j] = *reinterpret_cast<const half8*>(x + row * C + (j * LPR + sub) * 8);
+  }
+  half8 ga[CPL], be[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    ga[j] = *reinterpret_cast<const half8*>(gamma + (j * LPR + sub) * 8);
+    be[j] = *reinterpret_cast<const half8*>(beta + (j * LPR + sub) * 8);
+  }
+  const float inv_c = 1.0f / (float)C;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)v[u][j][e];
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    const float mean = s * inv_c;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[u][j][e] - mean;
+        q += d * d;
+      }
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+    const float rstd = rsqrtf(q * inv_c + eps);
+    const long long row = row0 + u * RPW;
+    if (row < rows) {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)(((float)v[u][j][e] - mean) * rstd * (float)ga[j][e] + (float)be[j][e]);
+        *reinterpret_cast<half8*>(out + row * C + (j * LPR + sub) * 8) = o;
+      }
+    }
+  }
+}
+
 // in-place softmax(scale * x) over each row of fp16 [rows, n] (block per row)
 __global__ __launch_bounds__(256) void softmax_kernel(_Float16* __restrict__ x, int n, int ld, float scale) {
   __shared__ float red[4];
@@ -390,10 +473,20 @@ extern "C" int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, c
 #define SD_LN_LAUNCH(R_, CH_)                                                                                                  \
   hipLaunchKernelGGL((layernorm_kernel<R_, CH_>), dim3((unsigned)((rows + 4 * R_ - 1) / (4 * R_))), dim3(256), 0, (hipStream_t)stream, \
                      (const _Float16*)x, (long long)rows, c, eps, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)out)
-  if (c <= 512) SD_LN_LAUNCH(4, 1);
+#define SD_LN_GROUP(LPR_, U_)                                                                                                   \
+  hipLaunchKernelGGL((layernorm_group_kernel<LPR_, U_>), dim3((unsigned)((rows + 4 * U_ * (64 / LPR_) - 1) / (4 * U_ * (64 / LPR_)))),  \
+                     dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (long long)rows, c, eps, (const _Float16*)gamma,    \
+                     (const _Float16*)beta, (_Float16*)out)
+  // (measured: two row groups per wave pay from 32768 rows at C = 320; at C = 640 one group is as fast, and the 4096 x 1280 tensors
+  // of the 16 x 16 level are launch / latency bound either way: 8.4 us for the wave-per-row form, 8.6 for this one)
+  if (c == 320) { if (rows >= 32768) SD_LN_GROUP(8, 2); else SD_LN_GROUP(8, 1); }
+  else if (c == 640) { if (rows >= 65536) SD_LN_GROUP(16, 2); else SD_LN_GROUP(16, 1); }
+  else if (c == 1280 && rows >= 16384) { if (rows >= 32768) SD_LN_GROUP(32, 2); else SD_LN_GROUP(32, 1); }
+  else if (c <= 512) SD_LN_LAUNCH(4, 1);
   else if (c <= 1024) SD_LN_LAUNCH(2, 2);
   else SD_LN_LAUNCH(1, 4);
 #undef SD_LN_LAUNCH
+#undef SD_LN_GROUP
   return check_launch("layernorm_kernel");
 }
 

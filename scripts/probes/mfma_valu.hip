@@ -5,7 +5,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(512) void k(float* out, int mode, int iters) {
   const int wave = threadIdx.x >> 6;
+  const int prio = mode >> 8;            // 1: VALU/exp wave runs at priority 3; 2: MFMA wave runs at priority 3
+  mode &= 255;
   const bool do_mfma = (mode & 1) && wave < 4, do_valu = (mode & 2) && wave >= 4, do_exp = (mode & 4) && wave >= 4;
+  if (prio == 1 && wave >= 4) __builtin_amdgcn_s_setprio(3);
+  if (prio == 2 && wave < 4) __builtin_amdgcn_s_setprio(3);
   float16v acc[4];
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   half8 a, b;
@@ -65,7 +69,7 @@ int main() {
   float* d; hipMalloc(&d, 512 * 256 * 4);
   const char* names[] = {"", "mfma only", "fma only", "mfma + fma", "exp only", "mfma + exp", "", "", "1mfma:8fma x8w", "1mfma:4fma x8w", "mfma x8w", "32fma x8w"};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int mode : {1, 2, 3, 4, 5, 8, 9, 10, 11}) {
+  for (int mode : {1, 2, 3, 256 + 3, 512 + 3, 4, 5, 256 + 5, 512 + 5, 8, 9, 10, 11}) {
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, 0);
@@ -74,7 +78,7 @@ int main() {
       hipDeviceSynchronize();
       hipEventElapsedTime(&ms, e0, e1);
     }
-    printf("%-16s %.3f ms\n", names[mode], ms);
+    printf("%-16s %s %.3f ms\n", names[mode & 255], (mode >> 8) == 1 ? "[VALU wave prio 3]" : (mode >> 8) == 2 ? "[MFMA wave prio 3]" : "", ms);
   }
   return 0;
 }

@@ -36,3 +36,10 @@ tot = sum(v[0] for v in acc.values())
 print(f"eager per-launch total {tot:.2f} ms")
 for cat, (ms, n, fl) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
     print(f"{ms:7.3f} ms {100 * ms / tot:5.1f}%  n={n:3d}  {fl / ms / 1e9 if ms else 0:7.1f} TF/s  {cat}")
+if "--shapes" in sys.argv:
+    per = collections.defaultdict(lambda: [0.0, 0, 0.0])
+    for tag, fl, ms in unet.g.profile(reps=3):
+        per[tag][0] += ms; per[tag][1] += 1; per[tag][2] += fl
+    print("per launch tag (top 45 by time):")
+    for tag, (ms, n, fl) in sorted(per.items(), key=lambda kv: -kv[1][0])[:45]:
+        print(f"{ms:7.3f} ms n={n:3d} {ms / n * 1e3:7.1f} us each {fl / ms / 1e9 if ms else 0:7.1f} TF/s  {tag}")

@@ -150,9 +150,9 @@ def test_groupnorm_two_sources(ops, c0, c1, hw, silu):
     close(out, so.groupnorm_ref(xc, ga, be, batch=B, hw=hw, eps=1e-5, silu=silu))
 
 
-@pytest.mark.parametrize("c", [320, 640, 1280])
-def test_layernorm(ops, c):
-    rows = 77
+@pytest.mark.parametrize("rows,c", [(77, 320), (77, 640), (77, 1280), (40003, 320), (33001, 640), (32769, 1280), (100, 512), (50, 2048), (9, 8)])
+def test_layernorm(ops, rows, c):
+    """Lane-group kernel (C = 320 / 640 / 1280, one and two row groups per wave, ragged row counts) and the wave-per-row fallback."""
     x, ga, be = rnd(rows, c, seed=1) * 2 + 0.3, rnd(c, seed=2) * 0.1 + 1, rnd(c, seed=3) * 0.1
     out = torch.empty(rows, c, dtype=F16, device=DEV)
     ops.layernorm(x.to(DEV), ga.to(DEV), be.to(DEV), out, rows=rows, c=c)
