@@ -22,6 +22,7 @@
 // quarter rate ~510 cycles, ~75 more full-rate instructions); the staging is kept off the VALU entirely.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"

@@ -837,8 +837,16 @@ extern "C" int sd_debug_timestamps(unsigned long long* host_dst, int n_blocks) {
   return COMA_OK;
 }
 
-extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
-  if (!d) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
+extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
+  if (!d_in) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
+  // SD_GEMM_TUNE=<mask> (or _1X1 / _3X3 for those launches only): OR tuning-knob bits (SD_EPI_TUNING_MASK) into every launch -- lets a dispatch rule be A/B-tested inside the
+  // captured UNet (scripts/time_unet.py), where cache state differs from a layer timed alone (profiles/r02_notes.md section 14)
+  static const int tune_env = getenv("SD_GEMM_TUNE") ? (int)strtol(getenv("SD_GEMM_TUNE"), nullptr, 0) & SD_EPI_TUNING_MASK : 0;
+  sd_conv_gemm_desc d_copy = *d_in;
+  static const int tune1_env = getenv("SD_GEMM_TUNE_1X1") ? (int)strtol(getenv("SD_GEMM_TUNE_1X1"), nullptr, 0) & SD_EPI_TUNING_MASK : 0;
+  static const int tune9_env = getenv("SD_GEMM_TUNE_3X3") ? (int)strtol(getenv("SD_GEMM_TUNE_3X3"), nullptr, 0) & SD_EPI_TUNING_MASK : 0;
+  d_copy.epi |= tune_env | (d_in->taps == 1 ? tune1_env : tune9_env);
+  const sd_conv_gemm_desc* d = &d_copy;
   if (!d->a0 || !d->w || !d->out) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null pointer");
   if (d->taps != 1 && d->taps != 9) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: taps must be 1 or 9");
   if (d->stride != 1 && d->stride != 2) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: stride must be 1 or 2");
@@ -882,7 +890,9 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: GEGLU needs N %% 128 == 0 and no residual / batch bias");
   // ---- tile configuration
   const bool k64 = d->c0 % 64 == 0 && d->c1 % 64 == 0;
-  const bool deep = g.K >= 2048 && k64;
+  // BK = 64 with two stages from K = 1024 (was 2048: the K = 1280 linears of the 16 x 16 level, -0.15 ms per UNet forward measured
+  // inside the captured graph)
+  const bool deep = g.K >= 1024 && k64;
   // 256 x 320 tile: N a multiple of 320 (every layer of the SD UNet), enough rows to fill the chip with 1 block / CU
   const bool big = !geglu && nz == 1 && k64 && g.N % 320 == 0 && (long long)((g.M + 255) / 256) * (g.N / 320) >= 192 && !(d->epi & ((1 << 20) | (1 << 21)));
   // GEGLU (needs an even number of MFMA column tiles per wave): 256 x 256, 8 waves, wave tile 64 x 128
@@ -951,7 +961,9 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d, void* stream) {
   if (lin_blocks > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: grid too large");
   dim3 grid((unsigned)lin_blocks, (unsigned)(g.ksplit > 1 ? g.ksplit : nz));
   hipStream_t st = (hipStream_t)stream;
-  const bool spread = !(d->epi & (1 << 22));   // tuning knob: DMA issued in one burst instead of spread over the K steps
+  // DMA issue spread over the K steps of a tile (3x3: +0.5 % of a UNet forward) or in one burst (1x1: +0.6 %) -- both measured inside the
+  // captured forward; knob 22 forces the burst
+  const bool spread = !(d->epi & (1 << 22)) && d->taps == 9;
 #define GEMM_LAUNCH(WM_, WN_, TN_, BK_, ST_, SP_, TM_, THREADS_)                                                                  \
   do {                                                                                                                           \
     if (lnx) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, true>), grid, dim3(THREADS_), 0, st, g);    \

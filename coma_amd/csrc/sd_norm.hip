@@ -236,15 +236,16 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const _Float16* __restric
 
 // y = silu(x * scale + shift): blockIdx.y = sample, tx = 8-channel chunk, ty = pixel lane -> no integer division
 constexpr int GN_APPLY_PIX = 64;     // pixels per block
+static int gn_pix() { return GN_APPLY_PIX; }
 __global__ __launch_bounds__(256) void gn_apply_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1,
                                                        int c0, int c1, int hw, const float* __restrict__ affine, int silu,
-                                                       _Float16* __restrict__ out) {
+                                                       _Float16* __restrict__ out, int pix) {
   const int C = c0 + c1, c8 = C / 8;
   const int b = blockIdx.y;
   const int nx = min(c8, 256), ny = 256 / nx;
   const int tx = threadIdx.x % nx, ty = threadIdx.x / nx;
   if (ty >= ny) return;
-  const int p0 = blockIdx.x * GN_APPLY_PIX, p1 = min(hw, p0 + GN_APPLY_PIX);
+  const int p0 = blockIdx.x * pix, p1 = min(hw, p0 + pix);
   for (int ch = tx; ch < c8; ch += nx) {
     const float4* ap = reinterpret_cast<const float4*>(affine + ((long long)b * C + ch * 8) * 2);
     float sc[8], sh[8];
@@ -461,8 +462,8 @@ extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, 
   const int total = batch * groups;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s, partial, nchunk, groups, C,
                      (float)hw * (float)(C / groups), eps, (const _Float16*)gamma, (const _Float16*)beta, stats, total);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + GN_APPLY_PIX - 1) / GN_APPLY_PIX, batch), dim3(256), 0, s, (const _Float16*)x0,
-                     (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + gn_pix() - 1) / gn_pix(), batch), dim3(256), 0, s, (const _Float16*)x0,
+                     (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out, gn_pix());
   return check_launch("groupnorm kernels");
 }
 
@@ -543,7 +544,7 @@ extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0,
   if (C / groups > 256) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: more than 256 channels per group");
   hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(total), dim3(256), 0, s, colstats0, colstats1, c0, c1, hw, groups, eps,
                      (const _Float16*)gamma, (const _Float16*)beta, stats);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + GN_APPLY_PIX - 1) / GN_APPLY_PIX, batch), dim3(256), 0, s, (const _Float16*)x0,
-                     (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + gn_pix() - 1) / gn_pix(), batch), dim3(256), 0, s, (const _Float16*)x0,
+                     (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out, gn_pix());
   return check_launch("groupnorm (colstats) kernels");
 }
