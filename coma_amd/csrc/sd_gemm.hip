@@ -21,6 +21,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "../../include/sd_hip.h"
@@ -846,6 +847,26 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   static const int tune1_env = getenv("SD_GEMM_TUNE_1X1") ? (int)strtol(getenv("SD_GEMM_TUNE_1X1"), nullptr, 0) & SD_EPI_TUNING_MASK : 0;
   static const int tune9_env = getenv("SD_GEMM_TUNE_3X3") ? (int)strtol(getenv("SD_GEMM_TUNE_3X3"), nullptr, 0) & SD_EPI_TUNING_MASK : 0;
   d_copy.epi |= tune_env | (d_in->taps == 1 ? tune1_env : tune9_env);
+  {   // SD_GEMM_FORCE="N,K,mask;N,K,mask;...": knob bits for the launches with that N and K only (K = taps * channels)
+    struct Force { int n, k, mask; };
+    static const std::vector<Force> forced = [] {
+      std::vector<Force> v;
+      const char* e = getenv("SD_GEMM_FORCE");
+      while (e && *e) {
+        Force f{0, 0, 0};
+        char* end = nullptr;
+        f.n = (int)strtol(e, &end, 0); if (*end != ',') break;
+        f.k = (int)strtol(end + 1, &end, 0); if (*end != ',') break;
+        f.mask = (int)strtol(end + 1, &end, 0) & SD_EPI_TUNING_MASK;
+        v.push_back(f);
+        e = *end == ';' ? end + 1 : end;
+        if (*end != ';') break;
+      }
+      return v;
+    }();
+    for (const Force& f : forced)
+      if (f.n == d_in->n && f.k == d_in->taps * (d_in->c0 + d_in->c1)) d_copy.epi |= f.mask;
+  }
   const sd_conv_gemm_desc* d = &d_copy;
   if (!d->a0 || !d->w || !d->out) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null pointer");
   if (d->taps != 1 && d->taps != 9) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: taps must be 1 or 9");
