@@ -34,6 +34,7 @@ using coma::fail;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int BKMIN = 32;   // source channel counts must be multiples of this (and of 64 for the deep-K variant)
 
@@ -514,7 +515,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
 //        cycles per wave instruction and NOT overlapped with MFMA issue, the limiter of the 128 x 128 tile (0.5 DMA per
 //        MFMA) -- drops to 0.225 DMA per MFMA.
 //   <WM=2, WN=1/2, ...> 64-wide fallbacks for small N.
-template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false, int TM = 2, bool LNX = false>
+template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false, int TM = 2, bool LNX = false, bool M16 = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per block
   constexpr int BM_ = WM * TM * 32, BN = WN * TN * 32;
@@ -739,14 +740,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // M16: the K loop runs on v_mfma_f32_16x16x32_f16 (a 32 x 32 output tile = 2 x 2 of them).  Same flops per clock as 32x32x16, but
+  // less power per flop: under the 1400 W package cap a register-resident loop of them sustains 1.95 PF against 1.69 PF
+  // (scripts/probes/mfma_shape.hip), and the vendor GEMM uses this shape.  acc16[2i+a][2j+b] holds rows 16a + (lane & 15), columns
+  // 16b + 4 (lane >> 4) + e of tile (i, j); it is re-laid into `acc` through LDS before the epilogue.
+  float4v acc16[M16 ? 2 * TM : 1][M16 ? 2 * TN : 1];
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; ++j) acc16[i][j] = float4v{0.0f, 0.0f, 0.0f, 0.0f};
+  }
 
   // fragment addressing: row = base + (lane & 31), K-chunk = 2*ks + (lane >> 5), slot = chunk ^ swizzle(row)
-  const int frow = lane & 31, fhalf = lane >> 5;
-  int a_fr[TM], b_fr[TN];
+  // (M16: row = base + (lane & 15), K-chunk = 4*ks + (lane >> 4))
+  const int frow = M16 ? (lane & 15) : (lane & 31), fhalf = M16 ? (lane >> 4) : (lane >> 5);
+  constexpr int FR = M16 ? 16 : 32;                  // rows per fragment
+  int a_fr[TM * 32 / FR], b_fr[TN * 32 / FR];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) a_fr[i] = wr * (TM * 32) + i * 32 + frow;
+  for (int i = 0; i < TM * 32 / FR; ++i) a_fr[i] = wr * (TM * 32) + i * FR + frow;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b_fr[j] = wc * (TN * 32) + j * 32 + frow;
+  for (int j = 0; j < TN * 32 / FR; ++j) b_fr[j] = wc * (TN * 32) + j * FR + frow;
 
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -771,6 +785,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     if constexpr (NEXT && !SPREAD) issue_tile(nbuf);
     const _Float16* Ab = As0 + (kt % STAGES) * (BM_ * BK);
     const _Float16* Bb = Bs0 + (kt % STAGES) * (BN * BK);
+    if constexpr (!M16) {
     [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
       ([&] {
         constexpr int ks = KSI;
@@ -790,6 +805,38 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
       }(), ...);
     }(std::make_integer_sequence<int, KS>{});
+    } else {
+    constexpr int KS2 = BK / 32;
+    [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
+      ([&] {
+        constexpr int ks = KSI;
+        half8 af[2 * TM], bf[TN];
+        // one lane offset per operand and K step: the swizzle term only looks at row bits 1-3 (BK = 64) / 2-3 (BK = 32), which the
+        // 16-row block index does not touch, so block i is a constant byte offset (an immediate of the ds_read)
+        const int offa = a_fr[0] * BK + swz<BK>(a_fr[0], 4 * ks + fhalf) * 8;
+        const int offb = b_fr[0] * BK + swz<BK>(b_fr[0], 4 * ks + fhalf) * 8;
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) af[i] = *reinterpret_cast<const half8*>(Ab + offa + i * 16 * BK);
+        // the W fragments come in two halves (TN at a time) to keep 20 fewer registers live; the next tile's DMA goes out in
+        // 2 * KS2 shares, one before each half of this K step's MFMAs
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            bf[j] = *reinterpret_cast<const half8*>(Bb + offb + (h * TN + j) * 16 * BK);
+          if constexpr (NEXT && SPREAD) {
+            if (h == 0) issue_range(nbuf, std::integral_constant<int, (2 * ks) * LPT / (2 * KS2)>{}, std::integral_constant<int, (2 * ks + 1) * LPT / (2 * KS2)>{});
+            else issue_range(nbuf, std::integral_constant<int, (2 * ks + 1) * LPT / (2 * KS2)>{}, std::integral_constant<int, (2 * ks + 2) * LPT / (2 * KS2)>{});
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < 2 * TM; ++i)
+              acc16[i][h * TN + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc16[i][h * TN + j], 0, 0, 0);
+        }
+      }(), ...);
+    }(std::make_integer_sequence<int, KS2>{});
+    }
     if constexpr (NEXT && SPREAD) advance_tile();
   };
   {
@@ -799,6 +846,34 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   }
   dbg_stamp(g, 2);
 
+  if constexpr (M16) {
+    // re-lay the 16 x 16 sub-tiles into the 32 x 32 C layout the epilogue works on, one tile at a time through this wave's staging rows
+    wait_vmcnt<0>();
+    __syncthreads();                              // every wave is done with the operand tiles
+    float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
+    const int r16 = lane & 15, q16 = lane >> 4, r32 = lane & 31, h32 = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const float4v v = acc16[2 * i + a][2 * j + b];
+            *reinterpret_cast<float4*>(stage + (16 * a + r16) * EP_STRIDE + 16 * b + 4 * q16) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(stage + r32 * EP_STRIDE + 8 * q + 4 * h32);
+          acc[i][j][4 * q] = v.x; acc[i][j][4 * q + 1] = v.y; acc[i][j][4 * q + 2] = v.z; acc[i][j][4 * q + 3] = v.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+  }
   gemm_epilogue<WM, WN, TN, TM, LNX>(g, acc, lds, m0, n0, wave, lane, z, split);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   dbg_stamp(g, 3);
@@ -988,9 +1063,17 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
 #define GEMM_LAUNCH(WM_, WN_, TN_, BK_, ST_, SP_, TM_, THREADS_)                                                                  \
   do {                                                                                                                           \
     if (lnx) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, true>), grid, dim3(THREADS_), 0, st, g);    \
+    else if (m16) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, false, true>), grid, dim3(THREADS_), 0, st, g); \
     else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, false>), grid, dim3(THREADS_), 0, st, g);       \
   } while (0)
   const bool lnx = g.ln_stats != nullptr || g.rowstats != nullptr;
+  // 16x16x32 MFMAs in the K loop of every 3x3 convolution (measured inside the captured graphs: UNet forward -0.17 ms, VAE decode
+  // -0.65 ms; alone the large convolutions gain 5-11 %).  The 1x1 / linear launches keep 32x32x16: their K loops are short, they are
+  // not power-limited, and the re-layout of the accumulators before the epilogue costs more than the shape saves (+0.05 ... +0.35 ms
+  // for K thresholds 2048 ... 256).  SD_GEMM_M16 / SD_GEMM_M16_1X1 = <minimum K, 0 = off> override the rule for A/B runs.
+  static const int m16_env = getenv("SD_GEMM_M16") ? atoi(getenv("SD_GEMM_M16")) : 256;
+  static const int m16_1x1 = getenv("SD_GEMM_M16_1X1") ? atoi(getenv("SD_GEMM_M16_1X1")) : 0;
+  const bool m16 = !lnx && (d->taps == 9 ? (m16_env && g.K >= m16_env) : (m16_1x1 && g.K >= m16_1x1));
   if (big && spread) GEMM_LAUNCH(4, 2, 5, 64, 2, true, 2, 512);
   else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) GEMM_LAUNCH(2, 2, 2, 64, 2, true, 2, 256);
   else if (big) GEMM_LAUNCH(4, 2, 5, 64, 2, false, 2, 512);
