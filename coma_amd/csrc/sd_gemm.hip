@@ -136,8 +136,12 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // residual / GEGLU / GroupNorm column statistics -> fp16 output (or fp32 split-K slab), staged through LDS per wave.
 // LNX = true: the variant for GEMMs that fold a LayerNorm (ln_stats) or leave row statistics for one (rowstats); it carries no
 // GroupNorm column statistics, and vice versa -- the two sets of live registers never have to fit next to the accumulators together.
-template <int WM, int WN, int TN, int TM, bool LNX>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)[TM][TN], _Float16* lds, const int m0, const int n0,
+// accq(i, j, q) = the q-th register quad of output tile (i, j) of this wave: four consecutive columns starting at column qcol(q) of row
+// qrow(q) of the tile.  32x32x16 MFMAs (M16 = false): row = lane & 31, column 8 q + 4 (lane >> 5).  16x16x32 MFMAs (M16 = true): quad
+// q = 2 a + b is sub-tile (a, b): row 16 a + (lane & 15), column 16 b + 4 (lane >> 4).  Everything after the staging write works on the
+// row-major read-back and does not care.
+template <int WM, int WN, int TN, int TM, bool LNX, bool M16, class AccQ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Float16* lds, const int m0, const int n0,
                                               const int wave, const int lane, const long long z, const bool split) {
   constexpr int EP_STRIDE = 32 + 4;                 // floats per staged row (one 32x32 MFMA tile per wave at a time)
   const int wr = wave / WN, wc = wave % WN;
@@ -150,20 +154,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
   __syncthreads();                              // every wave is done with the operand tiles (all DMA drained)
   float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
   const int lrow = lane & 31, hh = lane >> 5;
+  auto qrow = [&](int q) { return M16 ? 16 * (q >> 1) + (lane & 15) : lrow; };
+  auto qcol = [&](int q) { return M16 ? 16 * (q & 1) + 4 * (lane >> 4) : 8 * q + 4 * hh; };
   if (split) {
     float* part = g.partial + (long long)blockIdx.y * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int row = m0 + wr * (TM * 32) + i * 32 + lrow;
-      if (row >= g.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int col = n0 + wc * (TN * 32) + j * 32 + 8 * q + 4 * hh;
-          if (col < g.N)   // N % 8 == 0 on this path
-            *reinterpret_cast<float4*>(part + (long long)row * g.N + col) =
-                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          const int row = m0 + wr * (TM * 32) + i * 32 + qrow(q);
+          const int col = n0 + wc * (TN * 32) + j * 32 + qcol(q);
+          if (row < g.M && col < g.N)   // N % 8 == 0 on this path
+            *reinterpret_cast<float4*>(part + (long long)row * g.N + col) = accq(i, j, q);
         }
     }
     return;
@@ -191,51 +195,55 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
       for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c = ncolw + p * 64 + 8 * q + 4 * hh;
+          const int c = ncolw + p * 64 + qcol(q);
           hbv[p][q] = half4{0, 0, 0, 0};
           hbg[p][q] = half4{0, 0, 0, 0};
           if (g.bias) { hbv[p][q] = *reinterpret_cast<const half4*>(g.bias + c); hbg[p][q] = *reinterpret_cast<const half4*>(g.bias + c + 32); }
         }
-      float ln_mu[TM], ln_r[TM];                             // folded LayerNorm: this lane's row of each tile
+      float ln_mu[TM][2], ln_r[TM][2];                       // folded LayerNorm: this lane's row(s) of each tile (two with M16)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ln_mu[i] = 0.0f;
-        ln_r[i] = 1.0f;
-        if (LNX && g.ln_stats) {
-          const int rr = min(m0 + wr * (TM * 32) + i * 32 + lrow, g.M - 1);
-          ln_mu[i] = lnst[2 * rr];
-          ln_r[i] = lnst[2 * rr + 1];
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          ln_mu[i][a] = 0.0f;
+          ln_r[i][a] = 1.0f;
+          if (LNX && g.ln_stats) {
+            const int rr = min(m0 + wr * (TM * 32) + i * 32 + qrow(2 * a), g.M - 1);
+            ln_mu[i][a] = lnst[2 * rr];
+            ln_r[i][a] = lnst[2 * rr + 1];
+          }
         }
-      }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float4 sv = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
           if (LNX && g.ln_stats) {
-            const int c = ncolw + p * 64 + 8 * q + 4 * hh;
+            const int c = ncolw + p * 64 + qcol(q);
             sv = *reinterpret_cast<const float4*>(g.ln_colsum + c);
             sg = *reinterpret_cast<const float4*>(g.ln_colsum + c + 32);
           }
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             half4 o;
+            const float4 qv = accq(i, 2 * p, q), qg = accq(i, 2 * p + 1, q);
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-              f32x2 av = {acc[i][2 * p][4 * q + e], acc[i][2 * p][4 * q + e + 1]};
-              f32x2 ag = {acc[i][2 * p + 1][4 * q + e], acc[i][2 * p + 1][4 * q + e + 1]};
+              f32x2 av = e == 0 ? (f32x2){qv.x, qv.y} : (f32x2){qv.z, qv.w};
+              f32x2 ag = e == 0 ? (f32x2){qg.x, qg.y} : (f32x2){qg.z, qg.w};
               if (LNX && g.ln_stats) {
                 const f32x2 cv = e == 0 ? (f32x2){sv.x, sv.y} : (f32x2){sv.z, sv.w};
                 const f32x2 cg = e == 0 ? (f32x2){sg.x, sg.y} : (f32x2){sg.z, sg.w};
-                av = ln_r[i] * (av - ln_mu[i] * cv);
-                ag = ln_r[i] * (ag - ln_mu[i] * cg);
+                const int a = M16 ? (q >> 1) : 0;
+                av = ln_r[i][a] * (av - ln_mu[i][a] * cv);
+                ag = ln_r[i][a] * (ag - ln_mu[i][a] * cg);
               }
               const f32x2 r = (av + (f32x2){(float)hbv[p][q][e], (float)hbv[p][q][e + 1]}) *
                               gelu_erf2(ag + (f32x2){(float)hbg[p][q][e], (float)hbg[p][q][e + 1]});
               o[e] = (_Float16)r.x;
               o[e + 1] = (_Float16)r.y;
             }
-            *reinterpret_cast<half4*>(gs + (i * 32 + lrow) * GST + p * 32 + 8 * q + 4 * hh) = o;
+            *reinterpret_cast<half4*>(gs + (i * 32 + qrow(q)) * GST + p * 32 + qcol(q)) = o;
           }
         }
       }
@@ -326,8 +334,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
         for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) =
-              make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+          *reinterpret_cast<float4*>(stage + qrow(q) * EP_STRIDE + qcol(q)) = accq(i, j, q);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int soff_out = __builtin_amdgcn_readfirstlane((i * 32 * g.ldo + j * 32) * 2);
@@ -461,8 +468,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float16v (&acc)
       const int mbase = m0 + wr * (TM * 32) + i * 32;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(stage + lrow * EP_STRIDE + 8 * q + 4 * hh) =
-            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        *reinterpret_cast<float4*>(stage + qrow(q) * EP_STRIDE + qcol(q)) = accq(i, j, q);
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -743,7 +749,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   // M16: the K loop runs on v_mfma_f32_16x16x32_f16 (a 32 x 32 output tile = 2 x 2 of them).  Same flops per clock as 32x32x16, but
   // less power per flop: under the 1400 W package cap a register-resident loop of them sustains 1.95 PF against 1.69 PF
   // (scripts/probes/mfma_shape.hip), and the vendor GEMM uses this shape.  acc16[2i+a][2j+b] holds rows 16a + (lane & 15), columns
-  // 16b + 4 (lane >> 4) + e of tile (i, j); it is re-laid into `acc` through LDS before the epilogue.
+  // 16b + 4 (lane >> 4) + e of tile (i, j); the epilogue takes either layout (gemm_epilogue's accq / qrow / qcol).
   float4v acc16[M16 ? 2 * TM : 1][M16 ? 2 * TN : 1];
   if constexpr (M16) {
 #pragma unroll
@@ -847,34 +853,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   dbg_stamp(g, 2);
 
   if constexpr (M16) {
-    // re-lay the 16 x 16 sub-tiles into the 32 x 32 C layout the epilogue works on, one tile at a time through this wave's staging rows
-    wait_vmcnt<0>();
-    __syncthreads();                              // every wave is done with the operand tiles
-    float* stage = reinterpret_cast<float*>(lds) + wave * (32 * EP_STRIDE);
-    const int r16 = lane & 15, q16 = lane >> 4, r32 = lane & 31, h32 = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const float4v v = acc16[2 * i + a][2 * j + b];
-            *reinterpret_cast<float4*>(stage + (16 * a + r16) * EP_STRIDE + 16 * b + 4 * q16) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(stage + r32 * EP_STRIDE + 8 * q + 4 * h32);
-          acc[i][j][4 * q] = v.x; acc[i][j][4 * q + 1] = v.y; acc[i][j][4 * q + 2] = v.z; acc[i][j][4 * q + 3] = v.w;
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
+    gemm_epilogue<WM, WN, TN, TM, LNX, true>(g, [&](int i, int j, int q) {
+      const float4v v = acc16[2 * i + (q >> 1)][2 * j + (q & 1)];
+      return make_float4(v[0], v[1], v[2], v[3]);
+    }, lds, m0, n0, wave, lane, z, split);
+  } else {
+    gemm_epilogue<WM, WN, TN, TM, LNX, false>(g, [&](int i, int j, int q) {
+      return make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }, lds, m0, n0, wave, lane, z, split);
   }
-  gemm_epilogue<WM, WN, TN, TM, LNX>(g, acc, lds, m0, n0, wave, lane, z, split);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   dbg_stamp(g, 3);
 }
@@ -1067,12 +1054,12 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
     else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, false>), grid, dim3(THREADS_), 0, st, g);       \
   } while (0)
   const bool lnx = g.ln_stats != nullptr || g.rowstats != nullptr;
-  // 16x16x32 MFMAs in the K loop of every 3x3 convolution (measured inside the captured graphs: UNet forward -0.17 ms, VAE decode
-  // -0.65 ms; alone the large convolutions gain 5-11 %).  The 1x1 / linear launches keep 32x32x16: their K loops are short, they are
-  // not power-limited, and the re-layout of the accumulators before the epilogue costs more than the shape saves (+0.05 ... +0.35 ms
-  // for K thresholds 2048 ... 256).  SD_GEMM_M16 / SD_GEMM_M16_1X1 = <minimum K, 0 = off> override the rule for A/B runs.
+  // 16x16x32 MFMAs in the K loop of every launch with K >= 256 (measured inside the captured graphs, A B A B: UNet forward -0.2 ms from the
+  // 3x3 convolutions -- the power-limited ones -- and another -0.45 ms from the 1x1 / linear launches, most of it at K = 320; VAE decode
+  // -0.65 ms).  SD_GEMM_M16 / SD_GEMM_M16_1X1 = <minimum K, 0 = off> override the rule for A/B runs; the LayerNorm-folding variants
+  // (optional, off by default) keep 32x32x16.
   static const int m16_env = getenv("SD_GEMM_M16") ? atoi(getenv("SD_GEMM_M16")) : 256;
-  static const int m16_1x1 = getenv("SD_GEMM_M16_1X1") ? atoi(getenv("SD_GEMM_M16_1X1")) : 0;
+  static const int m16_1x1 = getenv("SD_GEMM_M16_1X1") ? atoi(getenv("SD_GEMM_M16_1X1")) : 256;
   const bool m16 = !lnx && (d->taps == 9 ? (m16_env && g.K >= m16_env) : (m16_1x1 && g.K >= m16_1x1));
   if (big && spread) GEMM_LAUNCH(4, 2, 5, 64, 2, true, 2, 512);
   else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) GEMM_LAUNCH(2, 2, 2, 64, 2, true, 2, 256);
