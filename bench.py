@@ -330,7 +330,7 @@ def bench_occupancy(args, dev, world, rank):
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
 #   profiles/r02_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
 #   profiles/r02_contact_pmc.txt         FETCH_SIZE 1.91551e6 KiB, WRITE_SIZE 3.71066e6 KiB per contact_accumulate launch
-UNET_GEMM_PMC_TRAFFIC_BYTES = int(160.40e6)
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(160.38e6)
 CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91551e6 + 3.71066e6) * 1024)
 
 
