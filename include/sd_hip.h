@@ -33,7 +33,9 @@ extern "C" {
                                16-byte LDS load per MFMA operand (vt_perm16 = 1).  n is rounded up to 16 columns (ldo must cover them);
                                columns whose source row is >= n hold a clamped finite row */
 /* bits 20..27 select kernel variants for tuning runs (scripts/time_gemm.py): 20 = generic 128x128 tiles only, 21 = 128x320
- * tile, 22 = tile DMA in one burst, 23 = 4-wave 128x320 tile, 24..27 = forced split-K factor, 28 = tap-major K order for 3x3.  Results are identical. */
+ * tile, 22 = tile DMA in one burst, 23 = 4-wave 128x320 tile, 24..27 = forced split-K factor, 28 = tap-major K order for 3x3.  Results agree to
+ * fp32 summation order.  Process-wide overrides for A/B runs inside a captured graph (read once): SD_GEMM_TUNE / SD_GEMM_TUNE_1X1 / SD_GEMM_TUNE_3X3 =
+ * <mask of these bits>, SD_GEMM_FORCE="N,K,mask;...", SD_GEMM_M16 / SD_GEMM_M16_1X1 = <minimum K for the 16x16x32 K loop, 0 = 32x32x16 everywhere>. */
 #define SD_EPI_TUNING_MASK 0x1ff00000
 
 /* out[m, n] = sum_k A[m, k] * W[n, k] (+ epilogue) with A gathered from one or two NHWC sources:
