@@ -44,6 +44,8 @@ def cat_of(tag):
 
 groups = collections.OrderedDict()
 for fn, (tag, fl) in zip(unet.g.launches, unet.g.tags):
+    if fn is None:
+        continue
     groups.setdefault(cat_of(tag), []).append(fn)
 
 
@@ -63,7 +65,7 @@ def measure(fns, seconds=1.0):
 
 idle0 = energy_uj(); time.sleep(1.0); idle_w = (energy_uj() - idle0) * 1e-6
 print(f"idle power {idle_w:.0f} W")
-fj, ft = measure(list(unet.g.launches), 2.0)
+fj, ft = measure([f for f in unet.g.launches if f is not None], 2.0)
 print(f"whole forward (eager): {ft * 1e3:.2f} ms, {fj:.2f} J -> {fj / ft:.0f} W")
 rows = []
 for cat, fns in groups.items():
