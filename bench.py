@@ -128,6 +128,7 @@ def bench_inpaint(args, dev, world, rank):
         # UNet launch list, outside the timed region, same process
         prof = pipe.unet.g.profile(reps=2)
         gemm = [(fl, ms) for tag, fl, ms in prof if tag.startswith("gemm")]
+        alg_bytes = sum(b for (tag, _), b in zip(pipe.unet.g.tags, pipe.unet.g.alg_bytes) if tag.startswith("gemm"))
         attn = [(fl, ms) for tag, fl, ms in prof if tag.startswith("attention")]
         tot_ms = sum(ms for _, _, ms in prof)
         g_fl, g_ms = sum(f for f, _ in gemm), sum(m for _, m in gemm)
@@ -147,7 +148,10 @@ def bench_inpaint(args, dev, world, rank):
             "roofline": {"bound": "mfma", "kernel": "sd::conv_gemm_kernel<WM,WN,TN,BK,STAGES> (all conv3x3/1x1/linear launches of one UNet forward)",
                          "achieved": g_fl / g_ms / 1e9, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, "launches": len(gemm),
-                         "avg_launch_ms": g_ms / len(gemm), "flops_per_forward": g_fl, "traffic": UNET_GEMM_PMC_TRAFFIC_BYTES if B == 8 else None,
+                         "avg_launch_ms": g_ms / len(gemm), "flops_per_forward": g_fl,
+                         "algorithmic_bytes": alg_bytes / len(gemm), "algorithmic_bytes_what": "per launch, mean over the launch list: every input "
+                         "activation, weight, bias / residual tile read once + the output written once (fp16)",
+                         "traffic": UNET_GEMM_PMC_TRAFFIC_BYTES if B == 8 else None,
                          "traffic_source": "profiles/r02_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
                                            "the launches of eager UNet forwards at batch 16 (fabric-side requests of the 8 L2s: "
                                            "weights are pulled once per XCD and mostly hit the Infinity Cache)",
@@ -203,8 +207,8 @@ def bench_contact(args, dev, world, rank):
 
     for _ in range(warmup):
         coma.accumulate_device(hv, hn, ov, on)
-        if world > 1:
-            coma.all_reduce()
+    if world > 1:
+        coma.all_reduce()                           # warm-up of the collective (communicator set-up is not part of the job)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
@@ -212,8 +216,15 @@ def bench_contact(args, dev, world, rank):
         ev[i][0].record()
         coma.accumulate_device(hv, hn, ov, on)      # same stream as the events (torch current stream)
         ev[i][1].record()
-        if world > 1:
-            coma.all_reduce()
+    t_ar = 0.0
+    if world > 1:
+        # north_star: the collective runs ONCE, on the final affordance histogram -- K accumulation steps, then one
+        # all-reduce(SUM) of the state; it is inside the timed region and also reported on its own
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        coma.all_reduce()
+        torch.cuda.synchronize()
+        t_ar = time.perf_counter() - t1
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -230,10 +241,10 @@ def bench_contact(args, dev, world, rank):
         "metric": "vertex-pair contacts/sec (ComA K1-K3 accumulation; BASELINE metric part 2)",
         "value": world * S * H * O * steps / dt, "unit": "vertex-pair contacts/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "final_allreduce_ms": t_ar * 1e3 if world > 1 else None,
         "config": {"workload": f"ComA contact+orientation accumulation, H={H} SMPL-X verts x O={O} object points x "
                                f"N={N} bins, {S} samples per GPU per step (BASELINE.json config 4 per-GPU slice)"
-                               + (", + RCCL all-reduce(SUM) of the ComA state every step" if world > 1 else ""),
+                               + (f"; ONE RCCL all-reduce(SUM) of the ComA state after the {steps} steps, inside the timed region" if world > 1 else ""),
                    "parallelism": f"samples sharded over {world} GPU(s)"},
         "roofline": {"bound": "fp32_valu", "kernel": "coma::contact_accumulate_kernel", "achieved": achieved,
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
@@ -265,44 +276,69 @@ def bench_adaptive(args, dev, world, rank):
         return pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=50,
                     strength=0.98, guidance_scale=11.0, generator=gen, output_type="u8", use_adaptive_mask=True,
                     enforce_full_mask_ratio=0.0, human_detection_thres=0.015).images
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     one(0)
-    torch.cuda.synchronize()
+    barrier()
     n = 2
     t0 = time.perf_counter()
     for k in range(n):
         one(1 + k)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n / AB
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item()) / n / AB
     del pipe
     torch.cuda.empty_cache()
     if rank != 0:
         return None
-    return {"metric": "adaptive-mask HOI images/s (49 steps, 21 mask re-estimations)", "value": world / dt, "unit": "images/s",
-            "s_per_image": dt, "config": {"workload": f"config 3 shape: full adaptive loop, synthetic mask plug-in, 512x512, {AB} images per call"}}
+    return {"metric": "adaptive-mask HOI images/s (49 steps, 21 mask re-estimations)", "value": world / dt, "unit": "images/s", "n_gpus": world,
+            "s_per_image": dt, "config": {"workload": f"config 3 shape: full adaptive loop, synthetic mask plug-in, 512x512, {AB} images per call per GPU"}}
 
 
 def bench_occupancy(args, dev, world, rank):
-    """BASELINE.json config 5, one GPU's share: human-vertex rows are sharded over 8 GPUs (1310 of 10475 rows each), every rank
-    splats all S=2000 samples into its [H/8, 128^3] grid (11 GB), reduces its rows and the [R,R,R] result is MAX-all-reduced."""
+    """BASELINE.json config 5, one GPU's share: human-vertex rows are sharded over the ranks of an 8-GPU job (1310 of 10475 rows
+    each; weak scaling: every rank of this run holds such a share), every rank runs all S=2000 samples through the fused pass over
+    its [1310, 128^3] grid (11 GB), and the [R,R,R] field is MAX-all-reduced (NaN-propagating) when there is more than one rank."""
     from coma_amd import dist as cdist
     from utils.coma_occupancy import ComA_Occupancy
     H, R, S = 1310, 128, 2000
     occ = ComA_Occupancy(scale_tolerance=3.0, human_res=H, obj_res=1, normal_res=0, spatial_res=R, device=dev)
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     q = (torch.rand([S, H, 3], generator=g, device=dev) * 2.6 - 1.3).contiguous()      # ~21 % of the points fall outside the grid
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
     occ.accumulate_device(q[:8])
-    occ.return_aggregated_spatial_grids()                # warm-up of the fused pass
-    torch.cuda.synchronize()
-    occ.reset()
-    a, b = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-    a.record()
-    occ.accumulate_device(q)                             # staged only: the reducer below runs splat + row sums + max as one pass
-    out = occ.return_aggregated_spatial_grids()
+    out = occ.return_aggregated_spatial_grids()          # warm-up of the fused pass
     if world > 1:
-        cdist.all_reduce_max_nan(out)
-    b.record()
-    torch.cuda.synchronize()
-    ms = a.elapsed_time(b)
+        cdist.all_reduce_max_nan(out)                    # ... and of the collective
+    reps, ms_kern = 3, []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        occ.reset()
+        a, b = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+        a.record()
+        occ.accumulate_device(q)                         # staged only: the reducer below runs splat + row sums + max as one pass
+        out = occ.return_aggregated_spatial_grids()
+        b.record()
+        if world > 1:
+            cdist.all_reduce_max_nan(out)
+        ms_kern.append((a, b))
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    ms_step = float(t.item()) / reps * 1e3               # includes grid.zero_() of reset() (an 11 GB memset) and the collective
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ms_kern]))
     # the unfused route (global-atomic splat, row sums, normalise + max: three passes over the grid) for comparison
     occ.reset()
     c, d = (torch.cuda.Event(enable_timing=True) for _ in range(2))
@@ -312,25 +348,38 @@ def bench_occupancy(args, dev, world, rank):
     d.record()
     torch.cuda.synchronize()
     ms_unfused = c.elapsed_time(d)
+    del occ
+    torch.cuda.empty_cache()
     if rank != 0:
         return None
-    # algorithmic bytes of SURVEY.md 8d structure B: the per-vertex grid written once + the samples re-read once per x-plane slab
+    # algorithmic bytes of SURVEY.md 8d structure B: the per-vertex grid written once + the samples re-read once per x-plane slab;
+    # hard floor: the grid written once and nothing else
     slabs = R // max(1, 20480 // (R * R)) if R * R <= 20480 else R
     alg = 4 * H * R**3 + 12 * S * H * slabs
+    floor = 4 * H * R**3
     return {"metric": "occupancy splats/s (ComA_Occupancy K5+K6 fused, R=128)", "value": world * S * H / (ms * 1e-3), "unit": "splats/s",
-            "dense_equivalent_voxel_tests_per_s": world * S * H * R**3 / (ms * 1e-3), "fused_ms": ms, "unfused_ms": ms_unfused,
-            "config": {"workload": f"H={H} rows/GPU (10475/8), R={R}, S={S}, scale_tolerance 3 (config 5 per-GPU share): zero grid, splat, "
-                                   "row sums, max over humans; raw per-vertex grid left in HBM"},
+            "n_gpus": world, "dense_equivalent_voxel_tests_per_s": world * S * H * R**3 / (ms * 1e-3), "fused_ms": ms, "unfused_ms": ms_unfused,
+            "ms_per_step_with_reset_and_collective": ms_step,
+            "config": {"workload": f"H={H} rows/GPU (10475/8), R={R}, S={S}, scale_tolerance 3 (config 5 per-GPU share): splat, row sums, "
+                                   "max over humans in one pass, raw per-vertex grid left in HBM"
+                                   + ("; NaN-propagating all-reduce(MAX) of the [R,R,R] field per step" if world > 1 else ""),
+                       "parallelism": f"rows sharded, {world} rank(s) each holding a 1310-row share"},
             "roofline": {"bound": "hbm", "kernel": "coma::occupancy_fused_kernel (+ rowprep, groupmax)", "achieved": alg / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes": alg, "traffic": None}}
+                         "algorithmic_bytes": alg, "hard_floor_bytes": floor, "hard_floor_frac": floor / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": OCCUPANCY_PMC_TRAFFIC_BYTES, "traffic_source": OCCUPANCY_PMC_SOURCE}}
 
 
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
 #   profiles/r02_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
 #   profiles/r02_contact_pmc.txt         FETCH_SIZE 1.91551e6 KiB, WRITE_SIZE 3.71066e6 KiB per contact_accumulate launch
+#   profiles/r02_inpaint_pmc.txt:20-25,391-396  occupancy at the config-5 share: fused WRITE 11.13 GB + 2 * FETCH 0.095 GB, rowprep 0.15 GB,
+#                                        groupmax 0.06 GB
 UNET_GEMM_PMC_TRAFFIC_BYTES = int(160.38e6)
+OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.53e9)
+OCCUPANCY_PMC_SOURCE = ("profiles/r02_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep + occupancy_fused + occupancy_groupmax "
+                        "at H=1310, R=128, S=2000 (the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM)")
 CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91551e6 + 3.71066e6) * 1024)
 
 
@@ -377,20 +426,23 @@ def main():
         args.contact_steps = args.steps
     inp = None if (args.workload == "contact" and args.no_secondary) else bench_inpaint(args, dev, world, rank)
     con = None if (args.workload == "inpaint" and args.no_secondary) else bench_contact(args, dev, world, rank)
+    occ = ada = None
+    if not args.no_secondary:          # collective sections: every rank enters them, rank 0 gets the record
+        try:
+            occ = bench_occupancy(args, dev, world, rank)
+        except Exception as e:   # noqa: BLE001  (never lose the primary line; a failure is the same on every rank)
+            occ = {"error": repr(e)}
+        try:
+            ada = bench_adaptive(args, dev, world, rank)
+        except Exception as e:   # noqa: BLE001
+            ada = {"error": repr(e)}
     if rank == 0:
         primary, secondary = (inp, con) if args.workload == "inpaint" else (con, inp)
         out = dict(primary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_inpaint() if args.workload == "inpaint" else cpu_baseline()
-        if not args.no_secondary and world == 1:      # single-GPU extras (rank 0 alone must never enter a collective)
-            try:
-                out["occupancy"] = bench_occupancy(args, dev, world, rank)
-            except Exception as e:   # noqa: BLE001  (never lose the primary line)
-                out["occupancy"] = {"error": repr(e)}
-            try:
-                out["adaptive_loop"] = bench_adaptive(args, dev, world, rank)
-            except Exception as e:   # noqa: BLE001
-                out["adaptive_loop"] = {"error": repr(e)}
+        if not args.no_secondary:
+            out["occupancy"], out["adaptive_loop"] = occ, ada
         if secondary is not None:
             sec = dict(secondary)
             if world == 1 and not args.no_cpu_baseline:

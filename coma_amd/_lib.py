@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "sd_vae_sample": (_i, [_vp, _i, _vp, _f, _i64, _vp, _vp, _vp]),
     "sd_add_noise": (_i, [_vp, _vp, _f, _i64, _vp, _vp]),
     "sd_mask_adapt": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sd_mask_adapt_batched": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -82,7 +84,16 @@ def lib():
     return _lib
 
 
+_switched = threading.local()       # device that was current before stream_ptr() switched it for one launch
+
+
 def check(rc: int, what: str):
+    """Raise on a non-zero return code.  Every wrapper calls this right after its launch, so it is also where the device that
+    stream_ptr() made current for that launch is handed back to the caller (the process-wide current device is not ours to change)."""
+    prev = getattr(_switched, "dev", None)
+    if prev is not None:
+        _switched.dev = None
+        torch.cuda.set_device(prev)
     if rc != 0:
         raise ComaHipError(f"{what} failed ({rc}): {lib().coma_last_error().decode()}")
 
@@ -101,11 +112,14 @@ def ptr(t: torch.Tensor | None, dtype=None, name="tensor"):
 
 
 def stream_ptr(device=None):
-    """Current stream of `device`, and that device made current for the launch that follows: the C ABI launches under HIP's
-    current device, so a tensor on cuda:1 with cuda:0 current would otherwise meet a stream of another device."""
+    """Current stream of `device`, and that device made current for the ONE launch that follows (the C ABI launches under HIP's
+    current device, so a tensor on cuda:1 with cuda:0 current would otherwise meet a stream of another device); check() puts
+    the caller's device back."""
     if device is not None:
         dev = torch.device(device)
         if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            if getattr(_switched, "dev", None) is None:
+                _switched.dev = torch.cuda.current_device()          # restored by check() after the launch
             torch.cuda.set_device(dev)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 

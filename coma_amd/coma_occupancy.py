@@ -166,16 +166,28 @@ class ComA_Occupancy:
     def accumulate_device(self, q, lazy=True):
         """q: f32 [S,H,3] on the HIP device, already relative to object point 0."""
         assert tuple(q.shape[1:]) == (self.human_res, 3)
-        if lazy and self._pristine and self._fusable():
+        if lazy and self._pristine and self._fusable(extra=q.shape[0]):
             self._pending.append(q)
             return
         self._materialize()
         self._field_all = None
         self._splat(q)
 
-    def _fusable(self):
+    def _window(self):
+        """Candidate cells per axis a sample can reach (what coma_occupancy_fused is told; it rounds up to a power of two)."""
+        voxel, thres = float(self.spatial_grid_metadata["voxel_size"]), float(self.rel_dist_thres)
+        return int(np.ceil(2.0 * thres / voxel - 1e-9)) + 2
+
+    def _fusable(self, extra=0):
+        """Can the fused pass take the staged samples (+ `extra` more)?  Mirrors every size check of coma_occupancy_fused:
+        cubic grid, R*R % 4 == 0, an x-plane fits the LDS slab, window <= 16 cells (scale_tolerance is a free CLI float) and
+        fewer than 65536 samples per call (16-bit counters)."""
         R = self.spatial_res
-        return self.N_x == self.N_y == self.N_z == R and (R * R) % 4 == 0 and R * R <= 20480 and R <= 255
+        w = self._window()
+        w2 = w if w <= 2 else 1 << (w - 1).bit_length()
+        staged = sum(int(p.shape[0]) for p in self._pending) + int(extra)
+        return (self.N_x == self.N_y == self.N_z == R and (R * R) % 4 == 0 and R * R <= 20480 and R <= 255 and w2 <= 16
+                and staged < 65536)
 
     def _flush(self):
         pend, self._pending = self._pending, []
@@ -214,11 +226,10 @@ class ComA_Occupancy:
         L = _lib.lib()
         q = self._pending[0] if len(self._pending) == 1 else torch.cat(self._pending, dim=0)
         q = q.contiguous()
-        self._pending, self._pristine = [], False
         S, H, R = int(q.shape[0]), self.human_res, self.spatial_res
         dev = self._grid.device
         voxel, thres = float(self.spatial_grid_metadata["voxel_size"]), float(self.rel_dist_thres)
-        window = int(np.ceil(2.0 * thres / voxel - 1e-9)) + 2
+        window = self._window()
         nbytes = int(L.coma_occupancy_fused_workspace_bytes(S, H, R))
         ws = getattr(self, "_ws", None)
         if ws is None or ws.numel() < nbytes:
@@ -230,6 +241,7 @@ class ComA_Occupancy:
                                     self._cut(thres), window, _lib.ptr(sel), 1, _lib.ptr(self._grid, torch.float32),
                                     _lib.ptr(rowsum), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
         _lib.check(rc, "coma_occupancy_fused")
+        self._pending, self._pristine = [], False          # only once the pass has been accepted: a refusal loses nothing
         return out
 
     def _reduce(self, human_indices):
@@ -250,6 +262,25 @@ class ComA_Occupancy:
         self._materialize()
         self._field_all = None
         return self._classic_reduce(sel)
+
+    def reduce_keep_raw(self, human_indices=None, want_raw=True):
+        """(raw per-vertex counts, field) of this object's rows: the reduction of return_aggregated_spatial_grids plus the RAW
+        grid the reference would have exported before it (used by the row-sharded multi-GPU path, coma_amd/dist.py).  When the
+        samples are still staged this is the one fused pass -- the counts it leaves in place are raw until somebody looks at the
+        attribute -- otherwise the grid is cloned before the in-place normalisation.  An empty selection gives a -inf field."""
+        fused = bool(self._pending) and self._pristine and self._fusable()
+        raw = None
+        if want_raw and not fused:
+            raw = self.spatial_occupancy_grids.clone()
+        if human_indices is not None and len(human_indices) == 0:
+            self.normalize_prob_grid_for_spatials()
+            field = torch.full([self.N_x, self.N_y, self.N_z], float("-inf"), dtype=torch.float32, device=self._grid.device)
+        else:
+            field = self._reduce(human_indices)
+        if want_raw and fused:
+            assert self._needs_norm, "the fused pass leaves raw counts"
+            raw = self._grid
+        return raw, field
 
     def _classic_reduce(self, sel):
         L = _lib.lib()

@@ -209,6 +209,65 @@ __global__ void mask_adapt_kernel(const uint8_t* __restrict__ seg, const uint8_t
     masked_img[p * cpad + c] = c < 3 ? (_Float16)(m ? 0.0f : image[(long long)c * H * W + p]) : (_Float16)0.0f;
 }
 
+
+// ---- batched form (B images per call, area test on the device: the adaptive loop never syncs with the host)
+// pass 1: horizontal (2k+1) box max of seg into `rowmax`, and area[b] += sum(seg[b]) (the VALUE sum, as `mask.sum()` at :1132)
+__global__ void mask_rowdilate_kernel(const uint8_t* __restrict__ seg, int H, int W, int iters, uint8_t* __restrict__ rowmax,
+                                      int* __restrict__ area) {
+  extern __shared__ uint8_t row[];
+  const int y = blockIdx.x, b = blockIdx.y;
+  const uint8_t* src = seg + ((long long)b * H + y) * W;
+  int part = 0;
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    uint8_t v = src[x];
+    row[x] = v;
+    part += v;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+  if ((threadIdx.x & 63) == 0 && part) atomicAdd(area + b, part);
+  __syncthreads();
+  for (int x = threadIdx.x; x < W; x += blockDim.x) {
+    const int x0 = max(0, x - iters), x1 = min(W - 1, x + iters);
+    int m = 0;
+    for (int xx = x0; xx <= x1; ++xx) m |= row[xx];
+    rowmax[((long long)b * H + y) * W + x] = (uint8_t)(m != 0);
+  }
+}
+
+// pass 2: vertical (2k+1) max over `rowmax`, AND with the default mask (or the default mask itself when the whole call is forced
+// to it or the image's segmentation is smaller than area_thres), and the three products.  The masked image leaves as ONE 16-byte
+// store per pixel (channels 0-7: 3 data + 5 zeros); channels >= 8 are rewritten as zeros only when write_pad is set.
+__global__ void mask_finish_kernel(const uint8_t* __restrict__ rowmax, const uint8_t* __restrict__ dflt, int H, int W, int iters,
+                                   int force_default, double area_thres, const int* __restrict__ area,
+                                   const float* __restrict__ image, int cpad, int write_pad, uint8_t* __restrict__ mask_full,
+                                   _Float16* __restrict__ mask_lat, _Float16* __restrict__ masked_img) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const long long p = (long long)y * W + x, img = (long long)b * H * W;
+  const bool use_default = force_default || (double)area[b] < area_thres;
+  int m = dflt[img + p] != 0;
+  if (!use_default && m) {
+    const int y0 = max(0, y - iters), y1 = min(H - 1, y + iters);
+    int any = 0;
+    for (int yy = y0; yy <= y1; ++yy) any |= rowmax[img + (long long)yy * W + x];
+    m = any != 0;
+  }
+  mask_full[img + p] = (uint8_t)m;
+  if ((y & 7) == 0 && (x & 7) == 0) mask_lat[(long long)b * (H >> 3) * (W >> 3) + (y >> 3) * (W >> 3) + (x >> 3)] = (_Float16)(float)m;
+  union { uint4 q; _Float16 h[8]; } v;
+  v.q = make_uint4(0u, 0u, 0u, 0u);
+  if (!m) {
+    const float* ip = image + img * 3 + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v.h[c] = (_Float16)ip[(long long)c * H * W];
+  }
+  uint4* o = reinterpret_cast<uint4*>(masked_img + (img + p) * cpad);
+  o[0] = v.q;
+  if (write_pad)
+    for (int q = 1; q < cpad / 8; ++q) o[q] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 }  // namespace sd
 
 extern "C" int sd_vae_sample(const void* moments, int ld, const float* noise, float scale, int64_t npix, float* latents_f32,
@@ -236,4 +295,24 @@ extern "C" int sd_mask_adapt(const uint8_t* seg, const uint8_t* default_mask, in
   hipLaunchKernelGGL(sd::mask_adapt_kernel, dim3((W + 127) / 128, H), dim3(128), 0, (hipStream_t)stream, seg, default_mask, H, W,
                      dilate_iters, use_default, image_nchw, cpad, mask_full, (_Float16*)mask_latent, (_Float16*)masked_image);
   return sd::check_launch("mask_adapt_kernel");
+}
+
+extern "C" int sd_mask_adapt_batched(const uint8_t* seg, const uint8_t* default_mask, int batch, int H, int W, int dilate_iters,
+                                     int force_default, double area_thres, const float* image_nchw, int cpad, int write_pad,
+                                     uint8_t* mask_full, void* mask_latent, void* masked_image, int32_t* area, uint8_t* scratch,
+                                     void* stream) {
+  if (!default_mask || !image_nchw || !mask_full || !mask_latent || !masked_image || !area || (!force_default && (!seg || !scratch)))
+    return sd::fail(COMA_E_INVALID, "sd_mask_adapt_batched: null pointer");
+  if (batch <= 0 || batch > 65535 || H <= 0 || H > 65535 || W <= 0 || W > 16384 || (H & 7) || (W & 7) || dilate_iters < 0 || cpad < 8 ||
+      (cpad & 7))
+    return sd::fail(COMA_E_INVALID, "sd_mask_adapt_batched: bad sizes (H, W multiples of 8; cpad a multiple of 8)");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(area, 0, sizeof(int32_t) * (size_t)batch, st) != hipSuccess)
+    return sd::fail(COMA_E_LAUNCH, "sd_mask_adapt_batched: memset failed");
+  if (!force_default)
+    hipLaunchKernelGGL(sd::mask_rowdilate_kernel, dim3(H, batch), dim3(256), (size_t)W, st, seg, H, W, dilate_iters, scratch, area);
+  hipLaunchKernelGGL(sd::mask_finish_kernel, dim3((W + 127) / 128, H, batch), dim3(128), 0, st, scratch, default_mask, H, W,
+                     dilate_iters, force_default, area_thres, area, image_nchw, cpad, write_pad, mask_full,
+                     (_Float16*)mask_latent, (_Float16*)masked_image);
+  return sd::check_launch("mask_finish_kernel");
 }

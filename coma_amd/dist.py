@@ -64,36 +64,41 @@ def all_reduce_max_nan(t: torch.Tensor, group=None):
 
 def gather_rows_to_rank0(local: torch.Tensor, n_rows: int, group=None, dst: int = 0):
     """Row-sharded state (rank r holds rows shard_slice(n_rows, r, world)) -> the full [n_rows, ...] tensor on rank `dst`
-    (None on the others).  Used once, for the exported per-vertex occupancy grid; the reduction itself never moves rows."""
+    (None on the others).  Used once, for the exported per-vertex occupancy grid; the reduction itself never moves rows.
+    Every shard is received straight into its slice of ONE preallocated tensor (point-to-point, no padding, no concatenation):
+    rank `dst` holds the full grid plus its own shard and nothing else (the grid is 88 GB at config 5)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    per = -(-n_rows // world)                                   # every shard padded to the largest one
-    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, parts, dst=dst, group=group)
+    local = local.contiguous()
     if rank != dst:
+        if local.shape[0] > 0:
+            dist.send(local, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
         return None
-    rows = [parts[r][:shard_slice(n_rows, r, world)[1] - shard_slice(n_rows, r, world)[0]] for r in range(world)]
-    return torch.cat(rows, dim=0)
+    full = torch.empty((n_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        lo, hi = shard_slice(n_rows, r, world)
+        if hi == lo:
+            continue
+        if r == dst:
+            full[lo:hi].copy_(local)
+        else:
+            dist.recv(full[lo:hi], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+    return full
 
 
-def occupancy_rows_reduce(occ_shard, n_rows: int, human_indices=None, group=None):
-    """SURVEY.md 8e-3 for a row-sharded ComA_Occupancy: gather the raw per-vertex counts to rank 0 (export), normalise and
-    max-reduce the local rows, all-reduce(MAX, NaN-propagating) the [R,R,R] field.  `human_indices` are GLOBAL row indices.
-    Returns (full raw grid on rank 0 else None, field on every rank)."""
+def occupancy_rows_reduce(occ_shard, n_rows: int, human_indices=None, group=None, gather: bool = True):
+    """SURVEY.md 8e-3 for a row-sharded ComA_Occupancy: normalise and max-reduce the local rows (ONE fused pass when the samples
+    are still staged: splat + row sums + max, raw counts left in place), all-reduce(MAX, NaN-propagating) the [R,R,R] field, and
+    -- for the export -- gather the raw per-vertex counts to rank 0.  `human_indices` are GLOBAL row indices.
+    Returns (full raw grid on rank 0 else None [None everywhere when gather=False], field on every rank)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_slice(n_rows, rank, world)
-    full = gather_rows_to_rank0(occ_shard.spatial_occupancy_grids, n_rows, group)
-    if full is not None and full is occ_shard.spatial_occupancy_grids:
-        full = full.clone()                                    # single process: the reduction below normalises in place
     local_sel = None if human_indices is None else [i - lo for i in human_indices if lo <= i < hi]
-    if local_sel is not None and not local_sel:
-        field = torch.full_like(occ_shard.spatial_grid[0], float("-inf")).to(torch.float32)
-        occ_shard.normalize_prob_grid_for_spatials()
-    else:
-        field = occ_shard.return_aggregated_spatial_grids(local_sel)
+    raw, field = occ_shard.reduce_keep_raw(local_sel, want_raw=gather)
     all_reduce_max_nan(field, group)
+    full = gather_rows_to_rank0(raw, n_rows, group) if gather else None
+    if full is not None and full is raw:
+        full = full.clone()                                    # single process: the grid is normalised in place later
     return full, field

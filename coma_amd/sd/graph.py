@@ -18,6 +18,7 @@ class LaunchGraph:
         self.device = torch.device(device)
         self.launches = []          # zero-argument closures
         self.tags = []              # (description, flops) per launch, for profiling
+        self.alg_bytes = []         # algorithmic HBM bytes per launch (inputs read once + output written once)
         self.flops = 0              # algorithmic MFMA flops per run (2*M*N*K of every GEMM-shaped launch)
         self._graph = None
         self._gn_stats = None
@@ -38,9 +39,10 @@ class LaunchGraph:
         return self._gn_stats
 
     # ---- recording
-    def add(self, fn, flops=0, tag=""):
+    def add(self, fn, flops=0, tag="", nbytes=0):
         self.launches.append(fn)
         self.tags.append((tag, flops))
+        self.alg_bytes.append(nbytes)
         self.flops += flops
 
     def conv(self, a0, w, out, *, batch, in_h, in_w, c0, n, out_h=None, out_w=None, a1=None, c1=0, taps=1, **kw):
@@ -64,6 +66,10 @@ class LaunchGraph:
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
                                        c1=c1, taps=taps, **kw),
                  flops=2 * batch * oh * ow * n * taps * (c0 + c1) * z,
+                 # unique bytes: the input activation(s), the weights (shared over z unless strided), bias / residual, the output
+                 nbytes=2 * (z * batch * in_h * in_w * (c0 + c1) + (z if kw.get("stride_w") else 1) * n * taps * (c0 + c1)
+                             + z * M * (n // 2 if kw.get("epi", 0) & ops.EPI_GEGLU else n) * (2 if kw.get("res") is not None else 1)
+                             + (n if kw.get("bias") is not None else 0) + (batch * n if kw.get("bias_bn") is not None else 0)),
                  tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}")
         return out
 

@@ -172,3 +172,13 @@ def mask_adapt(seg, default_mask, image_nchw, mask_full, mask_latent, masked_ima
                                   _p(image_nchw, "image", torch.float32), cpad, _p(mask_full, "mask_full", u8), _p(mask_latent),
                                   _p(masked_image), _stream(mask_full))
     _lib.check(rc, "sd_mask_adapt")
+
+
+def mask_adapt_batched(seg, default_mask, image_nchw, mask_full, mask_latent, masked_image, area, scratch, *, batch, H, W,
+                       dilate_iters, force_default, area_thres, cpad, write_pad=False):
+    u8 = torch.uint8
+    rc = _lib.lib().sd_mask_adapt_batched(_p(seg, "seg", u8), _p(default_mask, "default", u8), batch, H, W, dilate_iters,
+                                          1 if force_default else 0, float(area_thres), _p(image_nchw, "image", torch.float32), cpad,
+                                          1 if write_pad else 0, _p(mask_full, "mask_full", u8), _p(mask_latent), _p(masked_image),
+                                          _p(area, "area", torch.int32), _p(scratch, "scratch", u8), _stream(mask_full))
+    _lib.check(rc, "sd_mask_adapt_batched")

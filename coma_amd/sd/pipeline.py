@@ -188,6 +188,8 @@ class AdaptiveMaskInpaintPipeline:
         self.adaptive_mask_model = None
         self.adaptive_mask_settings = None
         self.safety_checker = None
+        self._noise_log = None          # tests: a list here receives every latent-shaped noise draw, in order
+        self._trace = None              # tests: a callable here is handed the per-step intermediates (device tensors)
 
     # ---- construction helpers
     @classmethod
@@ -253,12 +255,32 @@ class AdaptiveMaskInpaintPipeline:
             negative_prompt_embeds = torch.zeros_like(prompt_embeds)
         return torch.cat([negative_prompt_embeds, prompt_embeds]).to(self.device)      # [uncond | cond]
 
+    def _randn_latent(self, generator):
+        """One draw of latent-shaped noise the way the reference draws it -- `randn_tensor((B,4,h,w), generator, device, fp16)`
+        (prepare_latents :656, DiagonalGaussianDistribution.sample behind :677-680): NCHW element order, the pipeline's fp16
+        dtype, one (1,4,h,w) draw per image from its own generator when a list is given (:676-678), on the generator's device
+        -- returned as fp32 NHWC [B, h*w, 4] on the pipeline's device.  Same seed -> same stream positions as the reference."""
+        B, h, w = self.vae.batch, self.vae.dec.h, self.vae.dec.w
+        gens = generator if isinstance(generator, (list, tuple)) else [generator]
+        if isinstance(generator, (list, tuple)) and len(generator) != B:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {B}. Make sure the batch size matches the length of the generators.")
+        parts = []
+        for g in gens:
+            gdev = g.device if g is not None else self.device
+            n = B if len(gens) == 1 else 1
+            parts.append(torch.randn(n, 4, h, w, generator=g, device=gdev, dtype=torch.float16).to(self.device))
+        noise = torch.cat(parts, 0).to(torch.float32).permute(0, 2, 3, 1).reshape(B, h * w, 4).contiguous()
+        if self._noise_log is not None:
+            self._noise_log.append(noise.clone())
+        return noise
+
     def _encode_vae_image(self, image, generator):
         """image fp16 NHWC already in self.vae.enc.x -> latents fp16 [B,hw,4] scaled by scaling_factor (on device)."""
         enc = self.vae.enc
         mom = enc.encode_static()
         B, n = self.vae.batch, enc.lat_h * enc.lat_w
-        noise = torch.randn(B, n, 4, generator=generator, device=self.device, dtype=torch.float32)
+        noise = self._randn_latent(generator)
         lat32 = torch.empty(B, n, 4, dtype=torch.float32, device=self.device)
         lat16 = torch.empty(B, n, 4, dtype=torch.float16, device=self.device)
         ops.vae_sample(mom, 64, noise, float(self.vae.config.scaling_factor), B * n, lat32=lat32, lat16=lat16)
@@ -325,29 +347,37 @@ class AdaptiveMaskInpaintPipeline:
         default_mask_u8 = (mask[:, 0] >= 0.5).to(torch.uint8).to(dev).contiguous()             # [B,H,W]
         h, w = H // self.vae_scale_factor, W // self.vae_scale_factor
         hw = h * w
-        # 6. latents
+        # 6. latents -- the draw order is the reference's (prepare_latents :653-665): image encode first, then the noise; a
+        # caller-provided `latents` is used as the starting noise as is (no image mix-in even when strength < 1, :662-664)
         if latents is None:
-            noise = torch.randn(B, 4, h, w, generator=generator, device=dev, dtype=torch.float32)
+            if not is_strength_max:
+                ops.nchw_to_nhwc(init_image, self.vae.enc.x, batch=B, c=3, hw=H * W, cpad=64)
+                img_lat32, _ = self._encode_vae_image(init_image, generator)
+            noise = self._randn_latent(generator)
+            if is_strength_max:
+                lat = noise * self.scheduler.init_noise_sigma
+            else:
+                lat = torch.empty_like(noise)
+                ops.add_noise(img_lat32, noise, float(self.scheduler.alphas_cumprod[int(timesteps[0])]), lat)
         else:
             noise = latents.to(dev, torch.float32)
-        lat = noise.permute(0, 2, 3, 1).reshape(B, hw, 4).contiguous() * self.scheduler.init_noise_sigma
-        if not is_strength_max:
-            ops.nchw_to_nhwc(init_image, self.vae.enc.x, batch=B, c=3, hw=H * W, cpad=64)
-            img_lat32, _ = self._encode_vae_image(init_image, generator)
-            a_t = float(self.scheduler.alphas_cumprod[int(timesteps[0])])
-            ops.add_noise(img_lat32, noise.permute(0, 2, 3, 1).reshape(B, hw, 4).contiguous(), a_t, lat)
+            lat = noise.permute(0, 2, 3, 1).reshape(B, hw, 4).contiguous() * self.scheduler.init_noise_sigma
         # 7. mask latents (device glue + VAE encoder graph)
         mask_full = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
         mask_lat = torch.empty(B, hw, dtype=torch.float16, device=dev)
+        area = torch.zeros(B, dtype=torch.int32, device=dev)
+        scratch = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+        self.vae.enc.x.zero_()                # channels >= 8 of the encoder input stay zero from here on
 
-        def set_mask(segs, dilate_iters):
-            """segs[b]: u8 device mask to dilate & intersect with the default mask, or None -> default mask."""
-            for b in range(B):
-                ops.mask_adapt(segs[b], default_mask_u8[b], init_image[b], mask_full[b], mask_lat[b], self.vae.enc.x[b], H=H, W=W,
-                               dilate_iters=dilate_iters, use_default=segs[b] is None, cpad=64)
+        def set_mask(segs, dilate_iters, force_default=False, area_thres=0.0):
+            """segs: u8 [B,H,W] device masks to dilate & intersect with the default mask (None -> default mask); an image
+            whose segmentation sums to less than area_thres keeps the default mask (decided on the device)."""
+            ops.mask_adapt_batched(segs, default_mask_u8, init_image, mask_full, mask_lat, self.vae.enc.x, area, scratch, batch=B,
+                                   H=H, W=W, dilate_iters=dilate_iters, force_default=force_default or segs is None,
+                                   area_thres=area_thres, cpad=64)
             return self._encode_vae_image(None, generator)[1]
 
-        masked_lat = set_mask([None] * B, 0)
+        masked_lat = set_mask(None, 0)
         self._last_masked_lat = masked_lat
         x0 = torch.empty(B, hw, 4, dtype=torch.float32, device=dev)
         # first UNet input (no step yet)
@@ -383,16 +413,17 @@ class AdaptiveMaskInpaintPipeline:
                     for b in range(B):
                         seg = self.adaptive_mask_model(pred_orig_images[b])["mask"]
                         if isinstance(seg, torch.Tensor):
-                            seg = seg.to(device=dev, dtype=torch.uint8).contiguous()
+                            seg = seg.to(device=dev, dtype=torch.uint8)
                         else:
                             seg = torch.from_numpy(np.ascontiguousarray(seg).astype(np.uint8)).to(dev)
                         segs.append(seg)
-                    if use_default:
-                        segs = [None] * B
-                    else:
-                        areas = torch.stack([sg.sum(dtype=torch.int64) for sg in segs]).tolist()       # one sync for the batch
-                        segs = [None if a < 512 * 512 * human_detection_thres else sg for a, sg in zip(areas, segs)]
-                    masked_lat = set_mask(segs, int(self.adaptive_mask_settings.dilate_scheduler(i)))
+                    segs = torch.stack(segs).contiguous()
+                    # `use_default_mask or mask.sum() < 512 * 512 * thres` (:1132): the literal 512 * 512 is the reference's
+                    masked_lat = set_mask(segs, int(self.adaptive_mask_settings.dilate_scheduler(i)), force_default=use_default,
+                                          area_thres=512 * 512 * human_detection_thres)
+                    if self._trace is not None:
+                        self._trace(dict(i=i, t=t, x0=x0, image_u8=pred_orig_images, seg=segs, mask=mask_full, mask_lat=mask_lat,
+                                         masked_lat=masked_lat, lat=lat, area=area))
                     adapted = True
                 ops.cfg_ddim_step(None, 0, lat, None, mask_lat, masked_lat, self.unet.x_in, batch=B, hw=hw,
                                   guidance=guidance_scale, alpha_t=1.0, alpha_prev=1.0)

@@ -172,8 +172,10 @@ class _LatentDist:
 
     def sample(self, generator=None):
         B, h, w = self.vae.batch, self.vae.enc.lat_h, self.vae.enc.lat_w
-        noise = torch.randn(B, h * w, 4, generator=generator, device=self.vae.device, dtype=torch.float32)
-        return self._to_nchw(noise)
+        # drawn as diffusers draws it (randn_tensor(mean.shape, generator, dtype=fp16): NCHW element order), consumed NHWC
+        gdev = generator.device if generator is not None else self.vae.device
+        noise = torch.randn(B, 4, h, w, generator=generator, device=gdev, dtype=torch.float16).to(self.vae.device, torch.float32)
+        return self._to_nchw(noise.permute(0, 2, 3, 1).reshape(B, h * w, 4).contiguous())
 
     def mode(self):
         return self._to_nchw(None)

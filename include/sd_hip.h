@@ -166,6 +166,18 @@ int sd_add_noise(const float* x0, const float* noise, float alpha, int64_t n, fl
 int sd_mask_adapt(const uint8_t* seg, const uint8_t* default_mask, int H, int W, int dilate_iters, int use_default,
                   const float* image_nchw, int cpad, uint8_t* mask_full, void* mask_latent, void* masked_image, void* stream);
 
+/* The same for `batch` images in one call, with the reference's "mask too small -> default mask" test done on the device
+ * (no host round trip per re-estimation):  area[b] = sum(seg[b]) (sum of VALUES, as `mask.sum()`),
+ *   mask[b] = (force_default || (double)area[b] < area_thres) ? default[b] : AND(dilate(seg[b]), default[b]).
+ * seg / default_mask / mask_full: u8 [batch,H,W]; image_nchw fp32 [batch,3,H,W]; mask_latent fp16 [batch, H/8*W/8];
+ * masked_image fp16 NHWC [batch*H*W, cpad], cpad % 8 == 0: channels 0..7 are always written (3 data + zeros), channels >= 8
+ * only when write_pad != 0 (a caller that zero-initialised the buffer once passes 0).  area: int32 [batch] (output);
+ * scratch: u8 [batch,H,W] workspace.  seg / scratch may be NULL when force_default.
+ * replaces: utils/adaptive_mask_inpainting.py:1123-1141 (adapt_mask up to prepare_mask_latents), :686-694. */
+int sd_mask_adapt_batched(const uint8_t* seg, const uint8_t* default_mask, int batch, int H, int W, int dilate_iters,
+                          int force_default, double area_thres, const float* image_nchw, int cpad, int write_pad,
+                          uint8_t* mask_full, void* mask_latent, void* masked_image, int32_t* area, uint8_t* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

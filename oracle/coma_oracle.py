@@ -239,6 +239,33 @@ class OccupancyOracle:
             self.occ[h0:h0 + h_chunk] += (d < self.thres).astype(F32)
         self.used_count += 1
 
+    def aggregate_windowed(self, q, margin=2):
+        """q: f32 [S,H,3] already relative to the object point.  The SAME predicate as aggregate_sample, evaluated only on the
+        cube of cells around each point that can satisfy it (|centre - q| < thres needs every axis within thres; `margin` extra
+        cells each side) -- what makes S = 2000 samples at R = 128 checkable on a CPU.  Equality with the dense evaluation is
+        asserted in tests/test_oracle_golden.py (CPU)."""
+        q = np.asarray(q, F32)
+        S, H = q.shape[:2]
+        assert H == self.H
+        ax = [self.centers[0, :, 0, 0], self.centers[1, 0, :, 0], self.centers[2, 0, 0, :]]      # f64 axis centres
+        half = int(np.ceil(self.thres / self.voxel)) + margin
+        W = 2 * half + 1
+        qq = q.astype(F64).reshape(S * H, 3)
+        base = np.floor((qq - self.start[None]) / self.voxel).astype(np.int64) - half                # [P,3] first cell of the window
+        off = np.arange(W)
+        rows = np.tile(np.arange(H), S)
+        for p0 in range(0, S * H, 4096):
+            b = base[p0:p0 + 4096]
+            idx = b[:, :, None] + off[None, None, :]                                                 # [p,3,W]
+            ok = (idx >= 0) & (idx < self.R)
+            ic = np.clip(idx, 0, self.R - 1)
+            d2 = [np.square(ax[k][ic[:, k]] - qq[p0:p0 + 4096, k, None]) for k in range(3)]          # [p,W] each
+            d = np.sqrt((d2[0][:, :, None, None] + d2[1][:, None, :, None]) + d2[2][:, None, None, :])
+            hit = (d < self.thres) & ok[:, 0, :, None, None] & ok[:, 1, None, :, None] & ok[:, 2, None, None, :]
+            pi, xi, yi, zi = np.nonzero(hit)
+            np.add.at(self.occ, (rows[p0:p0 + 4096][pi], ic[pi, 0, xi], ic[pi, 1, yi], ic[pi, 2, zi]), F32(1.0))
+        self.used_count += S
+
     def aggregated_grid(self):
         flat = self.occ.reshape(self.H, -1)
         with np.errstate(divide="ignore", invalid="ignore"):

@@ -219,3 +219,118 @@ def vae_encode_ref(state, img, cfg):
     x = resnet_ref(x, None, s, "encoder.mid_block.resnets.1", eps=1e-6)
     x = _conv(F.silu(_gn(x, s, "encoder.conv_norm_out", 1e-6)), s, "encoder.conv_out")
     return _conv(x, s, "quant_conv", padding=0)
+
+
+# ------------------------------------------------------------------ the adaptive-mask branch of the loop (BASELINE config 3)
+# fp32 restatement of utils/adaptive_mask_inpainting.py:988-1076 (loop), :1111-1115 (decode_to_npuint8_image),
+# :1123-1157 (adapt_mask), :131-245 (prepare_mask_and_masked_image, tensor branch), :675-694 (VAE encode + mask
+# interpolation).  The reference handles ONE image per call when the mask adapts (squeeze() at :1114); `AdaptiveLoopRef`
+# carries B independent images side by side so that a batch-8 run of the HIP loop can be checked image by image.
+# cv2 is absent from this image: cv2.dilate(mask, ones((3,3)), iterations=k) (zero border, k = 0 copies) is restated
+# with scipy.ndimage.grey_dilation, k times.  "parity unpinned" as the rest of this file (diffusers absent).
+import numpy as np
+
+
+def dilate_ref(mask_u8, iterations):
+    from scipy.ndimage import grey_dilation
+    out = np.asarray(mask_u8).astype(np.uint8)
+    for _ in range(int(iterations)):
+        out = grey_dilation(out, size=(3, 3), mode="constant", cval=0)
+    return out
+
+
+def vae_sample_ref(moments, noise, scaling):
+    """DiagonalGaussianDistribution.sample(generator) * scaling_factor (:675-684) with the noise given."""
+    mean, logvar = moments.float().chunk(2, dim=1)
+    std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+    return (mean + std * noise.to(mean)) * scaling
+
+
+def decode_to_npuint8_ref(vstate, vcfg, latents):
+    """:1111-1115 -- decode(latents / scaling_factor), (x / 2 + 0.5).clamp(0, 1), HWC, * 255, TRUNCATING cast. -> u8 [B,H,W,3]"""
+    img = vae_decode_ref(vstate, latents.float() / vcfg["scaling_factor"], vcfg)
+    img = (img / 2 + 0.5).clamp(0, 1)
+    return (img.permute(0, 2, 3, 1).detach().cpu().numpy() * 255).astype(np.uint8)
+
+
+def adapt_mask_ref(seg, default_mask_np, dilate_num, use_default_mask, human_detection_thres):
+    """:1130-1141 up to the tensor mask: seg = plug-in output [H,W]; -> binary float32 [H,W]."""
+    seg = np.asarray(seg)
+    if use_default_mask or seg.sum() < 512 * 512 * human_detection_thres:
+        mask = default_mask_np
+    else:
+        mask = np.logical_and(dilate_ref(seg, dilate_num), default_mask_np)
+    return (np.asarray(mask, dtype=np.float32) >= 0.5).astype(np.float32)
+
+
+class AdaptiveLoopRef:
+    def __init__(self, ustate, vstate, ucfg, vcfg, *, image, default_mask, ctx_uncond, ctx_cond, lat0, plugin, settings,
+                 num_inference_steps=50, strength=1.0, guidance=7.5, enforce_full_mask_ratio=0.5, human_detection_thres=0.008,
+                 use_adaptive_mask=True, device="cpu"):
+        dev = torch.device(device)
+        self.dev = dev
+        self.us = {k: v.to(dev, torch.float32) for k, v in ustate.items()}
+        self.vs = {k: v.to(dev, torch.float32) for k, v in vstate.items()}
+        self.ucfg, self.vcfg = ucfg, vcfg
+        self.image = image.float().to(dev)                                     # [B,3,H,W] in [-1,1]
+        self.default_np = (default_mask.float().cpu().numpy()[:, 0] >= 0.5).astype(np.float32)     # [B,H,W]
+        self.ctx = torch.cat([ctx_uncond, ctx_cond]).float().to(dev)
+        self.B = image.shape[0]
+        self.plugin, self.settings = plugin, settings
+        self.N, self.guidance = num_inference_steps, guidance
+        self.ratio, self.thres, self.adaptive = enforce_full_mask_ratio, human_detection_thres, use_adaptive_mask
+        self.alphas = ddim_alphas()
+        ts = ddim_timesteps(num_inference_steps)
+        init = min(int(num_inference_steps * strength), num_inference_steps)
+        self.timesteps = ts[max(num_inference_steps - init, 0):]               # get_timesteps (:622-628)
+        self.lat = lat0.double().to(dev)                                       # caller-provided `latents` (:662-664), sigma = 1
+        self.mask_np = self.default_np.copy()
+        self.mask_lat = self.masked_lat = None
+
+    # -- :686-694 + :675-684
+    def set_mask(self, mask_np, noise):
+        """mask_np [B,H,W] in {0,1} -> mask latents (nearest, source pixel (8y, 8x)) + masked-image latents."""
+        m = torch.from_numpy(np.ascontiguousarray(mask_np)).to(self.dev)[:, None]
+        masked = self.image * (m < 0.5)
+        self.mask_np = mask_np
+        self.mask_lat = F.interpolate(m, size=(m.shape[-2] // 8, m.shape[-1] // 8))
+        mom = vae_encode_ref(self.vs, masked, self.vcfg)
+        self.masked_lat = vae_sample_ref(mom, noise.to(self.dev), self.vcfg["scaling_factor"])
+        return self.masked_lat
+
+    def unet_eps(self, t):
+        B = self.B
+        inp = torch.cat([self.lat.float(), self.mask_lat, self.masked_lat], dim=1)
+        eps = unet_ref(self.us, torch.cat([inp, inp]), torch.full((2 * B,), float(t), device=self.dev), self.ctx, self.ucfg)
+        return eps[:B] + self.guidance * (eps[B:] - eps[:B])
+
+    def segment(self, x0):
+        """decode x0 and run the plug-in per image (its NumPy contract) -> images u8 [B,H,W,3], segs u8 [B,H,W]."""
+        imgs = decode_to_npuint8_ref(self.vs, self.vcfg, x0)
+        segs = np.stack([np.asarray(self.plugin(imgs[b])["mask"]).astype(np.uint8) for b in range(self.B)])
+        return imgs, segs
+
+    def adapt(self, i, t, segs):
+        if self.ratio > 0.0:
+            use_default = t < 1000 * self.ratio
+        elif self.ratio == 0.0:
+            use_default = False
+        else:
+            raise NotImplementedError
+        k = self.settings.dilate_scheduler(i)
+        return np.stack([adapt_mask_ref(segs[b], self.default_np[b], k, use_default, self.thres) for b in range(self.B)])
+
+    def run(self, noises, on_adapt=None):
+        """noises: iterable of [B,4,h,w] draws, consumed one per VAE sample in the reference's order.  -> final latents."""
+        it = iter(noises)
+        self.set_mask(self.default_np, next(it))
+        for i, t in enumerate(self.timesteps):
+            e = self.unet_eps(t)
+            self.lat, x0 = ddim_step_ref(e, t, self.lat, self.alphas.to(self.dev), num_inference_steps=self.N)
+            if self.adaptive and self.settings.provoke_scheduler(i):
+                imgs, segs = self.segment(x0)
+                mask = self.adapt(i, t, segs)
+                self.set_mask(mask, next(it))
+                if on_adapt is not None:
+                    on_adapt(dict(i=i, t=t, x0=x0, image_u8=imgs, seg=segs, mask=mask, masked_lat=self.masked_lat, lat=self.lat))
+        return self.lat

@@ -161,8 +161,12 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
             coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **dict(common, human_res=row_hi - row_lo))
         else:
             coma = ComA(**common)
-        if skip_done and os.path.exists(save_pth) and not occ_rows:
-            coma.load(save_pth)
+        if skip_done and os.path.exists(save_pth):
+            if occ_rows:               # the exported pickle holds the complete grid: rank 0 reloads it whole, the others have nothing to do
+                del coma
+                coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **common) if rank == 0 else None
+            if coma is not None:
+                coma.load(save_pth)
         else:
             lo, hi = (0, len(inputs)) if occ_rows else shard_slice(len(inputs), rank, world)
             for pth in inputs[lo:hi]:

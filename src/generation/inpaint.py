@@ -146,8 +146,17 @@ def set_pipeline(ldm_model_key, adaptive_mask_model_type, default_ddim_steps, we
     if mask_model == "synthetic":
         pipeline.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
     elif mask_model == "auto":
-        pipeline.register_adaptive_mask_model(build_adaptive_mask_model(adaptive_mask_model_type, default_pointrend_threshold, use_visualizer,
-                                                                       enable_sam_multitask_output, device=device))
+        try:
+            model = build_adaptive_mask_model(adaptive_mask_model_type, default_pointrend_threshold, use_visualizer,
+                                              enable_sam_multitask_output, device=device)
+        except ImportError as e:
+            if weights_dir:                  # a real checkpoint with a stand-in segmenter would silently produce wrong masks
+                raise
+            import warnings
+            warnings.warn(f"\n{'#' * 100}\n--mask_model auto: {e}\nNo --weights_dir either (seeded random weights): falling back to the "
+                          f"dependency-free SyntheticHumanMaskPredictor, i.e. `--mask_model synthetic`.\n{'#' * 100}", RuntimeWarning)
+            model = SyntheticHumanMaskPredictor()
+        pipeline.register_adaptive_mask_model(model)
     else:
         raise ValueError(f"--mask_model {mask_model!r}: expected 'auto' or 'synthetic'")
     pipeline.register_adaptive_mask_settings(default_adaptive_mask_settings(default_ddim_steps, adaptive_mask_model_type))

@@ -78,6 +78,19 @@ def read_bgr(pth):
     return np.ascontiguousarray(np.asarray(Image.open(pth).convert("RGB"))[:, :, ::-1])
 
 
+def detectron2_visualizer():
+    """The reference's HUMAN / NO-HUMAN picture (src/generation/segment_human.py:139-140): detectron2's Visualizer over the RGB image
+    at half scale, grey-scale background, drawn from the raw Instances the detectron2 backend keeps under "raw"."""
+    from detectron2.data import MetadataCatalog
+    from detectron2.utils.visualizer import ColorMode, Visualizer
+    meta = MetadataCatalog.get("coco_2017_val")
+
+    def draw(image_rgb, inst):
+        v = Visualizer(image_rgb, meta, scale=0.5, instance_mode=ColorMode.IMAGE_BW)
+        return v.draw_instance_predictions(inst["raw"].to("cpu")).get_image()
+    return draw
+
+
 def human_segmentation_coco(supercategories, categories, prompts, inpaint_dir, save_dir, threshold, parallel_num, parallel_idx, save_full,
                             save_vis_in_same_folder, save_image, skip_done, verbose, detector=None, visualizer=None):
     """detector: backend with `.instances(image_bgr) -> dict(pred_boxes, scores, pred_classes, pred_masks, raw)`; default = PointRend
@@ -85,6 +98,8 @@ def human_segmentation_coco(supercategories, categories, prompts, inpaint_dir, s
     if detector is None:
         from coma_amd.sd.predictors import pointrend_backend
         detector = pointrend_backend(threshold, "cuda")
+        if save_image and visualizer is None:
+            visualizer = detectron2_visualizer()
     items = build_work_list(prepare_inpainting_pths(inpaint_dir, supercategories, categories, prompts), save_dir, save_vis_in_same_folder,
                             skip_done, verbose)
     sub = len(items) // parallel_num + 1

@@ -29,6 +29,10 @@ def test_single_gpu_line(hip_lib):
     assert KEYS <= set(line) and line["n_gpus"] == 1 and line["value"] > 0
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
     assert "workload" in line["config"] and line["secondary"]["value"] > 0
+    assert line["roofline"]["algorithmic_bytes"] > 0                       # so that traffic / algorithmic is on the line
+    occ = line["occupancy"]
+    assert occ["value"] > 0 and occ["roofline"]["traffic"] > 0 and 0 < occ["roofline"]["hard_floor_frac"] < occ["roofline"]["frac"] < 1
+    assert line["adaptive_loop"]["value"] > 0
 
 
 def test_two_ranks_control_flow(hip_lib):
@@ -39,3 +43,7 @@ def test_two_ranks_control_flow(hip_lib):
     assert r.returncode == 0, r.stderr[-2000:]
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["secondary"]["n_gpus"] == 2
+    # all four sections run at N > 1: the contact job ends with ONE all-reduce, occupancy runs row-sharded with its MAX all-reduce
+    assert line["secondary"]["final_allreduce_ms"] > 0 and "ONE RCCL all-reduce" in line["secondary"]["config"]["workload"]
+    assert line["occupancy"]["n_gpus"] == 2 and line["occupancy"]["value"] > 0 and "all-reduce(MAX)" in line["occupancy"]["config"]["workload"]
+    assert line["adaptive_loop"]["n_gpus"] == 2 and line["adaptive_loop"]["value"] > 0

@@ -386,6 +386,63 @@ def test_occupancy_fused_pass_matches_oracle(R, H, S, sel, dev, hip_lib):
     assert np.array_equal(_np(occ.spatial_occupancy_grids), norm, equal_nan=True)     # lazily normalised in place, as the reference leaves it
 
 
+def test_occupancy_config5_share_properties(dev, hip_lib):
+    """BASELINE config 5 at its per-GPU share -- H = 1310 rows (10475 / 8), R = 128, S = 2000 samples, one fused pass over the
+    11 GB per-vertex grid (16-bit LDS counters, chunked sample lists) -- checked without a dense CPU evaluation:
+      * the row sums of ALL rows on the device vs the oracle's count of cells inside each sample's threshold sphere, 32 rows;
+      * 16 rows bit-exact against the oracle (its windowed evaluation, pinned against the dense one on the CPU);
+      * the [R,R,R] field == max over rows of counts / row sum, recomputed with plain torch ops over the whole raw grid."""
+    H, R, S = 1310, 128, 2000
+    rng = np.random.default_rng(55)
+    centre = rng.uniform(-0.9, 0.9, size=(1, H, 3))
+    q = (centre + rng.normal(scale=0.08, size=(S, H, 3))).astype(np.float32)      # each vertex wanders around its own spot
+    q[:, 7] = rng.uniform(-1.3, 1.3, size=(S, 3))                                  # one vertex in and out of the grid
+    occ = _occ(H, R, dev)
+    occ.accumulate_device(torch.from_numpy(q).to(dev))
+    occ.used_count = S
+    assert occ._pending and occ._pristine
+    occ._materialize()                                                             # the fused pass, raw counts left in place
+    assert not occ._pending and occ._field_all is not None
+    raw = occ._grid
+    rows32 = np.unique(np.concatenate([[0, 7, H - 1], rng.choice(H, 29, replace=False)]))
+    rows16 = rows32[:16]
+    m = orc.OccupancyOracle(len(rows32), R, 3.0)
+    m.aggregate_windowed(q[:, rows32])
+    rowsum = raw.reshape(H, -1).sum(-1, dtype=torch.float64).cpu().numpy()
+    assert np.array_equal(rowsum[rows32], m.occ.reshape(len(rows32), -1).sum(-1, dtype=np.float64))
+    others = np.delete(rowsum, 7)
+    assert np.abs(others / S - 113.1).max() < 6 and 0 < rowsum[7] < others.min()     # 4/3 pi 3^3 cells per in-grid sample
+    idx16 = [int(np.nonzero(rows32 == r)[0][0]) for r in rows16]
+    assert np.array_equal(_np(raw[torch.as_tensor(rows16, device=dev)]), m.occ[idx16])
+    assert float(raw.max()) <= S
+    ref_field = (raw / raw.reshape(H, -1).sum(-1)[:, None, None, None]).amax(0)
+    field = occ.return_aggregated_spatial_grids()
+    assert torch.equal(field, ref_field)
+    norm_rows = _np(occ.spatial_occupancy_grids[torch.as_tensor(rows16, device=dev)])       # lazily normalised in place
+    with np.errstate(invalid="ignore", divide="ignore"):
+        exp_rows = m.occ[idx16] / m.occ[idx16].reshape(16, -1).sum(-1)[:, None, None, None]
+    assert np.array_equal(norm_rows, exp_rows, equal_nan=True)
+    assert (_np(field)[None] >= norm_rows).all()
+
+
+def test_occupancy_falls_back_when_the_fused_pass_cannot_take_the_configuration(dev, hip_lib):
+    """scale_tolerance is a free CLI float: a window wider than the fused kernel's 16 cells (tolerance > 7) must take the
+    splat + reduce route with every staged sample kept."""
+    from utils.coma_occupancy import ComA_Occupancy
+    H, R, S = 12, 30, 4
+    rng = np.random.default_rng(3)
+    occ = ComA_Occupancy(scale_tolerance=7.5, human_res=H, obj_res=3, normal_res=0, spatial_res=R, device=dev)
+    m = orc.OccupancyOracle(H, R, 7.5)
+    for s in range(S):
+        hv = rng.uniform(-1.2, 1.2, size=(H, 3))
+        occ.register_sample_to_cache(human_verts=hv, human_normals=np.zeros_like(hv), obj_verts=np.zeros((3, 3)), obj_normals=np.ones((3, 3)))
+        m.aggregate_sample(hv, np.zeros((3, 3)))
+    occ.aggregate_all_samples()
+    assert not occ._fusable()
+    assert np.array_equal(_np(occ.spatial_occupancy_grids), m.occ)
+    assert np.array_equal(_np(occ.return_aggregated_spatial_grids()), m.aggregated_grid(), equal_nan=True)
+
+
 def test_occupancy_export_then_reduce_and_many_samples(dev, hip_lib):
     """export() between aggregate and reduce (src/coma/extract_coma.py order) sees RAW counts and the reduce after it re-uses the
     field of the same fused pass; S > 2048 exercises the chunked sample list of the fused kernel."""

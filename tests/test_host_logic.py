@@ -192,6 +192,12 @@ class Shard:                                    # the device object's contract, 
         self.normalize_prob_grid_for_spatials()
         g = self.spatial_occupancy_grids if human_indices is None else self.spatial_occupancy_grids[list(human_indices)]
         return torch.max(g, dim=0).values
+    def reduce_keep_raw(self, human_indices=None, want_raw=True):
+        raw = self.spatial_occupancy_grids.clone() if want_raw else None
+        if human_indices is not None and len(human_indices) == 0:
+            self.normalize_prob_grid_for_spatials()
+            return raw, torch.full((R, R, R), float("-inf"))
+        return raw, self.return_aggregated_spatial_grids(human_indices)
 
 
 for sel in (None, [0, 1, 2, 9], [6, 7]):        # all rows (NaN row poisons the field), rows from both shards, rows of one shard only

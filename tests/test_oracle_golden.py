@@ -98,6 +98,21 @@ def test_voxel_grid_and_occupancy(golden):
     assert not np.isnan(golden["g10b_grid_sel012"]).any()
 
 
+def test_windowed_occupancy_oracle_equals_dense(golden):
+    """OccupancyOracle.aggregate_windowed (used to check the config-5-size GPU run) == the dense evaluation, bit for bit,
+    including points outside / on the edge of the grid and the golden near-threshold vertices."""
+    for R, H, S, span in ((8, 16, 4, 1.4), (30, 12, 6, 1.3), (37, 5, 3, 1.25)):
+        rng = np.random.default_rng(R)
+        q = rng.uniform(-span, span, size=(S, H, 3))
+        if R == 8:
+            q[:4] = np.stack([golden[f"g9_in{s}_human_verts"] for s in range(4)])
+        dense, win = orc.OccupancyOracle(H, R, 3.0), orc.OccupancyOracle(H, R, 3.0)
+        for s in range(S):
+            dense.aggregate_sample(q[s], np.zeros((1, 3)))
+        win.aggregate_windowed(q.astype(np.float32))
+        assert dense.occ.sum() > 0 and np.array_equal(dense.occ, win.occ)
+
+
 def test_nearest_vertex_first_minimum(golden):
     idx = orc.nearest_vertex(golden["g11_points"], golden["g11_verts"])
     assert np.array_equal(idx, golden["g11_idx"])
