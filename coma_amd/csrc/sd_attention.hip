@@ -24,6 +24,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "../../include/sd_hip.h"
@@ -300,6 +301,309 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention_sp_kernel<HQ> -- software-pipelined self-attention for d = 40 and whole 64-key tiles (the 64 x 64 level: 83 % of
+// the attention time of a forward).  The kernel is bound by the VALU, not by the matrix pipe: per 64-query x 64-key tile a wave
+// issues 28 MFMAs (896 cycles) and 64 v_exp_f32 (9-11 cycles each) + 32 conversions + 34 max -- measured on the whole chip
+// (profiles/r03_notes.md): MFMAs alone 292 us, VALU alone 348 us, together in ONE wave per SIMD 616 us (the sum: an MFMA and the
+// VALU instructions behind it do not overlap inside a wave here, whatever the placement), two waves per SIMD 487-500 us, the
+// previous kernel 542 us.  So the levers are fewer VALU instructions and two resident workgroups per CU:
+//   * no exp2-argument arithmetic at all: Q is pre-multiplied by scale*log2(e) (fp16), and the running maximum rides in the
+//     product itself -- head dim 40 pads to 48, so K gets a constant-one column at dd = 40 and Q carries -m there: the
+//     accumulator comes out as the exp2 argument (-32 v_pk_fma_f32 per tile).  m is kept on fp16 values, so numerator and
+//     denominator (the ones row of V^T) see the same factor and it cancels exactly;
+//   * a wave owns two halves (A, B) of HQ 32-query sub-tiles each; the softmax of one half is issued between the MFMAs of the
+//     other, slot by slot in source order (a sched_barrier per MFMA slot), so that the co-resident wave of the other workgroup
+//     always finds matrix work and VALU work mixed:
+//         segment 1 of tile t:  softmax A(t)   ||  S_B(t) = K(t) Q_B^T,  O_B += V(t-1)^T P_B(t-1)
+//         segment 2 of tile t:  softmax B(t)   ||  S_A(t+1) = K(t+1) Q_A^T,  O_A += V(t)^T P_A(t)
+//     and the maximum of a fresh S tile is taken under the second half of the segment that produced it (v_permlane32_swap
+//     instead of an LDS round trip for the partner lane);
+//   * three LDS stages for K and V^T (48 KB: two workgroups per CU) and ONE barrier per key tile.
+template <int HQ>
+__global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
+  constexpr int NQ = 2 * HQ;                       // 32-query sub-tiles per wave
+  constexpr int D = 40, STG = BKV * 64;            // halves per K / V^T stage (64 rows of 128 B)
+  __shared__ __attribute__((aligned(1024))) _Float16 Kbuf[3][STG];
+  __shared__ __attribute__((aligned(1024))) _Float16 Vbuf[3][STG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * (128 * NQ) + wave * (32 * NQ);
+  const int ql = lane & 31, hh = lane >> 5;
+
+  // ---- Q fragments, pre-scaled; element 0 of the (ks = 2, hh = 1) fragment is head dim 40: the slot that carries -m
+  half8 qf[NQ][3];
+#pragma unroll
+  for (int sq = 0; sq < NQ; ++sq) {
+    const int qi = q0 + sq * 32 + ql;
+    const _Float16* qp = a.q + ((long long)b * a.lq + (qi < a.lq ? qi : 0)) * a.ldq + h * D;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int dd = ks * 16 + hh * 8;
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.0f;
+      if (qi < a.lq && dd < D) v = *reinterpret_cast<const half8*>(qp + dd);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[sq][ks][j] = (_Float16)((float)v[j] * a.scale_log2);
+    }
+  }
+  float16v o[NQ][2], s[NQ][2];
+  half8 pf[NQ][4];
+  float m_run[NQ];
+#pragma unroll
+  for (int sq = 0; sq < NQ; ++sq) {
+    m_run[sq] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[sq][t][r] = 0.0f; s[sq][t][r] = 0.0f; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[sq][st][j] = (_Float16)0.0f;
+  }
+
+  // ---- LDS-DMA set-up (as in attention_kernel): K rows = keys, 5 valid 16-byte chunks per row; V^T rows = head dims
+  const _Float16* kbase = a.k + (long long)b * a.lk * a.ldk + h * D;
+  const _Float16* vbase = a.vt + ((long long)b * a.heads + h) * D * (long long)a.ldv;
+  auto make_rsrc = [](const void* p, unsigned bytes) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kbase, (unsigned)(((long long)(a.lk - 1) * a.ldk + D) * 2));
+  const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vbase, (unsigned)((long long)D * a.ldv * 2));
+  const int l_row = lane >> 3, l_slot = lane & 7;
+  // per wave and tile: 2 K instructions (16 keys) and 2 V^T instructions (16 head-dim rows)
+  unsigned k_off[2], v_off[2];
+  bool k_on[2], v_on[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wave * 2 + j) * 8 + l_row;
+    const int chunk = swz64(row, l_slot);
+    k_on[j] = chunk < 5;                          // chunk 5 holds the constant-one column, chunks 6-7 are never read
+    k_off[j] = (unsigned)(row * a.ldk * 2 + chunk * 16);
+    v_on[j] = row < D;                            // row 40 = ones (the softmax denominator), rows 41-63 stay zero
+    v_off[j] = (unsigned)(row * a.ldv * 2 + swz64(row, l_slot) * 16);
+  }
+  const unsigned k_step = (unsigned)(BKV * a.ldk * 2), v_step = BKV * 2;
+  auto issue_k = [&](int stage, int tile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16* kd = Kbuf[stage] + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (k_on[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(kd + j * 512), 16, k_off[j] + tile * k_step, 0, 0, 0);
+#endif
+  };
+  auto issue_v = [&](int stage, int tile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16* vd = Vbuf[stage] + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (v_on[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(vd + j * 512), 16, v_off[j] + tile * v_step, 0, 0, 0);
+#endif
+  };
+  // constant parts of the stages, written once: K chunk 5 = (1, 0, ..., 0), V^T row 40 = ones, rows 41-63 (and all of the
+  // stage the first O_B product reads before any V^T tile landed there) = zero
+  for (int i = tid; i < 3 * STG / 8; i += 256) reinterpret_cast<uint4*>(&Vbuf[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  if (tid < 3 * 64) {
+    const int stage = tid >> 6, row = tid & 63;
+    half8 e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (_Float16)(j == 0 ? 1.0f : 0.0f);
+    *reinterpret_cast<half8*>(&Kbuf[stage][row * 64 + swz64(row, 5) * 8]) = e;
+  }
+  if (tid < 3 * 8) {
+    half8 one;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one[j] = (_Float16)1.0f;
+    *reinterpret_cast<half8*>(&Vbuf[tid >> 3][D * 64 + (tid & 7) * 8]) = one;
+  }
+
+  const int ntiles = a.lk / BKV;
+  issue_k(0, 0);
+  issue_v(0, 0);
+  if (ntiles > 1) issue_k(1, 1);
+
+  // ---- per-lane LDS offsets (halves): row ql, chunk (2ks + hh) / (2st + hh), swizzled; stages and the 32-row tile add immediates
+  int k_lane[3], v_lane[4];
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) k_lane[ks] = ql * 64 + swz64(ql, 2 * ks + hh) * 8;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) v_lane[st] = ql * 64 + swz64(ql, 2 * st + hh) * 8;
+  float16v zero16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero16[r] = 0.0f;
+  float mxs[NQ];                                    // max of the S' tile in flight, per sub-tile
+
+  // A segment = 14 slots.  Slot g: fetch the fragment of slot g+1, HQ MFMAs on the MATRIX half (slots 0-5: S' = K Q^T, slots
+  // 6-13: O^T += V^T P^T), and on the VALU half a share of the 32 HQ exp2 + the conversions of the pairs finished one slot
+  // earlier (an exp2 result needs a wait state before a VALU may read it); from slot 8 on, the maximum of the S' tile the
+  // slots 0-5 produced.  The order is the source order: a sched_barrier closes every slot.
+  auto frag = [&](int g, const _Float16* Ks, const _Float16* Vs) -> half8 {
+    return g < 6 ? *reinterpret_cast<const half8*>(&Ks[(g & 1) * 32 * 64 + k_lane[g >> 1]])
+                 : *reinterpret_cast<const half8*>(&Vs[((g - 6) & 1) * 32 * 64 + v_lane[(g - 6) >> 1]]);
+  };
+  auto segment = [&](auto hvc, const _Float16* Ks, const _Float16* Vs) {
+    constexpr int HV = decltype(hvc)::value, HM = 1 - HV;       // VALU half, matrix half
+    constexpr int NE = 32 * HQ;                                  // exp2 per segment
+    half8 fr[3];                                                 // fragments are fetched two slots ahead
+    fr[0] = frag(0, Ks, Vs);
+    fr[1] = frag(1, Ks, Vs);
+    auto slot = [&](auto gc) {
+      constexpr int G = decltype(gc)::value;
+      if constexpr (G + 2 < 14) fr[(G + 2) % 3] = frag(G + 2, Ks, Vs);
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) {
+        const int sq = HM * HQ + j;
+        if constexpr (G < 6) {
+          constexpr int ks = G >> 1, t = G & 1;
+          s[sq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[G % 3], qf[sq][ks], ks == 0 ? zero16 : s[sq][t], 0, 0, 0);
+        } else {
+          constexpr int st = (G - 6) >> 1, t = (G - 6) & 1;
+          o[sq][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[G % 3], pf[sq][st], o[sq][t], 0, 0, 0);
+        }
+      }
+      constexpr int E0 = G * NE / 14, E1 = (G + 1) * NE / 14, EP = G == 0 ? 0 : (G - 1) * NE / 14;
+#pragma unroll
+      for (int e = E0; e < E1; ++e) {               // P = exp2(S'), written back over S'
+        const int sq = HV * HQ + e / 32, t = (e % 32) / 16, r = e % 16;
+        s[sq][t][r] = __builtin_amdgcn_exp2f(s[sq][t][r]);
+      }
+#pragma unroll
+      for (int pr = (EP + 1) / 2; pr < (G == 13 ? NE / 2 : (E0 + 1) / 2); ++pr) {   // pairs complete before this slot's exp2
+        const int e = 2 * pr, sq = HV * HQ + e / 32, t = (e % 32) / 16, r = e % 16;
+        pf[sq][t * 2 + (r >> 3)][r & 7] = (_Float16)s[sq][t][r];
+        pf[sq][t * 2 + (r >> 3)][(r & 7) + 1] = (_Float16)s[sq][t][r + 1];
+      }
+      if constexpr (G >= 8) {                       // 16 HQ max3 over the fresh S' of the matrix half, 6 slots
+        constexpr int M0 = (G - 8) * 16 * HQ / 6, M1 = (G - 7) * 16 * HQ / 6;
+#pragma unroll
+        for (int mi = M0; mi < M1; ++mi) {
+          const int j = mi / 16, pr = mi % 16, sq = HM * HQ + j;        // pair pr: (t = pr / 8, r = 2 (pr % 8))
+          const float x0 = s[sq][pr >> 3][2 * (pr & 7)], x1 = s[sq][pr >> 3][2 * (pr & 7) + 1];
+          mxs[sq] = pr == 0 ? fmaxf(x0, x1) : fmaxf(fmaxf(mxs[sq], x0), x1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    [&]<int... G>(std::integer_sequence<int, G...>) { (slot(std::integral_constant<int, G>{}), ...); }(std::make_integer_sequence<int, 14>{});
+    // the fp16 weights are only read by the NEXT segment's MFMAs: without a use here the compiler sinks the whole exp2 / convert
+    // chain of this segment into the next basic block (behind the rescale branch) and the interleave is gone
+#pragma unroll
+    for (int j = 0; j < HQ; ++j)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) asm volatile("" : "+v"(pf[HV * HQ + j][st]));
+#pragma unroll
+    for (int j = 0; j < HQ; ++j) {                  // the partner lane holds the other 32 keys of the query
+      const int sq = HM * HQ + j;
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxs[sq]), __float_as_uint(mxs[sq]), false, false);
+      mxs[sq] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+  };
+  // running maximum: the accumulators already hold score - m.  m only moves when a score exceeds it by more than 2^6 (or on
+  // the first tile): then the tile in flight, O and the -m slot of Q are shifted by delta (wave-uniform rare branch)
+  auto maxfix = [&](int half, bool first) {
+#pragma unroll
+    for (int j = 0; j < HQ; ++j) {
+      const int sq = half * HQ + j;
+      const bool need = first || mxs[sq] > 6.0f;
+      if (__any(need)) {
+        const float m_new = need ? (float)(_Float16)(m_run[sq] + mxs[sq]) : m_run[sq];      // stays an fp16 value
+        const float delta = m_new - m_run[sq];
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_run[sq] = m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[sq][t][r] -= delta; o[sq][t][r] *= alpha; }
+        if (hh) qf[sq][2][0] = (_Float16)(-m_new);
+      }
+    }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // S'_A(0) and its maximum, outside the pipeline
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const half8 kf = *reinterpret_cast<const half8*>(&Kbuf[0][t * 32 * 64 + k_lane[ks]]);
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) s[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j][ks], ks == 0 ? zero16 : s[j][t], 0, 0, 0);
+    }
+#pragma unroll
+  for (int j = 0; j < HQ; ++j) {
+    float mx = fmaxf(s[j][0][0], s[j][1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[j][0][r]), s[j][1][r]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    mxs[j] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  auto tile_body = [&](int t, auto s0c) {           // K(t), V^T(t) live in stage S0 = t % 3
+    constexpr int S0 = decltype(s0c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of K(t+1), V^T(t) (issued one tile ago) have landed
+    __builtin_amdgcn_s_barrier();                     // ... everyone's; and every wave is done with K(t-1), V^T(t-2)
+    if (t + 2 < ntiles) issue_k(S2, t + 2);
+    if (t + 1 < ntiles) issue_v(S1, t + 1);
+    maxfix(0, t == 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // segment 1: softmax A(t)  ||  S'_B(t) = K(t) Q_B^T, O_B += V(t-1)^T P_B(t-1)   (t = 0: P_B = 0 and the stage is zero-filled)
+    segment(std::integral_constant<int, 0>{}, Kbuf[S0], Vbuf[S2]);
+    maxfix(1, t == 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // segment 2: softmax B(t)  ||  S'_A(t+1) = K(t+1) Q_A^T, O_A += V(t)^T P_A(t)    (after the last tile S'_A is never used)
+    segment(std::integral_constant<int, 1>{}, Kbuf[S1], Vbuf[S0]);
+  };
+  for (int t = 0; t < ntiles; t += 3) {
+    tile_body(t, std::integral_constant<int, 0>{});
+    if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 1>{});
+    if (t + 2 < ntiles) tile_body(t + 2, std::integral_constant<int, 2>{});
+  }
+  // O_B of the last tile
+  {
+    const int ls = (ntiles - 1) % 3;
+    const _Float16* Vs = ls == 0 ? Vbuf[0] : ls == 1 ? Vbuf[1] : Vbuf[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const half8 vf = *reinterpret_cast<const half8*>(&Vs[t * 32 * 64 + v_lane[st]]);
+#pragma unroll
+        for (int j = 0; j < HQ; ++j) o[HQ + j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[HQ + j][st], o[HQ + j][t], 0, 0, 0);
+      }
+  }
+
+  // ---- normalise by the ones row (row 40 = register 4 of the second 32-row tile, hh = 0 lane) and store
+#pragma unroll
+  for (int sq = 0; sq < NQ; ++sq) {
+    const float l_tot = __shfl(o[sq][1][4], ql);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + sq * 32 + ql;
+    if (qi < a.lq) {
+      _Float16* op = a.out + ((long long)b * a.lq + qi) * a.ldo + h * D;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = t * 32 + 8 * g + 4 * hh;
+          if (dd < D) {
+            half4 v = {(_Float16)(o[sq][t][g * 4 + 0] * inv), (_Float16)(o[sq][t][g * 4 + 1] * inv),
+                       (_Float16)(o[sq][t][g * 4 + 2] * inv), (_Float16)(o[sq][t][g * 4 + 3] * inv)};
+            *reinterpret_cast<half4*>(op + dd) = v;
+          }
+        }
+    }
+  }
+}
+
 }  // namespace sd
 
 using namespace sd;
@@ -319,6 +623,20 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.scale_log2 = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
+  // software-pipelined kernel: d = 40, whole key tiles (at least two), V^T key-permuted; by default only when 256-query blocks
+  // fill the chip.  vt_perm16 bit 1 forces it wherever it is legal, bit 2 forbids it (tests / A-B timing); SD_ATTN_V=1 forbids
+  // it process-wide, SD_ATTN_V=4 selects the 128-queries-per-wave variant.
+  static const int sp_mode = [] { const char* e = getenv("SD_ATTN_V"); return e ? atoi(e) : 2; }();
+  const bool sp_legal = d == 40 && (vt_perm16 & 1) && lk % BKV == 0 && lk >= 2 * BKV;
+  const bool sp_auto = sp_mode >= 2 && !(vt_perm16 & 4) && (long long)batch * heads * ((lq + 255) / 256) >= 512;
+  if (sp_legal && ((vt_perm16 & 2) || sp_auto)) {
+    const int hq = sp_mode == 4 ? 2 : 1;
+    dim3 g2((unsigned)((lq + 256 * hq - 1) / (256 * hq)), (unsigned)heads, (unsigned)batch);
+    if (hq == 2) hipLaunchKernelGGL((attention_sp_kernel<2>), g2, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attention_sp_kernel<1>), g2, dim3(256), 0, s, a);
+    return check_launch("attention_sp_kernel");
+  }
+  vt_perm16 &= 1;
   const bool two = lq >= 1024 && d == 40;      // 64 queries per wave once there are enough blocks to fill the chip
   dim3 grid((unsigned)((lq + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)heads, (unsigned)batch);
 #define SD_ATTN_LAUNCH(KS, DVT, QT, ONES)                                                                       \

@@ -96,9 +96,11 @@ def layernorm(x, gamma, beta, out, *, rows, c, eps=1e-5):
     return out
 
 
-def attention(q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, vt_perm16=False):
+def attention(q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale, vt_perm16=False, pipelined=None):
+    """pipelined: None = the library's own choice; True / False force / forbid the software-pipelined d = 40 kernel (tests, A-B)."""
+    flags = (1 if vt_perm16 else 0) | (2 if pipelined is True else 0) | (4 if pipelined is False else 0)
     rc = _lib.lib().sd_attention_f16(_p(q, "q"), _p(k, "k"), _p(vt, "vt"), _p(out, "out"), batch, heads, lq, lk, d, ldq, ldk,
-                                     ldv, ldo, scale, 1 if vt_perm16 else 0, _stream(out))
+                                     ldv, ldo, scale, flags, _stream(out))
     _lib.check(rc, "sd_attention_f16")
     return out
 

@@ -114,7 +114,11 @@ int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* 
  *         multiple of 8); the pad columns lk..ldv-1 must hold finite values (they meet zero softmax weights).
  *         vt_perm16 = 1: the keys of every group of 16 are stored in the order (0-3, 8-11, 4-7, 12-15) (SD_EPI_PERM16_N of the
  *         producing GEMM), ldv a multiple of 16 -- the kernel then fetches each V^T MFMA operand with ONE conflict-free 16-byte
- *         LDS read instead of two 8-byte ones that collide two-way
+ *         LDS read instead of two 8-byte ones that collide two-way.  vt_perm16 is a bit field: bit 0 = the layout flag above;
+ *         bit 1 = use the software-pipelined kernel wherever it is legal (d = 40, lk a multiple of 64 and >= 128, bit 0 set),
+ *         bit 2 = never use it.  By default the library picks it when the launch fills the chip (the 64 x 64 level of the UNet).
+ *         Same results up to fp16 rounding of the weights: that kernel pre-multiplies Q by scale*log2(e) in fp16 and carries
+ *         the running maximum on fp16 values.
  *   out : [batch, lq, ldo]
  * out = softmax(q k^T * scale) v per (batch, head).  d: any multiple of 8 up to 160.  The K and V^T slices of one
  * (batch, head) must stay below 2 GiB (32-bit LDS-DMA offsets); violations return an error, nothing is launched.

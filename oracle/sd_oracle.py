@@ -74,7 +74,7 @@ def attention_ref(q, k, v, heads, scale):
 
 def timestep_embedding_ref(t, dim):
     half = dim // 2
-    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     a = t.float()[:, None] * freq[None]
     return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)      # flip_sin_to_cos=True, shift 0
 

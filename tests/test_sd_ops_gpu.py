@@ -197,6 +197,47 @@ def test_v_transposed_projection_in_the_permuted_layout(ops, L, C):
     assert bool(torch.isfinite(out.float()).all())
 
 
+@pytest.mark.parametrize("lq,lk,heads,B", [(256, 128, 2, 1), (300, 192, 8, 2), (1024, 1024, 8, 1), (77, 4096, 1, 1)])
+def test_attention_pipelined_d40(ops, lq, lk, heads, B):
+    """The software-pipelined d = 40 kernel (one wave per SIMD, softmax of one query half under the MFMAs of the other; running
+    maximum carried inside the QK^T product) forced at small sizes: ragged query counts, 2 ... 64 key tiles, vs torch fp32 and vs
+    the generic kernel."""
+    d, C = 40, heads * 40
+    q, k, v = rnd(B, lq, C, seed=1), rnd(B, lk, C, seed=2), rnd(B, lk, C, seed=3)
+    vp = ops.perm16_columns(v.transpose(1, 2).contiguous()).to(DEV)
+    kw = dict(batch=B, heads=heads, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=vp.shape[-1], ldo=C, scale=d**-0.5, vt_perm16=True)
+    out, base = torch.empty(B, lq, C, dtype=F16, device=DEV), torch.empty(B, lq, C, dtype=F16, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), vp, out, pipelined=True, **kw)
+    ops.attention(q.to(DEV), k.to(DEV), vp, base, pipelined=False, **kw)
+    ref = so.attention_ref(q, k, v, heads, d**-0.5)
+    close(out, ref, tol=4e-3)
+    close(out, base.float().cpu(), tol=4e-3)
+
+
+def test_attention_pipelined_rescale_and_low_scores(ops):
+    """(a) one key dominates from the 3rd key tile on (the maximum jumps by far more than 2^6: the rescale branch of both query
+    halves); (b) every score far below zero (the first-tile rule must set the maximum even when nothing exceeds the threshold)."""
+    B, heads, d, L = 1, 1, 40, 512
+    q, k, v = rnd(B, L, d, seed=1), rnd(B, L, d, seed=2), rnd(B, L, d, seed=3)
+    k[0, 150] = q[0, 7] * 8.0
+    k[0, 400] = q[0, 40] * 12.0
+    for shift in (0.0, -60.0):
+        kk = k.clone()
+        if shift:
+            q2 = q.clone()
+            q2[..., 0] = 4.0
+            kk[..., 0] = shift / 4.0 / d**-0.5 / 4.0            # adds shift/4 ... to every score of a query: all scores << 0
+        else:
+            q2 = q
+        vp = ops.perm16_columns(v.transpose(1, 2).contiguous()).to(DEV)
+        out = torch.empty(B, L, d, dtype=F16, device=DEV)
+        ops.attention(q2.to(DEV), kk.to(DEV), vp, out, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=d, ldk=d, ldv=L, ldo=d, scale=d**-0.5,
+                      vt_perm16=True, pipelined=True)
+        # scores of +-70 in log2 units: this kernel rounds Q * scale*log2(e) to fp16 before the product (relative 2^-11 per term,
+        # i.e. ~1e-2 in the exponent of the two competing keys); diffusers' own fp16 path rounds the scores themselves to fp16
+        close(out, so.attention_ref(q2, kk, v, heads, d**-0.5), tol=8e-3)
+
+
 def test_attention_peaked_scores_force_the_rescale_path(ops):
     """One key dominates from the 3rd key tile on: exercises the online-softmax rescale with a large max jump."""
     B, heads, d, L = 1, 1, 64, 256
