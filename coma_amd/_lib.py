@@ -34,7 +34,7 @@ SIGNATURES = {
     "coma_contact_select_u8": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "coma_occupancy_splat": (_i, [_vp, _i, _i, _i, _vp, _d, _d, _vp, _vp]),
     "coma_occupancy_reduce": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
-    "coma_occupancy_fused_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "coma_occupancy_fused_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "coma_occupancy_fused": (_i, [_vp, _i, _i, _i, _vp, _d, _d, _d, _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "coma_nearest_vertex_i64": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "coma_dlt_score_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),

@@ -230,7 +230,7 @@ class ComA_Occupancy:
         dev = self._grid.device
         voxel, thres = float(self.spatial_grid_metadata["voxel_size"]), float(self.rel_dist_thres)
         window = self._window()
-        nbytes = int(L.coma_occupancy_fused_workspace_bytes(S, H, R))
+        nbytes = int(L.coma_occupancy_fused_workspace_bytes(S, H, R, window))
         ws = getattr(self, "_ws", None)
         if ws is None or ws.numel() < nbytes:
             ws = self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # kept: the next call re-uses it

@@ -141,9 +141,14 @@ __global__ __launch_bounds__(256) void occupancy_norm_max4_kernel(float* __restr
 constexpr int kFusedThreads = 512;
 constexpr int kFusedMaxChunks = 5;                               // 8-cell chunks per thread -> slabs of <= 20480 cells
 constexpr int kFusedMaxCells = kFusedThreads * kFusedMaxChunks * 8;
-constexpr int kFusedListCap = 512;                               // samples of one row compacted per round (14 KB of LDS)
+constexpr int kFusedMaxWindow = 16;                              // candidate cells per axis the fused pass accepts (scale_tolerance <= 7)
+constexpr size_t occ_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr int kFusedListCap = 512;                               // items of one (row, slab) staged per round (8 KB of LDS)
 
-struct OccRec { float x, y, z; unsigned pack; };                 // pack: lo_x | n_x << 8 (n_x = 0: never inside the grid)
+// per (row, sample): the position (f32, as given) and where its candidate window starts along y and z
+struct OccRec { float x, y, z; unsigned pack; };                 // pack: lo_y | lo_z << 8
+// a (sample, x-plane) incidence as the fused pass stages it in LDS: the record + the plane
+struct OccItem { float x, y, z; unsigned pack; };                // pack: lo_y | lo_z << 8 | plane << 16
 
 __device__ __forceinline__ void axis_range(double qc, double thres, double c0, double inv, int R, int& lo, int& n) {
   int a = (int)floor((qc - thres - c0) * inv - 0.01);           // conservative (0.01-voxel margin), as in the splat kernel
@@ -154,55 +159,82 @@ __device__ __forceinline__ void axis_range(double qc, double thres, double c0, d
   n = b - a + 1;
 }
 
-__global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __restrict__ q, int S, int H, int R,
+// pass 1, one workgroup per human vertex (row): (i) the row sum -- every candidate of every sample tested once, an exact
+// integer; (ii) the row's (sample, x-plane) incidences BUCKETED BY PLANE: histogram over planes in LDS, exclusive prefix ->
+// plane_off[h][0..R], scatter of (sample | plane << 16) words into items[h][...], plus one 16-byte record per (row, sample).
+// The fused pass then reads exactly the incidences of its slab (r2 scanned all
+// S records of the row once per slab: 128 x 32 KB per row at R = 128, 5.4 GB of L2 reads per call, and compacted them with LDS
+// atomics).  Order inside a bucket is whatever the atomics give; the counts do not depend on it.
+__global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __restrict__ q, int S, int H, int R, int W,
                                                                 const double* __restrict__ centers, double voxel, double thres,
-                                                                double t2, OccRec* __restrict__ rec, float* __restrict__ rowsum) {
+                                                                double t2, OccRec* __restrict__ rec, unsigned* __restrict__ items,
+                                                                unsigned* __restrict__ plane_off, float* __restrict__ rowsum) {
   __shared__ unsigned part[4];
+  __shared__ unsigned hist[256], base[257];
   __shared__ double cen[3 * 256];                                 // per-axis centres: LDS, not three dependent global loads per test
   for (int i = threadIdx.x; i < 3 * R; i += 256) cen[i] = centers[i];
+  hist[threadIdx.x] = 0u;
   __syncthreads();
   const int h = blockIdx.x;
   const double inv = 1.0 / voxel;
   unsigned hits = 0;
   for (int s = threadIdx.x; s < S; s += 256) {
     const float* qp = q + ((int64_t)s * H + h) * 3;
-    const float fx = qp[0], fy = qp[1], fz = qp[2];
-    const double qc[3] = {(double)fx, (double)fy, (double)fz};
+    const double qc[3] = {(double)qp[0], (double)qp[1], (double)qp[2]};
     int lo[3], n[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) axis_range(qc[c], thres, cen[c * R], inv, R, lo[c], n[c]);
-    const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
-    if (!empty) {
-      for (int ix = lo[0]; ix < lo[0] + n[0]; ++ix) {
-        const double dx = cen[ix] - qc[0];
-        for (int iy = lo[1]; iy < lo[1] + n[1]; ++iy) {
-          const double dy = cen[R + iy] - qc[1];
-          const double dxy = dx * dx + dy * dy;
-          for (int iz = lo[2]; iz < lo[2] + n[2]; ++iz) {
-            const double dz = cen[2 * R + iz] - qc[2];
-            hits += (dxy + dz * dz) < t2 ? 1u : 0u;
-          }
+    if (n[0] <= 0 || n[1] <= 0 || n[2] <= 0) continue;
+    for (int ix = lo[0]; ix < lo[0] + n[0]; ++ix) {
+      const double dx = cen[ix] - qc[0];
+      for (int iy = lo[1]; iy < lo[1] + n[1]; ++iy) {
+        const double dy = cen[R + iy] - qc[1];
+        const double dxy = dx * dx + dy * dy;
+        for (int iz = lo[2]; iz < lo[2] + n[2]; ++iz) {
+          const double dz = cen[2 * R + iz] - qc[2];
+          hits += (dxy + dz * dz) < t2 ? 1u : 0u;
         }
       }
     }
-    OccRec r = {fx, fy, fz, empty ? 0u : ((unsigned)lo[0] | ((unsigned)n[0] << 8))};
-    rec[(int64_t)h * S + s] = r;
+    // hits can only lie in the first W cells of a conservative range (it is at most one cell wider than W on its far side)
+    for (int ix = lo[0]; ix < lo[0] + min(n[0], W); ++ix) atomicAdd(&hist[ix], 1u);
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) hits += __shfl_xor(hits, m);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = hits;
   __syncthreads();
-  if (threadIdx.x == 0) rowsum[h] = (float)((part[0] + part[1]) + (part[2] + part[3]));   // exact below 2^24, like the f32 row sum
+  if (threadIdx.x == 0) {
+    rowsum[h] = (float)((part[0] + part[1]) + (part[2] + part[3]));   // exact below 2^24, like the f32 row sum
+    unsigned acc = 0;
+    for (int p = 0; p < R; ++p) { base[p] = acc; acc += hist[p]; }
+    base[R] = acc;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p <= R; p += 256) plane_off[(int64_t)h * (R + 1) + p] = base[p];
+  hist[threadIdx.x] = 0u;                                         // now the per-plane cursors
+  __syncthreads();
+  unsigned* row_items = items + (int64_t)h * S * W;
+  for (int s = threadIdx.x; s < S; s += 256) {
+    const float* qp = q + ((int64_t)s * H + h) * 3;
+    const float fx = qp[0], fy = qp[1], fz = qp[2];
+    int lo[3], n[3];
+    axis_range((double)fx, thres, cen[0], inv, R, lo[0], n[0]);
+    axis_range((double)fy, thres, cen[R], inv, R, lo[1], n[1]);
+    axis_range((double)fz, thres, cen[2 * R], inv, R, lo[2], n[2]);
+    const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
+    rec[(int64_t)h * S + s] = OccRec{fx, fy, fz, empty ? 0u : ((unsigned)lo[1] | ((unsigned)lo[2] << 8))};
+    if (empty) continue;
+    for (int ix = lo[0]; ix < lo[0] + min(n[0], W); ++ix) row_items[base[ix] + atomicAdd(&hist[ix], 1u)] = (unsigned)s | ((unsigned)ix << 16);
+  }
 }
 
-struct OccItem { float x, y, z; int lo_y, lo_z, px0, pn; };      // a sample that reaches the slab: planes [px0, px0 + pn) of it
-
-// Counters are 16-bit halves of LDS words (a cell sees at most S < 65536 hits per row), so a 128 x 128 plane is 32 KB and
-// two workgroups share a CU: one's candidate tests (VALU / LDS) run under the other's slab stores (HBM).
+// pass 2.  Counters are 16-bit halves of LDS words (a cell sees at most S < 65536 hits per row), so a 128 x 128 plane is 32 KB
+// and three workgroups share a CU: one's candidate tests (VALU / LDS) run under another's slab stores (HBM).
 __global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
-    const OccRec* __restrict__ rec, const float* __restrict__ rowsum, const uint8_t* __restrict__ select, int S, int H, int R, int P,
-    int W, int groups, int write_raw, const double* __restrict__ centers, double voxel, double thres, double t2,
-    float* __restrict__ counts, float* __restrict__ partial) {
+    const OccRec* __restrict__ rec, const unsigned* __restrict__ items, const unsigned* __restrict__ plane_off, const float* __restrict__ rowsum,
+    const uint8_t* __restrict__ select, int S, int H, int R, int P, int W, int groups, int write_raw,
+    const double* __restrict__ centers, double voxel, double thres, double t2, float* __restrict__ counts,
+    float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int RR = R * R;
   const int x0 = blockIdx.x * P;
@@ -210,13 +242,11 @@ __global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
   const int cells = np * RR;                                     // multiple of 4 whenever RR is (checked on the host)
   unsigned* cnt = reinterpret_cast<unsigned*>(smem);
   const size_t cnt_bytes = (((size_t)P * RR * 2 + 15) / 16) * 16;
-  OccItem* items = reinterpret_cast<OccItem*>(smem + cnt_bytes);
+  OccItem* list = reinterpret_cast<OccItem*>(smem + cnt_bytes);
   double* cen = reinterpret_cast<double*>(smem + cnt_bytes + (size_t)kFusedListCap * sizeof(OccItem));   // [3][R]
   for (int i = threadIdx.x; i < 3 * R; i += kFusedThreads) cen[i] = centers[i];
-  __shared__ int n_items;
   const int g = blockIdx.y;
   const int h_lo = (int)((int64_t)H * g / groups), h_hi = (int)((int64_t)H * (g + 1) / groups);
-  const double inv = 1.0 / voxel;
   const int n8 = (cells + 7) >> 3;                               // 8-cell chunks; cells % 4 == 0, so a chunk is whole or its first half
   float mx[kFusedMaxChunks][8];
 #pragma unroll
@@ -226,54 +256,41 @@ __global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
   for (int i = threadIdx.x; i < n8; i += kFusedThreads) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
   const int WW = W * W;
   const int w_shift = __builtin_ctz(W);
-  int pl_shift = 0;
-  while ((1 << pl_shift) < min(np, W)) ++pl_shift;
-  // The records of a row's first kFusedListCap samples are fetched BEFORE the previous row's slab is stored: a wave's loads
-  // return in order behind its own stores (vmcnt), so a load issued after the sweep would wait for the whole slab to reach
-  // HBM and serialise the test phase with the store drain (measured: 13.8 k cycles per row and plane instead of ~7 k).
-  constexpr int RPT = kFusedListCap / kFusedThreads;             // records per thread per round
-  OccRec nxt[RPT];
-  auto fetch = [&](int hh, int s0) {
-#pragma unroll
-    for (int kk = 0; kk < RPT; ++kk) {
-      const int s = s0 + threadIdx.x + kk * kFusedThreads;
-      nxt[kk] = s < S ? rec[(int64_t)hh * S + s] : OccRec{0.f, 0.f, 0.f, 0u};
+  // The incidences of the NEXT row (its first kFusedListCap) are fetched BEFORE this row's slab is stored: a wave's loads return
+  // in order behind its own stores (vmcnt), so a load issued after the sweep would wait for the whole slab to reach HBM and
+  // serialise the test phase with the store drain (measured in r2: 13.8 k cycles per row and plane instead of ~7 k).
+  static_assert(kFusedListCap == kFusedThreads, "one incidence per thread and round");
+  OccItem nxt = {0.f, 0.f, 0.f, 0u};
+  unsigned o0 = 0, o1 = 0;                                       // [o0, o1): incidences of (row, slab) inside the row's list
+  auto bounds = [&](int hh) {
+    o0 = plane_off[(int64_t)hh * (R + 1) + x0];
+    o1 = plane_off[(int64_t)hh * (R + 1) + x0 + np];
+  };
+  auto fetch = [&](int hh, unsigned i0) {
+    const unsigned i = i0 + threadIdx.x;
+    if (i < o1) {
+      const unsigned it = items[(int64_t)hh * S * W + i];                       // sample | plane << 16
+      const OccRec r = rec[(int64_t)hh * S + (it & 0xffffu)];
+      nxt = OccItem{r.x, r.y, r.z, r.pack | (it & 0xffff0000u)};
     }
   };
-  if (h_lo < h_hi) fetch(h_lo, 0);
+  if (h_lo < h_hi) { bounds(h_lo); fetch(h_lo, o0); }
+  __syncthreads();
   for (int h = h_lo; h < h_hi; ++h) {
-    for (int s0 = 0; s0 < S; s0 += kFusedListCap) {               // the compacted list holds kFusedListCap samples at a time
-      if (s0 > 0) fetch(h, s0);
-      if (threadIdx.x == 0) n_items = 0;
+    const unsigned b0 = o0, b1 = o1;
+    for (unsigned i0 = b0; i0 < b1; i0 += kFusedListCap) {
+      if (i0 > b0) fetch(h, i0);
+      const int n_items = (int)min((unsigned)kFusedListCap, b1 - i0);
+      if ((int)threadIdx.x < n_items) list[threadIdx.x] = nxt;
       __syncthreads();
-      // ---- samples of this row that reach the slab, with their y / z windows.  Hits can only lie in the first W cells of
-      // a conservative range (it is at most one cell wider than W = ceil(2 thres / voxel) + 2 on its far side).
-#pragma unroll
-      for (int kk = 0; kk < RPT; ++kk) {
-        const OccRec r = nxt[kk];
-        const int lx = r.pack & 0xff, nx = (r.pack >> 8) & 0xff;
-        const int a = max(lx, x0), b = min(lx + min(nx, W), x0 + np);
-        if (nx > 0 && a < b) {
-          int lo_y, ny, lo_z, nz;
-          axis_range((double)r.y, thres, cen[R], inv, R, lo_y, ny);
-          axis_range((double)r.z, thres, cen[2 * R], inv, R, lo_z, nz);
-          if (ny > 0 && nz > 0) {
-            const int i = atomicAdd(&n_items, 1);
-            items[i] = {r.x, r.y, r.z, lo_y, lo_z, a, b - a};
-          }
-        }
-      }
-      __syncthreads();
-      // ---- candidate tests: item = (sample, plane, window cell), every lane busy
-      // W and the planes-per-item count are powers of two (host), so the item decode is shifts and masks
-      const int total = n_items << (pl_shift + 2 * w_shift);
+      // ---- candidate tests: (incidence, window cell), every lane busy; W is a power of two (host), so the decode is shifts
+      const int total = n_items << (2 * w_shift);
       for (int w = threadIdx.x; w < total; w += kFusedThreads) {
-        const int it = w >> (pl_shift + 2 * w_shift), c = w & ((1 << (pl_shift + 2 * w_shift)) - 1);
-        const OccItem m = items[it];
-        const int pl = c >> (2 * w_shift), wc = c & (WW - 1);
-        const int iy = m.lo_y + (wc >> w_shift), iz = m.lo_z + (wc & (W - 1));
-        if (pl < m.pn && iy < R && iz < R) {
-          const int ix = m.px0 + pl;
+        const OccItem m = list[w >> (2 * w_shift)];
+        const int wc = w & (WW - 1);
+        const int iy = (int)(m.pack & 0xffu) + (wc >> w_shift), iz = (int)((m.pack >> 8) & 0xffu) + (wc & (W - 1));
+        if (iy < R && iz < R) {
+          const int ix = (int)(m.pack >> 16);
           const double dx = cen[ix] - (double)m.x, dy = cen[R + iy] - (double)m.y, dz = cen[2 * R + iz] - (double)m.z;
           if (((dx * dx + dy * dy) + dz * dz) < t2) {
             const int cell = (ix - x0) * RR + iy * R + iz;
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
       }
       __syncthreads();
     }
-    if (h + 1 < h_hi) fetch(h + 1, 0);
+    if (h + 1 < h_hi) { bounds(h + 1); fetch(h + 1, o0); }
     // ---- sweep: normalise, store the slab of row h, fold into the running maximum, leave the counters zero
     const float rs = rowsum[h];
     const bool sel = !select || select[h];
@@ -368,28 +385,38 @@ extern "C" int coma_occupancy_reduce(float* counts, const uint8_t* select, int H
 }
 
 
-extern "C" size_t coma_occupancy_fused_workspace_bytes(int S, int H, int R) {
-  if (S <= 0 || H <= 0 || R <= 0) return 0;
+// workspace layout: [rec: H * S records | items: H * S * window words | plane_off: H * (R + 1) words | partial maxima: groups * R^3 f32]
+static size_t occ_ws_rec(int S, int H) { return occ_align256((size_t)S * H * sizeof(OccRec)); }
+static size_t occ_ws_items(int S, int H, int window) { return occ_align256((size_t)S * H * window * sizeof(unsigned)); }
+static size_t occ_ws_off(int H, int R) { return occ_align256((size_t)H * (R + 1) * sizeof(unsigned)); }
+static int occ_pow2_window(int window) {
+  if (window > 2 && (window & (window - 1))) { int w2 = 1; while (w2 < window) w2 <<= 1; window = w2; }   // cell decode by shifts
+  return window;
+}
+
+extern "C" size_t coma_occupancy_fused_workspace_bytes(int S, int H, int R, int window) {
+  window = occ_pow2_window(window);
+  if (S <= 0 || H <= 0 || R <= 0 || window < 2 || window > kFusedMaxWindow) return 0;
   const int64_t R3 = (int64_t)R * R * R;
   const int P = kFusedMaxCells / (R * R);
   if (P < 1) return 0;
   const int slabs = (R + P - 1) / P;
   int groups = (768 + slabs - 1) / slabs;   // three resident workgroups per CU (80 VGPRs, <= 50 KB of LDS each)
   if (groups > H) groups = H;
-  return (size_t)S * H * sizeof(OccRec) + (size_t)groups * R3 * sizeof(float) + 256;
+  return occ_ws_rec(S, H) + occ_ws_items(S, H, window) + occ_ws_off(H, R) + (size_t)groups * R3 * sizeof(float) + 256;
 }
 
 extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const double* centers, double voxel, double thres,
                                     double thres_sq_cut, int window, const uint8_t* select, int write_raw, float* counts, float* rowsum,
                                     float* out, void* workspace, size_t workspace_bytes, void* stream) {
   if (!q || !centers || !counts || !rowsum || !out || !workspace) return fail(COMA_E_INVALID, "coma_occupancy_fused: null pointer");
-  if (window > 2 && (window & (window - 1))) { int w2 = 1; while (w2 < window) w2 <<= 1; window = w2; }   // cell decode by shifts
+  window = occ_pow2_window(window);
   if (S <= 0 || H <= 0 || R <= 0 || R > 255 || (R * R) % 4 || !(voxel > 0.0) || !(thres > 0.0) || window < 2 || window > 16)
     return fail(COMA_E_INVALID, "coma_occupancy_fused: bad sizes S=%d H=%d R=%d window=%d (R*R must be a multiple of 4, R <= 255)", S, H, R, window);
   const int RR = R * R;
   const int P = kFusedMaxCells / RR;
   if (P < 1) return fail(COMA_E_INVALID, "coma_occupancy_fused: R=%d too large for an LDS-resident plane (use splat + reduce)", R);
-  const size_t need = coma_occupancy_fused_workspace_bytes(S, H, R);
+  const size_t need = coma_occupancy_fused_workspace_bytes(S, H, R, window);
   if (workspace_bytes < need) return fail(COMA_E_INVALID, "coma_occupancy_fused: workspace %zu < %zu bytes", workspace_bytes, need);
   const int slabs = (R + P - 1) / P;
   int groups = (768 + slabs - 1) / slabs;   // three resident workgroups per CU (80 VGPRs, <= 50 KB of LDS each)
@@ -397,13 +424,21 @@ extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const d
   const size_t lds = (((size_t)P * RR * 2 + 15) / 16) * 16 + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double);
   if (S >= 65536) return fail(COMA_E_INVALID, "coma_occupancy_fused: S=%d >= 65536 samples per call (16-bit counters)", S);
   hipStream_t st = (hipStream_t)stream;
-  OccRec* rec = reinterpret_cast<OccRec*>(workspace);
-  float* partial = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + (((size_t)S * H * sizeof(OccRec) + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(occupancy_rowprep_kernel, dim3((unsigned)H), dim3(256), 0, st, q, S, H, R, centers, voxel, thres, thres_sq_cut, rec, rowsum);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupancy_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return fail(COMA_E_LAUNCH, "coma_occupancy_fused: cannot reserve %zu bytes of LDS", lds);
-  hipLaunchKernelGGL(occupancy_fused_kernel, dim3((unsigned)slabs, (unsigned)groups), dim3(kFusedThreads), lds, st, rec, rowsum, select, S, H, R, P,
-                     window, groups, write_raw, centers, voxel, thres, thres_sq_cut, counts, partial);
+  unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+  OccRec* rec = reinterpret_cast<OccRec*>(wsb);
+  unsigned* items = reinterpret_cast<unsigned*>(wsb + occ_ws_rec(S, H));
+  unsigned* plane_off = reinterpret_cast<unsigned*>(wsb + occ_ws_rec(S, H) + occ_ws_items(S, H, window));
+  float* partial = reinterpret_cast<float*>(wsb + occ_ws_rec(S, H) + occ_ws_items(S, H, window) + occ_ws_off(H, R));
+  hipLaunchKernelGGL(occupancy_rowprep_kernel, dim3((unsigned)H), dim3(256), 0, st, q, S, H, R, window, centers, voxel, thres, thres_sq_cut,
+                     rec, items, plane_off, rowsum);
+  static size_t lds_set = 0;                                     // the attribute is per function, not per launch: set it when it grows
+  if (lds > lds_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupancy_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(COMA_E_LAUNCH, "coma_occupancy_fused: cannot reserve %zu bytes of LDS", lds);
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(occupancy_fused_kernel, dim3((unsigned)slabs, (unsigned)groups), dim3(kFusedThreads), lds, st, rec, items, plane_off, rowsum, select,
+                     S, H, R, P, window, groups, write_raw, centers, voxel, thres, thres_sq_cut, counts, partial);
   const int64_t R3 = (int64_t)R * RR;
   hipLaunchKernelGGL(occupancy_groupmax_kernel, dim3((unsigned)((R3 + 255) / 256)), dim3(256), 0, st, partial, groups, R3, out);
   return check_launch("occupancy fused kernels");

@@ -102,3 +102,92 @@ def occupancy_rows_reduce(occ_shard, n_rows: int, human_indices=None, group=None
     if full is not None and full is raw:
         full = full.clone()                                    # single process: the grid is normalised in place later
     return full, field
+
+
+# ------------------------------------------------------------------ K4 reducers, row-parallel
+def row_view(coma, lo: int, hi: int):
+    """A ComA over human rows [lo, hi) of `coma` that SHARES its state (dim-0 slices are contiguous views): the in-place
+    normalisation of the reducers then touches this rank's rows only."""
+    import copy
+    v = copy.copy(coma)
+    v.human_res = hi - lo
+    for k in type(coma)._STATE_KEYS:
+        setattr(v, k, getattr(coma, k)[lo:hi])
+    return v
+
+
+def _gather_rows(local: torch.Tensor, n_rows: int, group=None):
+    """Row shards (shard_slice) -> the full tensor on EVERY rank (padded all_gather: the vectors here are H or H*O floats)."""
+    world = dist.get_world_size(group)
+    per = -(-n_rows // world)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([parts[r][:shard_slice(n_rows, r, world)[1] - shard_slice(n_rows, r, world)[0]] for r in range(world)], dim=0)
+
+
+def aggregated_contact_row_parallel(coma, contact_map_type: str, significant_contact_ratio: float, group=None):
+    """`get_aggregated_contact` (utils/coma.py:614-641) on an all-reduced ComA with the K4 work sharded by human rows: every rank
+    normalises / reduces rows shard_slice(H, rank, world) of the two [H,O,N] grids and the small results are combined --
+    "human": the object-column mask is OR-ed over ranks (all-reduce MAX of a u8 vector), the [H] vector is all-gathered;
+    "obj": the per-shard column maxima are MAX-all-reduced (NaN-propagating), the row mask is all-gathered.
+    Returns (aggregated contact f32 NumPy vector, i64 index vector) on every rank, equal to the single-process call."""
+    import numpy as np
+    from . import _lib
+    assert contact_map_type in ["human", "obj"]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        from .coma import get_aggregated_contact
+        return get_aggregated_contact(coma, contact_map_type, significant_contact_ratio)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    H, O = coma.human_res, coma.obj_res
+    lo, hi = shard_slice(H, rank, world)
+    dev = coma.significant_contact_count.device
+    if hi > lo:
+        view = row_view(coma, lo, hi)
+        cm = view.compute_contact_map(contact_map_type=contact_map_type, as_numpy=False)[contact_map_type].contiguous()
+        _, col_any, row_any = view._pairs(significant_contact_ratio)
+    else:                                                    # more ranks than rows
+        cm = torch.zeros([0, O], dtype=torch.float32, device=dev)
+        col_any, row_any = torch.zeros([O], dtype=torch.uint8, device=dev), torch.zeros([0], dtype=torch.uint8, device=dev)
+    L = _lib.lib()
+    if contact_map_type == "human":
+        col = col_any.to(torch.int32)
+        dist.all_reduce(col, op=dist.ReduceOp.MAX, group=group)                 # object points with a significant contact anywhere
+        col_any = col.to(torch.uint8)
+        res = torch.zeros([hi - lo], dtype=torch.float32, device=dev)
+        if hi > lo:
+            rc = L.coma_masked_max_f32(_lib.ptr(cm, torch.float32), _lib.ptr(col_any), _lib.ptr(row_any), hi - lo, O, 0,
+                                       _lib.ptr(res), _lib.stream_ptr(dev))
+            _lib.check(rc, "coma_masked_max_f32")
+        agg = _gather_rows(res, H, group)
+        index = np.argwhere(col_any.cpu().numpy() > 0)[:, 0]                    # reference quirk: object columns for "human"
+    else:
+        res = torch.full([O], float("-inf"), dtype=torch.float32, device=dev)
+        if hi > lo and bool(row_any.any()):
+            rc = L.coma_masked_max_f32(_lib.ptr(cm, torch.float32), _lib.ptr(col_any), _lib.ptr(row_any), hi - lo, O, 1,
+                                       _lib.ptr(res), _lib.stream_ptr(dev))
+            _lib.check(rc, "coma_masked_max_f32")
+        all_reduce_max_nan(res, group)
+        rows = _gather_rows(row_any, H, group)
+        if not bool(rows.any()):
+            res = torch.zeros([O], dtype=torch.float32, device=dev)             # nothing significant anywhere (utils/coma.py:424-425)
+        agg = res
+        index = np.argwhere(rows.cpu().numpy() > 0)[:, 0]                       # ... and human rows for "obj"
+    return agg.cpu().numpy(), index
+
+
+def nonphysical_score_row_parallel(coma, nonphysical_type: str, group=None):
+    """`get_nonphysical_score` (entropy response, utils/coma.py:441-487) with the rows sharded the same way -> [H,O] f32 NumPy."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        from .coma import get_nonphysical_score
+        return get_nonphysical_score(coma, nonphysical_type)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    H, O = coma.human_res, coma.obj_res
+    lo, hi = shard_slice(H, rank, world)
+    dev = coma.significant_contact_count.device
+    if hi > lo:
+        s = row_view(coma, lo, hi).compute_nonphysical_response_sphere(n_bin=1e6, nonphysical_type=nonphysical_type, as_numpy=False)[nonphysical_type]
+    else:
+        s = torch.zeros([0, O], dtype=torch.float32, device=dev)
+    return _gather_rows(s.contiguous(), H, group).cpu().numpy()

@@ -130,8 +130,9 @@ int coma_occupancy_reduce(float* counts, const uint8_t* select, int H, int64_t R
  *                (dx^2+dy^2)+dz^2 < thres_sq_cut is bit-for-bit the reference's sqrt(...) < thres;
  * window       : candidate cells per axis, >= the number of voxel centres an open interval of length 2*thres (+ the 0.01-voxel
  *                margins) can contain: ceil(2*scale_tolerance) + 2;
- * workspace    : coma_occupancy_fused_workspace_bytes(S, H, R) bytes of device scratch.  R*R % 4 == 0, R*R <= 20480. */
-size_t coma_occupancy_fused_workspace_bytes(int S, int H, int R);
+ * workspace    : coma_occupancy_fused_workspace_bytes(S, H, R, window) bytes of device scratch (16 bytes per (vertex, sample) + 4 bytes per
+ *                (vertex, sample, window plane) + the per-group maxima).  R*R % 4 == 0, R*R <= 20480. */
+size_t coma_occupancy_fused_workspace_bytes(int S, int H, int R, int window);
 int coma_occupancy_fused(const float* q, int S, int H, int R, const double* centers, double voxel, double thres,
                          double thres_sq_cut, int window, const uint8_t* select, int write_raw, float* counts, float* rowsum,
                          float* out, void* workspace, size_t workspace_bytes, void* stream);

@@ -195,18 +195,32 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
             if rank == 0:
                 os.makedirs(save_dir, exist_ok=True)
                 coma.export(save_pth=save_pth)
+        # K4 reducers: with more than one rank every rank holds the all-reduced (or reloaded) state; each
+        # normalises / reduces its own human rows and the small vectors are combined (coma_amd/dist.py) -- after the export above,
+        # which must see the raw state (export-before-normalise, src/coma/extract_coma.py:426 of the reference)
+        agg = score = None
+        if world > 1 and visualize_type in ("aggr-human-contact", "aggr-object-contact"):
+            from coma_amd.dist import aggregated_contact_row_parallel
+            agg, _ = aggregated_contact_row_parallel(coma, "human" if visualize_type == "aggr-human-contact" else "obj",
+                                                     hp["significant_contact_ratio"])
+        elif world > 1 and visualize_type == "orientation":
+            from coma_amd.dist import nonphysical_score_row_parallel
+            score = nonphysical_score_row_parallel(coma, "human")
         if rank == 0:
             out = f"{affordance_save_dir}/{sc}/{c}/{asset_id}/{hyperparams_key}:{mp}"
             os.makedirs(out, exist_ok=True)
             if visualize_type == "aggr-human-contact":
-                agg, _ = get_aggregated_contact(coma=coma, contact_map_type="human", significant_contact_ratio=hp["significant_contact_ratio"])
+                if agg is None:
+                    agg, _ = get_aggregated_contact(coma=coma, contact_map_type="human", significant_contact_ratio=hp["significant_contact_ratio"])
                 np.save(f"{out}/human_contact.npy", agg / agg.max())
             elif visualize_type == "aggr-object-contact":
-                agg, _ = get_aggregated_contact(coma=coma, contact_map_type="obj", significant_contact_ratio=hp["significant_contact_ratio"])
+                if agg is None:
+                    agg, _ = get_aggregated_contact(coma=coma, contact_map_type="obj", significant_contact_ratio=hp["significant_contact_ratio"])
                 write_ply_pointcloud(f"{out}/object_contact.ply", object_meta["downsampled_pcd_points_raw"],
                                      object_meta["downsampled_pcd_normal_raw"], jet_rgb(agg / agg.max()))
             elif visualize_type == "orientation":
-                s = coma.compute_nonphysical_response_sphere(n_bin=1e6, nonphysical_type="human", as_numpy=True)["human"][:, 0]
+                s = (score if score is not None else
+                     coma.compute_nonphysical_response_sphere(n_bin=1e6, nonphysical_type="human", as_numpy=True)["human"])[:, 0]
                 np.save(f"{out}/orientational_tendency.npy", (s - s.min()) / (s.max() - s.min()))
             elif visualize_type == "occupancy":
                 field = (field_dev if field_dev is not None else coma.return_aggregated_spatial_grids(human_indices=None)).cpu().numpy()

@@ -531,3 +531,62 @@ def test_optimisation_app_targets_full_size_vs_oracle(dev, hip_lib):
     assert np.array_equal(got[2][0], ref[2][0]) and np.array_equal(got[3], ref[3]) and 0 < len(ref[3]) < H
     with pytest.raises(IndexError):
         orientation_and_contact_targets(info, O, 2.5, device=dev)
+
+
+_K4_WORKER = r"""
+import copy, os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from coma_amd import dist as cdist
+from tests.synth import make_samples
+from utils.coma import ComA, get_aggregated_contact, get_nonphysical_score
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)          # two ranks on one GPU: gloo (RCCL refuses a shared device)
+H, O, N, S = 37, 9, 250, 6                                             # 37 rows over 2 ranks: 19 + 18
+
+
+def build(samples):
+    c = ComA(H, O, N, 0, proximity_settings=dict(spatial_grid_size=0.07, spatial_grid_thres=0.03), normal_gaussian_sigma=0.25,
+             eps=1e-10, device="cuda:0")
+    for s in samples:
+        c.register_sample_to_cache(**copy.deepcopy(s))
+    c.aggregate_all_samples()
+    return c
+
+
+samples = make_samples(H, O, S, seed=4, thres=0.03)
+# sharded accumulation + the SUM all-reduce, then the row-parallel reducers on the all-reduced state
+lo, hi = cdist.shard_slice(S, rank, world)
+part = build(samples[lo:hi])
+part.all_reduce()
+assert part.used_count == S
+whole = build(samples)                                                 # the single-process ComA of all samples
+for ratio in (0.1, 0.5, 2.0):                                          # 2.0: no significant pair anywhere -> zeros
+    for kind in ("human", "obj"):
+        ref_agg, ref_idx = get_aggregated_contact(copy.deepcopy(whole), kind, ratio)
+        agg, idx = cdist.aggregated_contact_row_parallel(copy.deepcopy(part), kind, ratio)
+        assert np.array_equal(idx, ref_idx), (kind, ratio)
+        assert agg.shape == ref_agg.shape and np.allclose(agg, ref_agg, rtol=1e-5, atol=0, equal_nan=True), (kind, ratio)
+ref_s = get_nonphysical_score(copy.deepcopy(whole), "human")
+s = cdist.nonphysical_score_row_parallel(copy.deepcopy(part), "human")
+assert s.shape == (H, O) and np.allclose(s, ref_s, rtol=1e-5, atol=1e-7, equal_nan=True)
+dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def test_k4_reducers_row_parallel_two_ranks(tmp_path, hip_lib):
+    """after the SUM all-reduce every rank normalises / reduces its own human rows; aggregated contact (both kinds,
+    incl. the index-vector quirk and the nothing-significant case) and the entropy response equal the single-process results."""
+    import subprocess
+    import sys
+    script = tmp_path / "wk4.py"
+    script.write_text(_K4_WORKER)
+    port = 33500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, out[-3000:]
