@@ -58,6 +58,23 @@ SIGNATURES = {
     "sd_vae_sample": (_i, [_vp, _i, _vp, _f, _i64, _vp, _vp, _vp]),
     "sd_add_noise": (_i, [_vp, _vp, _f, _i64, _vp, _vp]),
     "sd_mask_adapt": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sd_model_create": (_i, [C.POINTER(_vp)]),
+    "sd_model_destroy": (_i, [_vp]),
+    "sd_model_register_buffer": (_i, [_vp, _vp, C.c_size_t, _i]),
+    "sd_model_bind": (_i, [_vp, C.c_char_p, _vp, C.c_size_t]),
+    "sd_model_binding": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "sd_model_record_begin": (_i, [_vp, C.c_char_p]),
+    "sd_model_record_end": (_i, [_vp]),
+    "sd_model_num_launches": (_i, [_vp, C.c_char_p]),
+    "sd_model_run": (_i, [_vp, C.c_char_p, _vp]),
+    "sd_model_replay": (_i, [_vp, C.c_char_p, _vp]),
+    "sd_model_save": (_i, [_vp, C.c_char_p]),
+    "sd_model_load": (_i, [C.c_char_p, C.POINTER(_vp)]),
+    "sd_copy_d2d": (_i, [_vp, _vp, C.c_size_t, _vp]),
+    "sd_unet_set_context": (_i, [_vp, _vp, _vp]),
+    "sd_unet_forward": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "sd_vae_decode": (_i, [_vp, _vp, _vp, _vp]),
+    "sd_vae_encode": (_i, [_vp, _vp, _vp, _vp]),
     "sd_mask_adapt_batched": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

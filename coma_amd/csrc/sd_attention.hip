@@ -27,6 +27,7 @@
 #include <utility>
 
 #include "common.h"
+#include "sd_plan.h"
 #include "../../include/sd_hip.h"
 
 namespace sd {
@@ -610,6 +611,15 @@ using namespace sd;
 
 extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq,
                                 int lk, int d, int ldq, int ldk, int ldv, int ldo, float scale, int vt_perm16, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_ATTN;
+    r.p[0] = (void*)q; r.p[1] = (void*)k; r.p[2] = (void*)vt; r.p[3] = out;
+    const int64_t is[10] = {batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, vt_perm16};
+    for (int j = 0; j < 10; ++j) r.i[j] = is[j];
+    r.f[0] = scale;
+    return sd::plan_record(r);
+  }
   if (!q || !k || !vt || !out) return fail(COMA_E_INVALID, "sd_attention_f16: null pointer");
   if (batch <= 0 || heads <= 0 || lq <= 0 || lk <= 0) return fail(COMA_E_INVALID, "sd_attention_f16: bad sizes");
   if (d % 8 || d <= 0 || d > 160) return fail(COMA_E_INVALID, "sd_attention_f16: head dim %d unsupported (multiple of 8, <= 160)", d);

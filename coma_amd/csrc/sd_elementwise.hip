@@ -5,6 +5,7 @@
 #include <hip/hip_fp16.h>
 
 #include "common.h"
+#include "sd_plan.h"
 #include "../../include/sd_hip.h"
 
 namespace sd {
@@ -119,6 +120,12 @@ extern "C" int sd_cfg_ddim_step(const void* eps_uc, int eps_ld, float* latents, 
 }
 
 extern "C" int sd_timestep_embedding_f16(const float* timesteps, int batch, int dim, void* out, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_TEMB;
+    r.p[0] = (void*)timesteps; r.p[1] = out; r.i[0] = batch; r.i[1] = dim;
+    return sd::plan_record(r);
+  }
   if (!timesteps || !out || batch <= 0 || dim <= 0 || dim % 2) return fail(COMA_E_INVALID, "sd_timestep_embedding_f16: bad args");
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3((batch * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, timesteps,
                      batch, dim, (_Float16*)out);

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "common.h"
+#include "sd_plan.h"
 #include "../../include/sd_hip.h"
 
 namespace sd {
@@ -901,6 +902,19 @@ extern "C" int sd_debug_timestamps(unsigned long long* host_dst, int n_blocks) {
 }
 
 extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
+  if (sd::plan_recording()) {
+    if (!d_in) return sd::fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
+    const sd_conv_gemm_desc& d = *d_in;
+    sd::PlanRec r{};
+    r.kind = sd::PK_CONV;
+    void* ps[12] = {(void*)d.a0, (void*)d.a1, (void*)d.w, (void*)d.bias, (void*)d.bias_bn, (void*)d.res, d.out, d.workspace, d.colstats,
+                    (void*)d.ln_stats, (void*)d.ln_colsum, d.rowstats};
+    for (int k = 0; k < 12; ++k) r.p[k] = ps[k];
+    const int64_t is[23] = {d.c0, d.c1, d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.taps, d.stride, d.upsample, d.pad, d.n, d.ldbb, d.ldr, d.ldo,
+                            d.epi, d.nbatch_z, d.stride_a, d.stride_w, d.stride_out, d.stride_res, (int64_t)d.workspace_bytes, d.stride_ln_stats};
+    for (int k = 0; k < 23; ++k) r.i[k] = is[k];
+    return sd::plan_record(r);
+  }
   if (!d_in) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
   // SD_GEMM_TUNE=<mask> (or _1X1 / _3X3 for those launches only): OR tuning-knob bits (SD_EPI_TUNING_MASK) into every launch -- lets a dispatch rule be A/B-tested inside the
   // captured UNet (scripts/time_unet.py), where cache state differs from a layer timed alone (profiles/r02_notes.md section 14)

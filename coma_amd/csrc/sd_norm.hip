@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "sd_plan.h"
 #include "../../include/sd_hip.h"
 
 namespace sd {
@@ -443,6 +444,13 @@ using namespace sd;
 // scratch layout (floats): [batch*C*2] affine table, then [batch*nchunk*groups*2] partial sums
 extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                                 const void* gamma, const void* beta, int silu, void* out, float* stats, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_GN;
+    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = (void*)gamma; r.p[3] = (void*)beta; r.p[4] = out; r.p[5] = stats;
+    r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = hw; r.i[4] = groups; r.i[5] = silu; r.f[0] = eps;
+    return sd::plan_record(r);
+  }
   if (!x0 || !gamma || !beta || !out || !stats) return fail(COMA_E_INVALID, "sd_groupnorm_f16: null pointer");
   if (c1 > 0 && !x1) return fail(COMA_E_INVALID, "sd_groupnorm_f16: x1 missing");
   const int C = c0 + c1;
@@ -469,6 +477,12 @@ extern "C" int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, 
 
 extern "C" int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* gamma, const void* beta,
                                 void* out, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_LN;
+    r.p[0] = (void*)x; r.p[1] = (void*)gamma; r.p[2] = (void*)beta; r.p[3] = out; r.i[0] = rows; r.i[1] = c; r.f[0] = eps;
+    return sd::plan_record(r);
+  }
   if (!x || !gamma || !beta || !out) return fail(COMA_E_INVALID, "sd_layernorm_f16: null pointer");
   if (rows <= 0 || c <= 0 || c % 8 || c > 2048) return fail(COMA_E_INVALID, "sd_layernorm_f16: bad shape c=%d", c);
 #define SD_LN_LAUNCH(R_, CH_)                                                                                                  \
@@ -492,6 +506,12 @@ extern "C" int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, c
 }
 
 extern "C" int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_SOFTMAX;
+    r.p[0] = x; r.i[0] = rows; r.i[1] = n; r.i[2] = ld; r.f[0] = scale;
+    return sd::plan_record(r);
+  }
   if (!x) return fail(COMA_E_INVALID, "sd_softmax_f16: null pointer");
   if (rows <= 0 || n <= 0 || ld < n) return fail(COMA_E_INVALID, "sd_softmax_f16: bad shape");
   hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (_Float16*)x, n, ld, scale);
@@ -524,6 +544,12 @@ __global__ __launch_bounds__(256) void ln_rowstats_finalize_kernel(const float* 
 }  // namespace sd
 
 extern "C" int sd_ln_rowstats_finalize(const float* partial, int64_t rows, int parts, int c, float eps, float* stats, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_LN_STATS;
+    r.p[0] = (void*)partial; r.p[1] = stats; r.i[0] = rows; r.i[1] = parts; r.i[2] = c; r.f[0] = eps;
+    return sd::plan_record(r);
+  }
   if (!partial || !stats) return coma::fail(COMA_E_INVALID, "sd_ln_rowstats_finalize: null pointer");
   if (rows <= 0 || parts <= 0 || c != parts * 32) return coma::fail(COMA_E_INVALID, "sd_ln_rowstats_finalize: bad sizes rows=%lld parts=%d c=%d", (long long)rows, parts, c);
   hipLaunchKernelGGL(sd::ln_rowstats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
@@ -534,6 +560,14 @@ extern "C" int sd_ln_rowstats_finalize(const float* partial, int64_t rows, int p
 extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                                          const void* gamma, const void* beta, int silu, void* out, float* stats,
                                          const float* colstats0, const float* colstats1, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_GN_COLSTATS;
+    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = (void*)gamma; r.p[3] = (void*)beta; r.p[4] = out; r.p[5] = stats;
+    r.p[6] = (void*)colstats0; r.p[7] = (void*)colstats1;
+    r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = hw; r.i[4] = groups; r.i[5] = silu; r.f[0] = eps;
+    return sd::plan_record(r);
+  }
   if (!x0 || !gamma || !beta || !out || !stats || !colstats0) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: null pointer");
   if (c1 > 0 && (!x1 || !colstats1)) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: second source incomplete");
   const int C = c0 + c1;

@@ -1,0 +1,22 @@
+// Internal: recording hook shared by the sd_* launch entry points (see sd_plan.hip).
+#pragma once
+#include <cstdint>
+
+namespace sd {
+
+enum PlanKind : int { PK_CONV = 1, PK_GN, PK_GN_COLSTATS, PK_LN_STATS, PK_LN, PK_ATTN, PK_SOFTMAX, PK_TEMB, PK_COPY, PK_COUNT_ };
+
+// One recorded launch: every pointer argument in p[], every integer in i[], every float in f[] (the entry point that records it
+// and the replay switch in sd_plan.hip agree on the order).  Pointers are kept apart so that a saved model can be relocated.
+struct PlanRec {
+  int kind;
+  int reserved;
+  void* p[14];
+  int64_t i[24];
+  double f[4];
+};
+
+bool plan_recording();                 // is this thread recording into a model?
+int plan_record(const PlanRec& r);     // append; returns COMA_OK
+
+}  // namespace sd

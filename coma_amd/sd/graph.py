@@ -1,26 +1,30 @@
-"""Static launch graphs: a model is compiled ONCE into a flat list of kernel launches over pre-allocated NHWC fp16
-buffers (no allocation, no host sync inside), which is then either run eagerly or captured into a HIP graph
-(torch.cuda.CUDAGraph on ROCm) and replayed per denoising step.  This replaces the per-op Python dispatch of the
-reference's diffusers modules -- the MI355X-first equivalent of a tracing compiler is "hipGraph over hand-written
-kernels" (round brief), not op-by-op eager execution.
+"""Static launch graphs: a network is compiled ONCE into a flat list of kernel launches over pre-allocated NHWC fp16 buffers (no
+allocation, no host sync inside).  The list is RECORDED into a library-owned model (coma_amd/csrc/sd_plan.hip, sd/model.py): the
+launch list and the hipGraph captured from it live in libcoma_hip.so, a denoising step is one sd_model_replay, and the model can
+be saved to a file a caller without Python loads and runs (sd_model_load / sd_unet_forward).  The Python closures are kept for
+per-launch profiling (`run`, `profile`).  This replaces the per-op Python dispatch of the reference's diffusers modules -- the
+MI355X-first equivalent of a tracing compiler is "hipGraph over hand-written kernels", not op-by-op eager execution.
 """
 from __future__ import annotations
 
 import torch
 
 from . import ops
+from .model import BUF_ZEROED, SdModel
 
 F16 = torch.float16
 
 
 class LaunchGraph:
-    def __init__(self, device):
+    def __init__(self, device, model=None, plan="step"):
         self.device = torch.device(device)
+        self.model = model if model is not None else SdModel(device)     # several graphs may share one model (UNet: step + context)
+        self.plan = plan
+        self._recorded = False
         self.launches = []          # zero-argument closures
         self.tags = []              # (description, flops) per launch, for profiling
         self.alg_bytes = []         # algorithmic HBM bytes per launch (inputs read once + output written once)
         self.flops = 0              # algorithmic MFMA flops per run (2*M*N*K of every GEMM-shaped launch)
-        self._graph = None
         self._gn_stats = None
         self._ws = None             # split-K workspace shared by every GEMM of the graph (launches are serial)
         self._colstats = {}         # data_ptr of a GEMM output -> its [M/32][2][N] column-sum buffer (GroupNorm statistics)
@@ -30,12 +34,14 @@ class LaunchGraph:
 
     # ---- memory
     def buf(self, *shape, dtype=F16, zero=False):
-        return (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.device)
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.device)
+        self.model.register(t, BUF_ZEROED if zero else 0)                # scratch: not part of a saved model's contents
+        return t
 
     def gn_scratch(self, batch, hw):
         n = ops.gn_scratch_floats(batch, hw)
         if self._gn_stats is None or self._gn_stats.numel() < n:
-            self._gn_stats = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=self.device)
+            self._gn_stats = self.buf(max(n, 1 << 16), dtype=torch.float32)
         return self._gn_stats
 
     # ---- recording
@@ -50,17 +56,17 @@ class LaunchGraph:
         ow = out_w if out_w is not None else in_w
         z = kw.get("nbatch_z", 1)
         if self._ws is None:
-            self._ws = torch.empty(16 << 20, dtype=torch.float32, device=self.device)   # 64 MiB
+            self._ws = self.buf(16 << 20, dtype=torch.float32)   # 64 MiB
         kw.setdefault("workspace", self._ws)
         # GroupNorm statistics of the consumer come for free from the epilogue of large, never-split GEMMs
         M = batch * oh * ow
         if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= 16384 and M % 32 == 0:
-            cs = torch.zeros(M // 32, 2, n, dtype=torch.float32, device=self.device)
+            cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
             kw["colstats"] = cs
             self._colstats[out.data_ptr()] = cs
         # ... and the LayerNorm statistics of a transformer-block consumer from the same epilogue (never with split-K)
         if kw.pop("rowstats", False):
-            rs = torch.zeros(n // 32, M, 2, dtype=torch.float32, device=self.device)
+            rs = self.buf(n // 32, M, 2, dtype=torch.float32, zero=True)
             kw["rowstats"] = rs
             self._rowstats[out.data_ptr()] = rs
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
@@ -76,18 +82,24 @@ class LaunchGraph:
     def dup(self, src, dst):
         """dst = [src | src] along the batch axis (two identical CFG halves); the GroupNorm column sums of src follow."""
         assert dst.numel() == 2 * src.numel()
-        self.add(lambda: dst.view(2, -1).copy_(src.view(1, -1)), tag=f"dup {src.numel() * 2 >> 20} MiB")
+        self._dup(src, dst, tag=f"dup {src.numel() * 2 >> 20} MiB")
         rs = self._rowstats.get(src.data_ptr())
         if rs is not None:
-            rs2 = torch.zeros(rs.shape[0], 2 * rs.shape[1], 2, dtype=rs.dtype, device=self.device)      # [parts][rows][2]: rows double
-            self.add(lambda: rs2.view(rs.shape[0], 2, -1).copy_(rs.view(rs.shape[0], 1, -1)), tag="dup rowstats")
+            rs2 = self.buf(rs.shape[0], 2 * rs.shape[1], 2, dtype=rs.dtype, zero=True)      # [parts][rows][2]: rows double
+            for part in range(rs.shape[0]):
+                self._dup(rs[part], rs2[part], tag="dup rowstats")
             self._rowstats[dst.data_ptr()] = rs2
         cs = self._colstats.get(src.data_ptr())
         if cs is not None:
-            cs2 = torch.zeros(2 * cs.shape[0], *cs.shape[1:], dtype=cs.dtype, device=self.device)
-            self.add(lambda: cs2.view(2, -1).copy_(cs.view(1, -1)), tag="dup colstats")
+            cs2 = self.buf(2 * cs.shape[0], *cs.shape[1:], dtype=cs.dtype, zero=True)
+            self._dup(cs, cs2, tag="dup colstats")
             self._colstats[dst.data_ptr()] = cs2
         return dst
+
+    def _dup(self, src, dst, tag):
+        """dst = [src | src]: two device-to-device copies (recordable, unlike a torch copy_)."""
+        half = dst.view(2, -1)
+        self.add(lambda: (ops.copy_d2d(half[0], src.view(-1)), ops.copy_d2d(half[1], src.view(-1))), tag=tag)
 
     def groupnorm(self, x0, gamma, beta, out, *, batch, hw, c0, x1=None, c1=0, eps, silu):
         stats = self.gn_scratch(batch, hw)
@@ -146,21 +158,22 @@ class LaunchGraph:
         return out
 
     def capture(self):
-        """Capture the launch list into a HIP graph (warm-up run first, on a side stream as torch requires)."""
-        s = torch.cuda.Stream(self.device)
-        s.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(s):
-            self.run()
-        torch.cuda.current_stream(self.device).wait_stream(s)
-        torch.cuda.synchronize(self.device)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.run()
-        self._graph = g
-        return g
+        """Record the launch list into the library-owned plan (once), run it eagerly once (module loading and argument checks happen
+        outside any capture); the library captures its hipGraph on the first replay."""
+        if not self._recorded:
+            self.model.record(self.plan, self.run)
+            assert self.model.num_launches(self.plan) >= len(self.launches)
+            self._recorded = True
+            self.model.run(self.plan)
+            torch.cuda.synchronize(self.device)
+        return self.model
+
+    def run_recorded(self):
+        """The recorded list launched natively one by one (no Python per launch, no graph)."""
+        self.capture()
+        self.model.run(self.plan)
 
     def replay(self):
-        if self._graph is None:
-            self.run()
-        else:
-            self._graph.replay()
+        if not self._recorded:
+            self.capture()
+        self.model.replay(self.plan)

@@ -26,6 +26,9 @@ class ConvGemmDesc(C.Structure):
 def _p(t, name="tensor", dtype=F16):
     if t is None:
         return None
+    from . import model
+    if model._recording is not None:            # a plan is being recorded: whatever it points into belongs to the model
+        model._recording.register(t)            # (buffers of LaunchGraph.buf were registered as scratch before: no-op for them)
     return _lib.ptr(t, dtype, name).value
 
 
@@ -184,3 +187,11 @@ def mask_adapt_batched(seg, default_mask, image_nchw, mask_full, mask_latent, ma
                                           1 if write_pad else 0, _p(mask_full, "mask_full", u8), _p(mask_latent), _p(masked_image),
                                           _p(area, "area", torch.int32), _p(scratch, "scratch", u8), _stream(mask_full))
     _lib.check(rc, "sd_mask_adapt_batched")
+
+
+def copy_d2d(dst, src):
+    """dst <- src (same byte count), device to device on the current stream; recordable into a plan."""
+    n = src.numel() * src.element_size()
+    assert dst.numel() * dst.element_size() == n and dst.is_contiguous() and src.is_contiguous()
+    _p(dst, "dst", dst.dtype), _p(src, "src", src.dtype)
+    _lib.check(_lib.lib().sd_copy_d2d(dst.data_ptr(), src.data_ptr(), n, _stream(dst)), "sd_copy_d2d")

@@ -50,8 +50,8 @@ class HipUNet2DConditionModel:
         self._B = batch                              # batch the block builders currently emit launches for
         self.dtype = F16
         self.s = {k: v.to(self.device, F16) for k, v in state.items()}
-        self.g = LaunchGraph(self.device)        # per-step graph
-        self.gc = LaunchGraph(self.device)       # per-prompt graph (cross-attention K / V^T of the text context)
+        self.g = LaunchGraph(self.device, plan="step")                              # per-step graph
+        self.gc = LaunchGraph(self.device, model=self.g.model, plan="context")      # per-prompt graph (cross-attention K / V^T of the text context)
         B, HW = batch, height * width
         # static inputs / outputs
         self.x_in = self.g.buf(B, HW, 64, zero=True)              # 9 valid channels (latents|mask|masked latents)
@@ -59,7 +59,9 @@ class HipUNet2DConditionModel:
         self.ctx = self.g.buf(B, ctx_len, self.ctx_dim, zero=True)
         self.eps = None
         self._build()
-        self._captured = False
+        # the names sd_unet_forward / sd_unet_set_context look up (include/sd_hip.h)
+        for name, t in (("x_in", self.x_in), ("timesteps", self.timesteps), ("ctx", self.ctx), ("eps", self.eps)):
+            self.g.model.bind(name, t)
 
     # ------------------------------------------------------------------ graph construction
     def _build(self):
@@ -242,18 +244,24 @@ class HipUNet2DConditionModel:
     def set_context(self, encoder_hidden_states):
         """[batch, ctx_len, 768]; recomputes the cross-attention K / V^T of every transformer block."""
         self.ctx.copy_(encoder_hidden_states.to(self.device, F16).reshape(self.ctx.shape))
-        self.gc.run()
+        if self.use_graph:
+            self.gc.replay()
+        else:
+            self.gc.run()
 
     def forward_static(self):
         """x_in / timesteps already written into the static buffers; result lands in self.eps ([B*HW, 64])."""
         if self.use_graph:
-            if not self._captured:
-                self.g.capture()
-                self._captured = True
-            self.g.replay()
+            self.g.replay()                  # sd_model_replay: the library's hipGraph of the recorded launch list
         else:
             self.g.run()
         return self.eps
+
+    def save(self, path):
+        """Write the model file (registry + bindings + both plans + weights) that sd_model_load / sd_unet_forward run without Python."""
+        self.g.capture()
+        self.gc.capture()
+        self.g.model.save(path)
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, return_dict=False, **kw):
         """diffusers-compatible call: sample NCHW [batch, 9, H, W] -> (noise_pred NCHW [batch, 4, H, W],)."""

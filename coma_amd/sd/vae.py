@@ -20,14 +20,13 @@ class _Cfg(dict):
 
 
 class _VaeBase:
-    def __init__(self, state, batch, device, cfg, use_graph=True):
+    def __init__(self, state, batch, device, cfg, use_graph=True, plan="decode"):
         self.use_graph = use_graph
         self.cfgd = cfg
         self.device = torch.device(device)
         self.batch = batch
         self.s = {k: v.to(self.device, F16) for k, v in state.items()}
-        self.g = LaunchGraph(self.device)
-        self._captured = False
+        self.g = LaunchGraph(self.device, plan=plan)
 
     def _resnet(self, p, x, cin, cout, H, W):
         g, s, B = self.g, self.s, self.batch
@@ -74,17 +73,19 @@ class _VaeBase:
     def _replay(self):
         if not self.use_graph:
             return self.g.run()
-        if not self._captured:
-            self.g.capture()
-            self._captured = True
         self.g.replay()
+
+    def save(self, path):
+        """The model file sd_model_load + sd_vae_decode / sd_vae_encode run without Python."""
+        self.g.capture()
+        self.g.model.save(path)
 
 
 class HipVaeDecoder(_VaeBase):
     """z (fp16 NHWC [B, h*w, 64], 4 valid channels, ALREADY divided by scaling_factor) -> image NHWC [B, 64*h*w, 64]."""
 
     def __init__(self, state, batch, latent_h=64, latent_w=64, device="cuda", cfg=VAE_CFG):
-        super().__init__(state, batch, device, cfg)
+        super().__init__(state, batch, device, cfg, plan="decode")
         g, s, B = self.g, self.s, batch
         ch = cfg["block_out_channels"]
         H, W = latent_h, latent_w
@@ -117,6 +118,8 @@ class HipVaeDecoder(_VaeBase):
         g.conv(gn, conv_weight(s["decoder.conv_out.weight"], cout_pad=64), self.image, batch=B, in_h=H, in_w=W, c0=cin, n=64,
                taps=9, bias=pad_vec(s["decoder.conv_out.bias"], 64))
         self.out_h, self.out_w = H, W
+        g.model.bind("z", self.z)
+        g.model.bind("image", self.image)
 
     def decode_static(self):
         self._replay()
@@ -127,7 +130,7 @@ class HipVaeEncoder(_VaeBase):
     """image (fp16 NHWC [B, H*W, 64], 3 valid channels in [-1,1]) -> moments NHWC [B, H/8*W/8, 64] (mean 4 | logvar 4)."""
 
     def __init__(self, state, batch, height=512, width=512, device="cuda", cfg=VAE_CFG):
-        super().__init__(state, batch, device, cfg)
+        super().__init__(state, batch, device, cfg, plan="encode")
         g, s, B = self.g, self.s, batch
         ch = cfg["block_out_channels"]
         H, W = height, width
@@ -160,6 +163,8 @@ class HipVaeEncoder(_VaeBase):
         g.conv(mo, conv_weight(s["quant_conv.weight"], cin_pad=64, cout_pad=64), self.moments, batch=B * H * W, in_h=1, in_w=1,
                c0=64, n=64, bias=pad_vec(s["quant_conv.bias"], 64))
         self.lat_h, self.lat_w = H, W
+        g.model.bind("x", self.x)
+        g.model.bind("moments", self.moments)
 
     def encode_static(self):
         self._replay()

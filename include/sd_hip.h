@@ -182,6 +182,52 @@ int sd_mask_adapt_batched(const uint8_t* seg, const uint8_t* default_mask, int b
                           int force_default, double area_thres, const float* image_nchw, int cpad, int write_pad,
                           uint8_t* mask_full, void* mask_latent, void* masked_image, int32_t* area, uint8_t* scratch, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Models: the launch list and the hipGraph of a network live in the library (coma_amd/csrc/sd_plan.hip).
+ * A model = a registry of device buffers + named bindings (inputs / outputs) + named plans (recorded launch lists).
+ * Recording: between sd_model_record_begin and sd_model_record_end every sd_* LAUNCH entry point called on the thread
+ * (sd_conv_gemm_f16, sd_groupnorm*_f16, sd_layernorm_f16, sd_ln_rowstats_finalize, sd_attention_f16, sd_softmax_f16,
+ * sd_timestep_embedding_f16, sd_copy_d2d) appends its arguments to the plan instead of launching; arguments are validated when
+ * the plan first runs.  sd_model_run launches the list eagerly on `stream`; sd_model_replay captures it once into a hipGraph (on a
+ * private stream, nothing executes during capture) and launches the graph on `stream`.
+ * sd_model_save / sd_model_load: ONE file with the registry, the bindings, the plans and the contents of the SD_BUF_PERSISTENT
+ * buffers (weights, constants); a loaded model owns its device memory (freed by sd_model_destroy), a recorded one borrows the
+ * caller's buffers, which must outlive it.  Every pointer a plan uses must lie inside a registered buffer for the model to be
+ * saved.  Not thread-safe per model; distinct models are independent. */
+#define SD_BUF_PERSISTENT 1   /* contents are part of the model (saved / restored) */
+#define SD_BUF_ZEROED 2       /* must start as zeros (pad channels that kernels never write); loaded buffers always start zeroed */
+int sd_model_create(void** model);
+int sd_model_destroy(void* model);
+int sd_model_register_buffer(void* model, void* ptr, size_t bytes, int flags);
+int sd_model_bind(void* model, const char* name, void* ptr, size_t bytes);            /* name: at most 31 characters */
+int sd_model_binding(const void* model, const char* name, void** ptr, size_t* bytes);
+int sd_model_record_begin(void* model, const char* plan_name);                        /* an existing plan of that name is replaced */
+int sd_model_record_end(void* model);
+int sd_model_num_launches(const void* model, const char* plan_name);                  /* -1: no such plan */
+int sd_model_run(void* model, const char* plan_name, void* stream);
+int sd_model_replay(void* model, const char* plan_name, void* stream);
+int sd_model_save(const void* model, const char* path);
+int sd_model_load(const char* path, void** model);
+/* dst[0:bytes) = src[0:bytes), device to device, on `stream` (recordable: the duplicated CFG halves of the UNet). */
+int sd_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+
+/* The three networks of the inpainting loop as entry points over a model (recorded by coma_amd/sd/{unet,vae}.py or loaded from a
+ * file).  Inputs are copied device-to-device into the model's bound buffers, the plan's hipGraph is launched, the result is copied
+ * out; a NULL input / output pointer means "already in place / leave it in the bound buffer" (sd_model_binding gives the address).
+ *   sd_unet_set_context  plan "context": ctx fp16 [2B,77,768] -> cross-attention K / V^T of every block   (once per prompt)
+ *   sd_unet_forward      plan "step":    x_in fp16 [2B, h*w, 64] (9 valid channels: latents | mask | masked-image latents),
+ *                                        timesteps fp32 [2B] -> eps fp16 [2B*h*w, 64] (4 valid channels)
+ *                        replaces: self.unet(latent_model_input, t, encoder_hidden_states=prompt_embeds, ...)[0],
+ *                                  utils/adaptive_mask_inpainting.py:1001-1007
+ *   sd_vae_decode        plan "decode":  z fp16 [B, h*w, 64] (4 valid channels, already divided by scaling_factor)
+ *                                        -> image fp16 [B*8h*8w, 64] (3 valid channels)     replaces: self.vae.decode, :1086, :1112
+ *   sd_vae_encode        plan "encode":  x fp16 [B, H*W, 64] (3 valid channels in [-1,1]) -> moments fp16 [B*h*w, 64] (mean 4 | logvar 4)
+ *                                        replaces: self.vae.encode(image).latent_dist (before .sample), :677-680 */
+int sd_unet_set_context(void* model, const void* ctx, void* stream);
+int sd_unet_forward(void* model, const void* x_in, const float* timesteps, void* eps_out, void* stream);
+int sd_vae_decode(void* model, const void* z, void* image_out, void* stream);
+int sd_vae_encode(void* model, const void* image, void* moments_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

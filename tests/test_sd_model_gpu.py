@@ -1,0 +1,141 @@
+"""GPU: the library-owned models (include/sd_hip.h "Models", coma_amd/csrc/sd_plan.hip).
+(1) the recorded plan replayed by the library (eager list and hipGraph) gives the same bits as the Python launch list;
+(2) a model file written by sd_model_save is loaded and run by a C program that never touches Python -- sd_model_load +
+    sd_unet_set_context / sd_unet_forward, sd_vae_decode, sd_vae_encode -- and returns the same bits as the in-process network
+    (these three are C entry points now)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY_UNET = dict(in_channels=9, out_channels=4, block_out_channels=(64, 128, 256, 256), layers_per_block=2, heads=8, cross_attention_dim=768,
+                 groups=32, down_has_attn=(True, True, True, False), up_has_attn=(False, True, True, True))
+TINY_VAE = dict(latent_channels=4, block_out_channels=(64, 128, 128, 128), layers_per_block=2, groups=32, scaling_factor=0.18215)
+
+
+@pytest.fixture(scope="module")
+def c_runner(tmp_path_factory, hip_lib):
+    exe = tmp_path_factory.mktemp("c") / "run_model"
+    libdir = os.path.join(ROOT, "coma_amd")
+    # plain gcc: the caller is C, it needs only the two headers, libcoma_hip.so and the HIP runtime for its own buffers
+    cmd = ["gcc", os.path.join(ROOT, "tests", "c", "run_model.c"), "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           "-D__HIP_PLATFORM_AMD__", "-L" + libdir, "-lcoma_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return str(exe)
+
+
+def _unet(batch=2, hw=16, **kw):
+    from coma_amd.sd import weights
+    from coma_amd.sd.unet import HipUNet2DConditionModel
+    st = weights.random_state(weights.unet_shapes(TINY_UNET), seed=0)
+    return HipUNet2DConditionModel(st, batch=batch, height=hw, width=hw, device=DEV, cfg=TINY_UNET, **kw)
+
+
+def test_recorded_plan_equals_python_launch_list(hip_lib):
+    g = torch.Generator().manual_seed(0)
+    ctx, x, t = torch.randn(2, 77, 768, generator=g), torch.randn(2, 9, 16, 16, generator=g), torch.tensor([961.0, 961.0])
+    eager = _unet(use_graph=False)
+    ref = eager(x, t, encoder_hidden_states=ctx)[0]
+    lib = _unet(use_graph=True)
+    out1 = lib(x, t, encoder_hidden_states=ctx)[0]                    # first replay: records, warms up, captures
+    out2 = lib(x, t, encoder_hidden_states=ctx)[0]                    # graph replay
+    assert lib.g.model.num_launches("step") >= len(lib.g.launches) and lib.g.model.num_launches("context") >= len(lib.gc.launches)
+    assert torch.equal(ref, out1) and torch.equal(ref, out2)
+    lib.g.run_recorded()                                              # the recorded list launched natively, no graph
+    torch.cuda.synchronize()
+    out3 = torch.empty_like(ref)
+    from coma_amd.sd import ops
+    ops.nhwc_to_nchw(lib.eps, out3, batch=2, c=4, hw=256, ld=64)
+    assert torch.equal(ref, out3)
+
+
+def test_c_program_runs_saved_unet_and_vae(tmp_path, c_runner, hip_lib):
+    from coma_amd.sd import weights
+    from coma_amd.sd.vae import HipVaeDecoder, HipVaeEncoder
+    g = torch.Generator().manual_seed(1)
+    # ---- UNet: batch 2 (one image, CFG), 16 x 16 latents
+    unet = _unet(cfg_shared_prefix=True)
+    ctx = torch.randn(2, 77, 768, generator=g).half()
+    x_in = torch.zeros(2, 256, 64, dtype=torch.float16)
+    x_in[0, :, :9] = torch.randn(256, 9, generator=g).half()
+    x_in[1] = x_in[0]                                                 # the shared CFG prefix wants identical halves
+    t = torch.tensor([961.0, 961.0])
+    unet.set_context(ctx.to(DEV))
+    unet.x_in.copy_(x_in.to(DEV))
+    unet.timesteps.copy_(t.to(DEV))
+    ref = unet.forward_static().cpu().numpy().copy()
+    unet.save(tmp_path / "unet.sdm")
+    for name, arr in (("ctx", ctx), ("x_in", x_in), ("t", t)):
+        arr.numpy().tofile(tmp_path / f"{name}.bin")
+    r = subprocess.run([c_runner, "unet", str(tmp_path / "unet.sdm"), str(tmp_path / "ctx.bin"), str(tmp_path / "x_in.bin"),
+                        str(tmp_path / "t.bin"), str(tmp_path / "eps.bin")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(tmp_path / "eps.bin", dtype=np.float16).reshape(ref.shape)
+    assert np.array_equal(got, ref) and np.isfinite(got.astype(np.float32)).all() and np.abs(got[:, :4]).max() > 0
+    del unet
+    # ---- VAE decoder / encoder at 64 x 64 pixels
+    vst = weights.random_state(weights.vae_shapes(TINY_VAE), seed=1)
+    dec = HipVaeDecoder(vst, 1, latent_h=8, latent_w=8, device=DEV, cfg=TINY_VAE)
+    z = torch.zeros(1, 64, 64, dtype=torch.float16)
+    z[..., :4] = torch.randn(1, 64, 4, generator=g).half()
+    dec.z.copy_(z.to(DEV))
+    img = dec.decode_static().cpu().numpy().copy()
+    dec.save(tmp_path / "dec.sdm")
+    z.numpy().tofile(tmp_path / "z.bin")
+    r = subprocess.run([c_runner, "decode", str(tmp_path / "dec.sdm"), str(tmp_path / "z.bin"), str(tmp_path / "img.bin")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "img.bin", dtype=np.float16).reshape(img.shape), img)
+    enc = HipVaeEncoder(vst, 1, height=64, width=64, device=DEV, cfg=TINY_VAE)
+    x = torch.zeros(1, 4096, 64, dtype=torch.float16)
+    x[..., :3] = (torch.rand(1, 4096, 3, generator=g) * 2 - 1).half()
+    enc.x.copy_(x.to(DEV))
+    mom = enc.encode_static().cpu().numpy().copy()
+    enc.save(tmp_path / "enc.sdm")
+    x.numpy().tofile(tmp_path / "x.bin")
+    r = subprocess.run([c_runner, "encode", str(tmp_path / "enc.sdm"), str(tmp_path / "x.bin"), str(tmp_path / "mom.bin")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(tmp_path / "mom.bin", dtype=np.float16).reshape(mom.shape), mom)
+
+
+def test_model_python_roundtrip_and_errors(tmp_path, hip_lib):
+    """sd_model_load from Python gives the same network; unknown plans / bindings and unregistered pointers are errors, not crashes."""
+    from coma_amd._lib import ComaHipError
+    from coma_amd.sd.model import SdModel
+    unet = _unet()
+    g = torch.Generator().manual_seed(2)
+    ctx, x, t = torch.randn(2, 77, 768, generator=g), torch.randn(2, 9, 16, 16, generator=g), torch.tensor([500.0, 500.0])
+    ref = unet(x, t, encoder_hidden_states=ctx)[0]
+    unet.save(tmp_path / "u.sdm")
+    m = SdModel.load(tmp_path / "u.sdm", DEV)
+    assert m.num_launches("step") == unet.g.model.num_launches("step") and m.num_launches("nope") == -1
+    eps = torch.empty_like(unet.eps)
+    m.unet_set_context(unet.ctx.clone())
+    m.unet_forward(unet.x_in.clone(), unet.timesteps.clone(), eps)
+    torch.cuda.synchronize()
+    assert torch.equal(eps, unet.eps)
+    with pytest.raises(ComaHipError):
+        m.replay("nope")
+    with pytest.raises(ComaHipError):
+        m.binding("nope")
+    with pytest.raises(ComaHipError):
+        SdModel.load(tmp_path / "missing.sdm", DEV)
+    bad = SdModel(DEV)
+    stray = torch.zeros(64, 320, dtype=torch.float16, device=DEV)
+    out = torch.zeros(64, 320, dtype=torch.float16, device=DEV)
+    gm, bt = torch.ones(320, dtype=torch.float16, device=DEV), torch.zeros(320, dtype=torch.float16, device=DEV)
+    import coma_amd.sd.model as mm
+    from coma_amd.sd import ops
+    bad.record("p", lambda: ops.layernorm(stray, gm, bt, out, rows=64, c=320))
+    assert bad.num_launches("p") == 1
+    bad.run("p")                                                      # runs from the caller's buffers
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0                              # LayerNorm of zeros with beta = 0
+    assert mm._recording is None
