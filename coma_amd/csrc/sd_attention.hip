@@ -605,6 +605,175 @@ __global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention_wide_kernel<DT> -- wide heads (d = 32 DT <= 512): the VAE mid-block attention (one head, d = 512, 4096 tokens).
+// Un-fused (r2) this was QK^T GEMM -> a 4096 x 4096 fp16 score matrix through HBM -> row softmax in place -> PV GEMM: 1.3 ms of
+// every decode / encode, i.e. of every mask re-estimation.  O^T of 512 x 32 queries is 256 accumulator registers on the 32x32
+// MFMA, so a wave owns 16 queries on v_mfma_f32_16x16x32_f16 instead:
+//     S^T[16 keys, 16 q] += K[keys, 32 dd] . Q[q, 32 dd]^T        A = K fragment (LDS), B = Q (64 registers, loaded once)
+//     O^T[16 dd, 16 q]  += V^T[dd, 32 keys] . P^T[32 keys, q]     A = V^T fragment (LDS), B = P straight from the S accumulators
+// The C layout puts query (lane & 15) in all 4 registers of a lane and keys 4 (lane >> 4) + i in register i, so the softmax
+// state is per lane (two cross-lane exchanges per tile for the maximum) and the P operand of a 32-key step is the lane's own
+// 8 values of two key blocks -- keys {4g + i, 16 + 4g + i}; V^T is stored in exactly that key order (SD_EPI_PERM32_N of the
+// projection GEMM), so its operand is ONE conflict-free 16-byte LDS read.  K and V^T tiles of 64 keys are 64 KB each: they live
+// in two single-buffered LDS regions and alternate -- the next K tile streams in (LDS-DMA) while P.V runs, the next V^T tile
+// while Q.K^T runs.  128 MFMAs (2048 cycles) against 16 exp2 per lane and tile: matrix-bound; every fragment feeds one MFMA,
+// so the LDS read port (128 B / clk / CU) is the practical limit.
+template <int DT>
+__global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
+  constexpr int D = 32 * DT;                       // head dim
+  constexpr int KROW = D;                          // halves per K row in LDS (16-byte chunks: D / 8, swizzled with the key index)
+  extern __shared__ __attribute__((aligned(1024))) _Float16 wide_smem[];
+  _Float16* Kbuf = wide_smem;                      // [64 keys][D]
+  _Float16* Vbuf = wide_smem + BKV * D;            // [D rows][64 keys]
+  typedef float float4v __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int n = lane & 15, g = lane >> 4;
+
+  // Q fragments (B operand): lane (query n, chunk g) holds dd = 32 j + 8 g .. + 7
+  half8 qf[DT];
+  {
+    const int qi = q0 + n;
+    const _Float16* qp = a.q + ((long long)b * a.lq + (qi < a.lq ? qi : 0)) * a.ldq + h * D;
+#pragma unroll
+    for (int j = 0; j < DT; ++j) {
+      if (qi < a.lq) {
+        qf[j] = *reinterpret_cast<const half8*>(qp + 32 * j + 8 * g);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[j][e] = (_Float16)0.0f;
+      }
+    }
+  }
+  float4v o[2 * DT];                               // O^T blocks of 16 head dims
+#pragma unroll
+  for (int db = 0; db < 2 * DT; ++db) o[db] = float4v{0.f, 0.f, 0.f, 0.f};
+  float m_run = -__builtin_inff(), l_run = 0.0f;
+
+  // ---- LDS-DMA: one instruction = 1 KiB.  K: D * 2 bytes per key row -> D / 512 instructions per key, chunk c of key r lands
+  // in slot c ^ (r & 15) of its 256-byte group (the 16 keys of a fragment read then hit 16 distinct bank groups).
+  // V^T: 8 rows of 128 bytes per instruction, swz64 as in the other kernels.
+  const _Float16* kbase = a.k + (long long)b * a.lk * a.ldk + h * D;
+  const _Float16* vbase = a.vt + ((long long)b * a.heads + h) * D * (long long)a.ldv;
+  auto make_rsrc = [](const void* p, unsigned bytes) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kbase, (unsigned)(((long long)(a.lk - 1) * a.ldk + D) * 2));
+  const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vbase, (unsigned)((long long)D * a.ldv * 2));
+  constexpr int KPI = D / 512 > 0 ? D / 512 : 1;   // K instructions per key row (D = 512: 1); smaller D: several rows per instruction
+  constexpr int K_INSTR = BKV * D * 2 / 1024 / 4;  // per wave and tile
+  constexpr int V_INSTR = D * 128 / 1024 / 4;
+  static_assert(D % 64 == 0 || D == 32, "row pitch");
+  const unsigned k_step = (unsigned)(BKV * a.ldk * 2), v_step = BKV * 2;
+  auto issue_k = [&](int tile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < K_INSTR; ++i) {
+      const int idx = wave * K_INSTR + i;          // 1 KiB piece of the tile
+      const int e16 = idx * 64 + lane;             // 16-byte element of the tile
+      const int row = e16 / (D / 8), slot = e16 % (D / 8);
+      const int chunk = (slot & ~15) | ((slot ^ row) & 15);
+      const unsigned off = (unsigned)(row * a.ldk * 2 + chunk * 16) + tile * k_step;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(Kbuf + idx * 512), 16, off, 0, 0, 0);
+    }
+#endif
+  };
+  auto issue_v = [&](int tile) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < V_INSTR; ++i) {
+      const int idx = wave * V_INSTR + i;
+      const int row = idx * 8 + (lane >> 3), slot = lane & 7;
+      const unsigned off = (unsigned)(row * a.ldv * 2 + swz64(row, slot) * 16) + tile * v_step;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(Vbuf + idx * 512), 16, off, 0, 0, 0);
+    }
+#endif
+  };
+  (void)KPI;
+
+  const int ntiles = a.lk / BKV;
+  issue_k(0);
+  issue_v(0);
+  for (int t = 0; t < ntiles; ++t) {
+    // K(t) was issued before V^T(t): all but the youngest V_INSTR pieces of this wave have landed
+    if (V_INSTR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- S^T = K Q^T, 4 key blocks of 16
+    float4v s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) s[kb] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < DT; ++j)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const int row = kb * 16 + n, c = 4 * j + g;
+        const half8 kf = *reinterpret_cast<const half8*>(&Kbuf[row * KROW + ((c & ~15) | ((c ^ row) & 15)) * 8]);
+        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[j], s[kb], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_barrier();                    // every wave is done with K(t)
+    if (t + 1 < ntiles) issue_k(t + 1);
+    // ---- online softmax: per lane 16 scores of query n (keys 16 kb + 4 g + i); the other 3 key quarters sit in lanes n + 16 g'
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+    for (int kb = 1; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(s[kb][0], s[kb][1]), fmaxf(s[kb][2], s[kb][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
+    if (mx > m_run) {                                // lane-divergent is fine: all state here is per lane
+      const float alpha = __builtin_amdgcn_exp2f(m_run - mx);    // 0 on the first tile
+      m_run = mx;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2 * DT; ++db) o[db] *= alpha;
+    }
+    half8 pf[2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], a.scale_log2, -m_run));
+        l_run += p;
+        pf[kb >> 1][(kb & 1) * 4 + i] = (_Float16)p;
+      }
+    // V^T(t) has landed (the K(t+1) pieces issued above may still be in flight)
+    if (t + 1 < ntiles && K_INSTR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- O^T += V^T P^T: 2 key steps of 32, 2 DT blocks of 16 head dims
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int db = 0; db < 2 * DT; ++db) {
+        const int row = db * 16 + n;
+        const half8 vf = *reinterpret_cast<const half8*>(&Vbuf[row * 64 + swz64(row, 4 * ks + g) * 8]);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ks], o[db], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_barrier();                    // every wave is done with V^T(t)
+    if (t + 1 < ntiles) issue_v(t + 1);
+  }
+  // ---- denominator over the 4 key quarters, normalise, store: lane (query n, quarter g) owns dd = 16 db + 4 g + i
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_run;
+  const int qi = q0 + n;
+  if (qi < a.lq) {
+    _Float16* op = a.out + ((long long)b * a.lq + qi) * a.ldo + h * D;
+#pragma unroll
+    for (int db = 0; db < 2 * DT; ++db) {
+      half4 v = {(_Float16)(o[db][0] * inv), (_Float16)(o[db][1] * inv), (_Float16)(o[db][2] * inv), (_Float16)(o[db][3] * inv)};
+      *reinterpret_cast<half4*>(op + db * 16 + 4 * g) = v;
+    }
+  }
+}
+
 }  // namespace sd
 
 using namespace sd;
@@ -664,4 +833,47 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   else SD_ATTN_LAUNCH(10, 5, 1, -1);
 #undef SD_ATTN_LAUNCH
   return check_launch("attention_kernel");
+}
+
+extern "C" int sd_attention_wide_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk, int d,
+                                     int ldq, int ldk, int ldv, int ldo, float scale, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_ATTN_WIDE;
+    r.p[0] = (void*)q; r.p[1] = (void*)k; r.p[2] = (void*)vt; r.p[3] = out;
+    const int64_t is[9] = {batch, heads, lq, lk, d, ldq, ldk, ldv, ldo};
+    for (int j = 0; j < 9; ++j) r.i[j] = is[j];
+    r.f[0] = scale;
+    return sd::plan_record(r);
+  }
+  if (!q || !k || !vt || !out) return fail(COMA_E_INVALID, "sd_attention_wide_f16: null pointer");
+  if (batch <= 0 || heads <= 0 || lq <= 0 || lk <= 0 || lk % BKV) return fail(COMA_E_INVALID, "sd_attention_wide_f16: bad sizes (lk must be a multiple of 64)");
+  if (d != 512 && d != 256 && d != 128) return fail(COMA_E_INVALID, "sd_attention_wide_f16: head dim %d unsupported (128, 256 or 512)", d);
+  if (ldq < heads * d || ldk < heads * d || ldo < heads * d || ldv < lk || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
+    return fail(COMA_E_INVALID, "sd_attention_wide_f16: bad leading dimensions");
+  if ((long long)lk * ldk * 2 >= 0x80000000LL || (long long)d * ldv * 2 >= 0x80000000LL)
+    return fail(COMA_E_INVALID, "sd_attention_wide_f16: K / V^T slice of one (batch, head) exceeds 2 GiB");
+  AttnArgs a;
+  a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.vt = (const _Float16*)vt; a.out = (_Float16*)out;
+  a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  const size_t lds = (size_t)2 * BKV * d * sizeof(_Float16);          // K tile + V^T tile
+  dim3 grid((unsigned)((lq + 63) / 64), (unsigned)heads, (unsigned)batch);
+  hipStream_t s = (hipStream_t)stream;
+#define SD_WIDE_LAUNCH(DT)                                                                                                    \
+  do {                                                                                                                        \
+    static bool attr_set = false;                                                                                             \
+    if (!attr_set) {                                                                                                          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_wide_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds) != hipSuccess)                                                                        \
+        return fail(COMA_E_LAUNCH, "sd_attention_wide_f16: cannot reserve %zu bytes of LDS", lds);                            \
+      attr_set = true;                                                                                                        \
+    }                                                                                                                         \
+    hipLaunchKernelGGL((attention_wide_kernel<DT>), grid, dim3(256), lds, s, a);                                              \
+  } while (0)
+  if (d == 512) SD_WIDE_LAUNCH(16);
+  else if (d == 256) SD_WIDE_LAUNCH(8);
+  else SD_WIDE_LAUNCH(4);
+#undef SD_WIDE_LAUNCH
+  return check_launch("attention_wide_kernel");
 }

@@ -101,6 +101,8 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 }
 
 __device__ __forceinline__ int kappa16(int j) { return (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1); }
+// SD_EPI_PERM32_N: position p = 8g + e of every group of 32 columns holds key 16 (e >> 2) + 4g + (e & 3)
+__device__ __forceinline__ int kappa32(int p) { return (p & ~28) | (((p >> 3) & 3) << 2) | (((p >> 2) & 1) << 4); }
 
 // Shared epilogue math: v = acc (folded LayerNorm)(+bias)(+per-batch bias) -> SiLU -> (+residual)
 __device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int row, int col, const _Float16* resp, const float* lnst) {
@@ -613,6 +615,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     const int r = (wave * B_LD + j) * RPI + l_row;
     int nn = n0 + r;
     if (g.epi & SD_EPI_PERM16_N) nn = kappa16(nn);   // output column j <- W row with bits 2, 3 of j swapped
+    if (g.epi & SD_EPI_PERM32_N) nn = kappa32(nn);   // ... or with bits 2, 3, 4 rotated (sd_attention_wide_f16's V^T operand)
     const int n = min(nn, g.n_valid - 1);
     b_off[j] = (unsigned)(n * g.K) * 2u + swz<BK>(r, l_slot) * 16;
   }
@@ -976,6 +979,10 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
     g.N = (d->n + 15) & ~15;            // whole 16-column groups: positions past n hold clamped (finite) rows the consumer masks
     if ((d->ldo > 0 ? d->ldo : d->n) < g.N) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: SD_EPI_PERM16_N needs ldo >= n rounded up to 16");
     if ((d->epi & SD_EPI_GEGLU) || d->res || d->bias_bn || d->colstats) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: SD_EPI_PERM16_N takes no GEGLU / residual / per-sample bias / colstats");
+  }
+  if (d->epi & SD_EPI_PERM32_N) {
+    if ((d->epi & (SD_EPI_PERM16_N | SD_EPI_GEGLU)) || d->n % 32 || d->res || d->bias_bn || d->colstats || d->ln_stats || d->rowstats)
+      return fail(COMA_E_INVALID, "sd_conv_gemm_f16: SD_EPI_PERM32_N needs n %% 32 == 0 and takes no other column-dependent epilogue");
   }
   g.w = (const _Float16*)d->w; g.bias = (const _Float16*)d->bias; g.bias_bn = (const _Float16*)d->bias_bn;
   g.res = (const _Float16*)d->res; g.ldr = d->ldr > 0 ? d->ldr : d->n;

@@ -102,6 +102,9 @@ static int launch(const PlanRec& r, void* st) {
       return sd_softmax_f16(p[0], i[0], (int)i[1], (int)i[2], (float)f[0], st);
     case PK_TEMB:
       return sd_timestep_embedding_f16((const float*)p[0], (int)i[0], (int)i[1], p[1], st);
+    case PK_ATTN_WIDE:
+      return sd_attention_wide_f16(p[0], p[1], p[2], p[3], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], (int)i[6], (int)i[7],
+                                   (int)i[8], (float)f[0], st);
     case PK_COPY:
       return sd_copy_d2d(p[0], p[1], (size_t)i[0], st);
     default:

@@ -13,6 +13,7 @@ from . import ops
 from .model import BUF_ZEROED, SdModel
 
 F16 = torch.float16
+_TORCH_GRAPH = __import__("os").environ.get("SD_TORCH_GRAPH") == "1"
 
 
 class LaunchGraph:
@@ -136,6 +137,12 @@ class LaunchGraph:
                  flops=4 * batch * heads * lq * lk * d, tag=f"attention B={batch} h={heads} lq={lq} lk={lk} d={d}")
         return out
 
+    def attention_wide(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
+        self.add(lambda: ops.attention_wide(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
+                                            scale=d ** -0.5),
+                 flops=4 * batch * heads * lq * lk * d, tag=f"attention(wide) B={batch} h={heads} lq={lq} lk={lk} d={d}")
+        return out
+
     # ---- execution
     def run(self):
         for fn in self.launches:
@@ -174,6 +181,18 @@ class LaunchGraph:
         self.model.run(self.plan)
 
     def replay(self):
+        if _TORCH_GRAPH:                          # A/B aid (SD_TORCH_GRAPH=1): torch.cuda.CUDAGraph over the Python closures
+            if getattr(self, "_tg", None) is None:
+                s = torch.cuda.Stream(self.device)
+                s.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(s):
+                    self.run()
+                torch.cuda.current_stream(self.device).wait_stream(s)
+                torch.cuda.synchronize(self.device)
+                self._tg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._tg):
+                    self.run()
+            return self._tg.replay()
         if not self._recorded:
             self.capture()
         self.model.replay(self.plan)

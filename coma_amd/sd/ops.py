@@ -8,7 +8,7 @@ import torch
 
 from .. import _lib
 
-EPI_NONE, EPI_GEGLU, EPI_SILU, EPI_BIAS_ROWS, EPI_PERM16_N = 0, 1, 2, 4, 8
+EPI_NONE, EPI_GEGLU, EPI_SILU, EPI_BIAS_ROWS, EPI_PERM16_N, EPI_PERM32_N = 0, 1, 2, 4, 8, 16
 F16 = torch.float16
 
 
@@ -118,6 +118,23 @@ def perm16_columns(x):
     j = torch.arange(n16, device=x.device)
     src = (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)
     return y[..., src].contiguous()
+
+
+def attention_wide(q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo, scale):
+    """Wide heads (d = 128 / 256 / 512), lk % 64 == 0, V^T in the EPI_PERM32_N key order (perm32_columns)."""
+    rc = _lib.lib().sd_attention_wide_f16(_p(q, "q"), _p(k, "k"), _p(vt, "vt"), _p(out, "out"), batch, heads, lq, lk, d, ldq, ldk, ldv, ldo,
+                                          scale, _stream(out))
+    _lib.check(rc, "sd_attention_wide_f16")
+    return out
+
+
+def perm32_columns(x):
+    """[..., n] (n % 32 == 0) -> the column order SD_EPI_PERM32_N produces: position 8g + e of every 32 holds column 16 (e >> 2) + 4g + (e & 3)."""
+    n = x.shape[-1]
+    assert n % 32 == 0
+    p = torch.arange(n, device=x.device)
+    src = (p & ~28) | (((p >> 3) & 3) << 2) | (((p >> 2) & 1) << 4)
+    return x[..., src].contiguous()
 
 
 def softmax_(x, *, rows, n, ld, scale):

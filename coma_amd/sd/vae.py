@@ -4,7 +4,7 @@ The reference pipeline uses exactly: ``vae.decode(z / scaling_factor, return_dic
 (utils/adaptive_mask_inpainting.py:1086, :1112), ``vae.encode(img).latent_dist.sample(generator)`` (:677-680) and
 ``vae.config.{scaling_factor, latent_channels, block_out_channels}`` (:371, :682, :927).  Architecture: public
 SD-1.5 VAE (diffusers is third party).  GroupNorm eps 1e-6, no time embedding, single-head
-attention over 4096 tokens at C = 512 in the mid block (un-fused here: it runs once per image, d = 512).
+attention over 4096 tokens at C = 512 in the mid block (sd_attention_wide_f16: 16 queries per wave on 16x16x32 MFMAs).
 """
 from __future__ import annotations
 
@@ -20,6 +20,8 @@ class _Cfg(dict):
 
 
 class _VaeBase:
+    fused_attention = True       # class-level switch (tests / A-B): False = QK^T GEMM -> softmax -> PV GEMM through memory
+
     def __init__(self, state, batch, device, cfg, use_graph=True, plan="decode"):
         self.use_graph = use_graph
         self.cfgd = cfg
@@ -50,7 +52,9 @@ class _VaeBase:
         return out
 
     def _attention(self, p, x, C, H, W):
-        """Single-head attention with q/k/v/out biases and a residual, un-fused: S = QK^T, row softmax, O = P V."""
+        """Single-head attention with q/k/v/out biases and a residual.  Fused (sd_attention_wide_f16) when the head is 128 / 256 /
+        512 wide and the token count a multiple of 64 -- the score matrix (4096 x 4096 per image at 512 x 512) never exists;
+        otherwise S = QK^T, row softmax, O = P V through memory."""
         g, s, B = self.g, self.s, self.batch
         L, M = H * W, B * H * W
         gn = g.buf(M, C)
@@ -58,14 +62,18 @@ class _VaeBase:
         q, k = g.buf(M, C), g.buf(M, C)
         g.conv(gn, s[p + ".to_q.weight"], q, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_q.bias"])
         g.conv(gn, s[p + ".to_k.weight"], k, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_k.bias"])
+        fused = self.fused_attention and C in (128, 256, 512) and L % 64 == 0
         vt = g.buf(B, C, L)                                  # V^T[b] = Wv . X_b^T + bv (bias per row)
         g.conv(s[p + ".to_v.weight"], gn, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, bias=s[p + ".to_v.bias"],
-               epi=ops.EPI_BIAS_ROWS, nbatch_z=B, stride_w=L * C, stride_out=C * L)
-        sc = g.buf(B, L, L)
-        g.conv(q, k, sc, batch=L, in_h=1, in_w=1, c0=C, n=L, nbatch_z=B, stride_a=L * C, stride_w=L * C, stride_out=L * L)
-        g.add(lambda: ops.softmax_(sc, rows=B * L, n=L, ld=L, scale=C ** -0.5), tag=f"softmax rows={B * L} n={L}")
+               epi=ops.EPI_BIAS_ROWS | (ops.EPI_PERM32_N if fused else 0), nbatch_z=B, stride_w=L * C, stride_out=C * L)
         a = g.buf(M, C)
-        g.conv(sc, vt, a, batch=L, in_h=1, in_w=1, c0=L, n=C, nbatch_z=B, stride_a=L * L, stride_w=C * L, stride_out=L * C)
+        if fused:
+            g.attention_wide(q, k, vt, a, batch=B, heads=1, lq=L, lk=L, d=C, ldq=C, ldk=C, ldv=L, ldo=C)
+        else:
+            sc = g.buf(B, L, L)
+            g.conv(q, k, sc, batch=L, in_h=1, in_w=1, c0=C, n=L, nbatch_z=B, stride_a=L * C, stride_w=L * C, stride_out=L * L)
+            g.add(lambda: ops.softmax_(sc, rows=B * L, n=L, ld=L, scale=C ** -0.5), tag=f"softmax rows={B * L} n={L}")
+            g.conv(sc, vt, a, batch=L, in_h=1, in_w=1, c0=L, n=C, nbatch_z=B, stride_a=L * L, stride_w=C * L, stride_out=L * C)
         out = g.buf(M, C)
         g.conv(a, s[p + ".to_out.0.weight"], out, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".to_out.0.bias"], res=x)   # (M tokens as batch: no stats)
         return out

@@ -32,6 +32,8 @@ extern "C" {
                                16 columns is stored in the order (0-3, 8-11, 4-7, 12-15): the V^T layout sd_attention_f16 reads with one
                                16-byte LDS load per MFMA operand (vt_perm16 = 1).  n is rounded up to 16 columns (ldo must cover them);
                                columns whose source row is >= n hold a clamped finite row */
+#define SD_EPI_PERM32_N 16  /* position p = 8g + e of every group of 32 output columns holds the product with W row 16 (e >> 2) + 4g + (e & 3):
+                               the V^T layout sd_attention_wide_f16 reads (one 16-byte LDS load per 16x16x32 MFMA operand).  n % 32 == 0 */
 /* bits 20..27 select kernel variants for tuning runs (scripts/time_gemm.py): 20 = generic 128x128 tiles only, 21 = 128x320
  * tile, 22 = tile DMA in one burst, 23 = 4-wave 128x320 tile, 24..27 = forced split-K factor, 28 = tap-major K order for 3x3.  Results agree to
  * fp32 summation order.  Process-wide overrides for A/B runs inside a captured graph (read once): SD_GEMM_TUNE / SD_GEMM_TUNE_1X1 / SD_GEMM_TUNE_3X3 =
@@ -125,6 +127,14 @@ int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* 
  * replaces: diffusers Attention (xformers / AttnProcessor2_0 scaled_dot_product_attention) in the UNet. */
 int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk,
                      int d, int ldq, int ldk, int ldv, int ldo, float scale, int vt_perm16, void* stream);
+
+/* Fused attention for WIDE heads (32 <= d <= 512, d a multiple of 32; the VAE mid-block: one head of 512 over 4096 tokens,
+ * diffusers AttentionBlock reached through self.vae.decode / self.vae.encode, utils/adaptive_mask_inpainting.py:1112, :677-680).
+ * Same tensors as sd_attention_f16, except: lk must be a multiple of 64 and V^T must be in the SD_EPI_PERM32_N key order
+ * (ldv >= lk).  A wave owns 16 queries on v_mfma_f32_16x16x32_f16 (O^T of 512 x 16 is 128 accumulator registers), K and V^T
+ * tiles of 64 keys alternate through two single-buffered 64 KB LDS regions.  out = softmax(q k^T * scale) v. */
+int sd_attention_wide_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk, int d,
+                          int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
 
 /* Row softmax in place over fp16 [rows, n] with scale (VAE mid-block attention, un-fused). */
 int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream);

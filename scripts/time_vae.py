@@ -4,7 +4,10 @@ import sys, os, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coma_amd.sd import weights
+from coma_amd.sd import vae as vae_mod
 from coma_amd.sd.vae import HipAutoencoderKL
+if "--unfused" in sys.argv:
+    vae_mod._VaeBase.fused_attention = False          # A/B: QK^T GEMM -> softmax -> PV GEMM through memory
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = "cuda:0"
 vae = HipAutoencoderKL(weights.random_state(weights.vae_shapes(), seed=1), batch=B, device=dev)

@@ -238,6 +238,30 @@ def test_attention_pipelined_rescale_and_low_scores(ops):
         close(out, so.attention_ref(q2, kk, v, heads, d**-0.5), tol=8e-3)
 
 
+@pytest.mark.parametrize("d,L,heads,B", [(512, 256, 1, 2), (512, 4096, 1, 1), (256, 128, 2, 1), (128, 192, 3, 2)])
+def test_attention_wide_heads(ops, d, L, heads, B):
+    """sd_attention_wide_f16 (the VAE mid-block: one head of 512 over 4096 tokens) vs torch fp32, V^T in the PERM32 key order."""
+    C = heads * d
+    q, k, v = rnd(B, L, C, seed=1, scale=0.5), rnd(B, L, C, seed=2, scale=0.5), rnd(B, L, C, seed=3)
+    if d == 512 and L == 256:
+        k[0, 200] = q[0, 3] * 3.0                                  # one dominant key in the last tile: the rescale path
+    vt = ops.perm32_columns(v.transpose(1, 2).contiguous()).to(DEV)
+    out = torch.empty(B, L, C, dtype=F16, device=DEV)
+    ops.attention_wide(q.to(DEV), k.to(DEV), vt, out, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=C, ldk=C, ldv=L, ldo=C, scale=d**-0.5)
+    close(out, so.attention_ref(q, k, v, heads, d**-0.5), tol=4e-3)
+
+
+def test_v_transposed_projection_in_the_perm32_layout(ops):
+    """SD_EPI_PERM32_N + SD_EPI_BIAS_ROWS: the VAE's V^T = Wv X^T + bv with the keys of every 32 in the wide kernel's operand order."""
+    B, L, C = 2, 128, 256
+    x, wv, bv = rnd(B, L, C, seed=1), rnd(C, C, seed=2, scale=C**-0.5), rnd(C, seed=3)
+    out = torch.zeros(B, C, L, dtype=F16, device=DEV)
+    ops.conv_gemm(wv.to(DEV), x.to(DEV), out, batch=C, in_h=1, in_w=1, c0=C, n=L, bias=bv.to(DEV), epi=ops.EPI_PERM32_N | ops.EPI_BIAS_ROWS,
+                  nbatch_z=B, stride_w=L * C, stride_out=C * L)
+    ref = ops.perm32_columns(torch.einsum("ck,blk->bcl", wv.float(), x.float()) + bv.float()[None, :, None])
+    close(out, ref)
+
+
 def test_attention_peaked_scores_force_the_rescale_path(ops):
     """One key dominates from the 3rd key tile on: exercises the online-softmax rescale with a large max jump."""
     B, heads, d, L = 1, 1, 64, 256
