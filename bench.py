@@ -152,7 +152,7 @@ def bench_inpaint(args, dev, world, rank):
                          "algorithmic_bytes": alg_bytes / len(gemm), "algorithmic_bytes_what": "per launch, mean over the launch list: every input "
                          "activation, weight, bias / residual tile read once + the output written once (fp16)",
                          "traffic": UNET_GEMM_PMC_TRAFFIC_BYTES if B == 8 else None,
-                         "traffic_source": "profiles/r02_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
+                         "traffic_source": "profiles/r03_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
                                            "the launches of eager UNet forwards at batch 16 (fabric-side requests of the 8 L2s: "
                                            "weights are pulled once per XCD and mostly hit the Infinity Cache)",
                          "unet_forward_ms_eager_sum": tot_ms,
@@ -372,14 +372,15 @@ def bench_occupancy(args, dev, world, rank):
 
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
-#   profiles/r02_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
+#   profiles/r03_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
 #   profiles/r02_contact_pmc.txt         FETCH_SIZE 1.91551e6 KiB, WRITE_SIZE 3.71066e6 KiB per contact_accumulate launch
-#   profiles/r02_inpaint_pmc.txt:20-25,391-396  occupancy at the config-5 share: fused WRITE 11.13 GB + 2 * FETCH 0.095 GB, rowprep 0.15 GB,
+#   profiles/r03_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.11 GB + 2 * FETCH 0.21 GB, rowprep 2 * 0.20 + 0.09 GB,
 #                                        groupmax 0.06 GB
-UNET_GEMM_PMC_TRAFFIC_BYTES = int(160.38e6)
-OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.53e9)
-OCCUPANCY_PMC_SOURCE = ("profiles/r02_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep + occupancy_fused + occupancy_groupmax "
-                        "at H=1310, R=128, S=2000 (the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM)")
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(160.26e6)
+OCCUPANCY_PMC_TRAFFIC_BYTES = int(12.09e9)
+OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.50 GB) + occupancy_fused (11.11 GB written, "
+                        "0.42 GB fetched) + occupancy_groupmax (0.06 GB) at H=1310, R=128, S=2000: the grid written once + the bucketed incidences; "
+                        "the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
 CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91551e6 + 3.71066e6) * 1024)
 
 
@@ -398,6 +399,8 @@ def main():
     ap.add_argument("--normal-res", type=int, default=250)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--skip", default="", help="comma-separated sections to leave out: occupancy, adaptive (profiling runs: rocprofv3 --pmc "
+                    "segfaults under hipGraph replay on this image, and the adaptive loop always replays graphs)")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph "
                     "(profiling aid: rocprofv3 --pmc segfaults under graph replay on this image)")
     ap.add_argument("--ddim-steps", type=int, default=50, help="only for profiling runs; the metric is defined at 50")
@@ -427,15 +430,18 @@ def main():
     inp = None if (args.workload == "contact" and args.no_secondary) else bench_inpaint(args, dev, world, rank)
     con = None if (args.workload == "inpaint" and args.no_secondary) else bench_contact(args, dev, world, rank)
     occ = ada = None
+    skip = set(filter(None, args.skip.split(",")))
     if not args.no_secondary:          # collective sections: every rank enters them, rank 0 gets the record
-        try:
-            occ = bench_occupancy(args, dev, world, rank)
-        except Exception as e:   # noqa: BLE001  (never lose the primary line; a failure is the same on every rank)
-            occ = {"error": repr(e)}
-        try:
-            ada = bench_adaptive(args, dev, world, rank)
-        except Exception as e:   # noqa: BLE001
-            ada = {"error": repr(e)}
+        if "occupancy" not in skip:
+            try:
+                occ = bench_occupancy(args, dev, world, rank)
+            except Exception as e:   # noqa: BLE001  (never lose the primary line; a failure is the same on every rank)
+                occ = {"error": repr(e)}
+        if "adaptive" not in skip:
+            try:
+                ada = bench_adaptive(args, dev, world, rank)
+            except Exception as e:   # noqa: BLE001
+                ada = {"error": repr(e)}
     if rank == 0:
         primary, secondary = (inp, con) if args.workload == "inpaint" else (con, inp)
         out = dict(primary)

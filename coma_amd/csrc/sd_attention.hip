@@ -816,7 +816,10 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
     return check_launch("attention_sp_kernel");
   }
   vt_perm16 &= 1;
-  const bool two = lq >= 1024 && d == 40;      // 64 queries per wave once there are enough blocks to fill the chip
+  // 64 queries per wave once there are enough blocks to fill the chip -- unless there are only a few key tiles (the 77-token cross
+  // attention): then a block is all prologue / epilogue latency and more resident blocks (QT = 1: ~100 registers) hide it better
+  static const int xqt1 = [] { const char* e = getenv("SD_ATTN_XQT1"); return e ? atoi(e) : 1; }();   // 38.5 -> 34.9 us at lq = 4096, lk = 77
+  const bool two = lq >= 1024 && d == 40 && !(xqt1 && lk <= 128);
   dim3 grid((unsigned)((lq + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)heads, (unsigned)batch);
 #define SD_ATTN_LAUNCH(KS, DVT, QT, ONES)                                                                       \
   do {                                                                                                          \

@@ -17,11 +17,12 @@ grep -E "^\{\"metric" $OUT/trace.log | tail -1 > $OUT/bench_line_under_profiler.
 rm -f $OUT/trace/*kernel_trace.csv
 # passes 2-4: counters, one group per pass (FETCH_SIZE uses 3 TCC slots, WRITE_SIZE 2); never mixed with trace domains
 # (counter passes run the launch list eagerly with 2 DDIM steps: rocprofv3 --pmc segfaults under hipGraph replay here)
-PCMD="$CMD --eager --ddim-steps 2 --steps 1 --warmup 0 --contact-steps 3"
+PCMD="$CMD --eager --skip adaptive --ddim-steps 2 --steps 1 --warmup 0 --contact-steps 3"
 rocprofv3 -f csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- $PCMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 -f csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- $PCMD > $OUT/pmc_write.log 2>&1
 rocprofv3 -f csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT -d $OUT/pmc_sq -o sq -- $PCMD > $OUT/pmc_sq.log 2>&1
 python $REPO/scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt
+for f in $OUT/pmc_*.log; do tail -3 $f | cut -c1-200; done
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/*.log
 head -12 $OUT/trace/trace_kernel_stats.csv | cut -c1-160
 grep -E "sd::|coma::|_ZN2sd" $OUT/pmc_summary.txt | head -60
