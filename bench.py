@@ -250,7 +250,7 @@ def bench_contact(args, dev, world, rank):
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                      "kernel_ms": kern_ms, "flop_per_pair": flop_per_pair(N), "algorithmic_hbm_bytes": alg_bytes,
                      "traffic": CONTACT_PMC_TRAFFIC_BYTES if (S, H, O, N) == (64, 10475, 180, 250) else None,
-                     "traffic_source": "profiles/r02_contact_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
+                     "traffic_source": "profiles/r03_inpaint_pmc.txt (contact_accumulate_kernel): (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
     }
 
 
@@ -373,7 +373,7 @@ def bench_occupancy(args, dev, world, rank):
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
 #   profiles/r03_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
-#   profiles/r02_contact_pmc.txt         FETCH_SIZE 1.91551e6 KiB, WRITE_SIZE 3.71066e6 KiB per contact_accumulate launch
+#   profiles/r03_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91548e6 KiB, WRITE_SIZE 3.71222e6 KiB per launch
 #   profiles/r03_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.11 GB + 2 * FETCH 0.21 GB, rowprep 2 * 0.20 + 0.09 GB,
 #                                        groupmax 0.06 GB
 UNET_GEMM_PMC_TRAFFIC_BYTES = int(160.26e6)
@@ -381,7 +381,7 @@ OCCUPANCY_PMC_TRAFFIC_BYTES = int(12.09e9)
 OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.50 GB) + occupancy_fused (11.11 GB written, "
                         "0.42 GB fetched) + occupancy_groupmax (0.06 GB) at H=1310, R=128, S=2000: the grid written once + the bucketed incidences; "
                         "the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
-CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91551e6 + 3.71066e6) * 1024)
+CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91548e6 + 3.71222e6) * 1024)
 
 
 def main():
