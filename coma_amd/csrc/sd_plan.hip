@@ -105,6 +105,9 @@ static int launch(const PlanRec& r, void* st) {
     case PK_ATTN_WIDE:
       return sd_attention_wide_f16(p[0], p[1], p[2], p[3], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], (int)i[6], (int)i[7],
                                    (int)i[8], (float)f[0], st);
+    case PK_XCHAIN:
+      return sd_xattn_chain_f16(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], i[0], (int)i[1],
+                                (int)i[2], (int)i[3], (float)f[0], nullptr, 0, st);
     case PK_COPY:
       return sd_copy_d2d(p[0], p[1], (size_t)i[0], st);
     default:

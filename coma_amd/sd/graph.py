@@ -137,6 +137,13 @@ class LaunchGraph:
                  flops=4 * batch * heads * lq * lk * d, tag=f"attention B={batch} h={heads} lq={lq} lk={lk} d={d}")
         return out
 
+    def xattn_chain(self, a, h, wo1, bo1, g2, b2, wq, k2, vt2, wo2, bo2, g3, b3, h2, n3, *, rows, rows_per_sample, lk, ldv2):
+        c = 320
+        self.add(lambda: ops.xattn_chain(a, h, wo1, bo1, g2, b2, wq, k2, vt2, wo2, bo2, g3, b3, h2, n3, rows=rows, rows_per_sample=rows_per_sample,
+                                         lk=lk, ldv2=ldv2),
+                 flops=3 * 2 * rows * c * c + 4 * rows * lk * c, tag=f"xchain rows={rows} C={c} lk={lk}", nbytes=2 * (4 * rows * c + 3 * c * c))
+        return h2, n3
+
     def attention_wide(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
         self.add(lambda: ops.attention_wide(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
                                             scale=d ** -0.5),

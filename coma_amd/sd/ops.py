@@ -137,6 +137,16 @@ def perm32_columns(x):
     return x[..., src].contiguous()
 
 
+def xattn_chain(a, h, wo1, bo1, g2, b2, wq, k2, vt2, wo2, bo2, g3, b3, h2, n3, *, rows, rows_per_sample, lk, ldv2, eps=1e-5, debug_out=None,
+                debug_stage=0):
+    """attn1.to_out + residual -> LayerNorm2 -> attn2 (to_q, 77-key cross attention, to_out + residual) -> LayerNorm3 in one launch
+    (C = 320, 8 heads of 40); see sd_xattn_chain_f16 in include/sd_hip.h."""
+    args = [_p(t, n) for t, n in ((a, "attn1_out"), (h, "h"), (wo1, "wo1"), (bo1, "bo1"), (g2, "gamma2"), (b2, "beta2"), (wq, "wq2"), (k2, "k2"),
+                                  (vt2, "vt2"), (wo2, "wo2"), (bo2, "bo2"), (g3, "gamma3"), (b3, "beta3"), (h2, "h2"), (n3, "n3"))]
+    rc = _lib.lib().sd_xattn_chain_f16(*args, rows, rows_per_sample, lk, ldv2, eps, _p(debug_out, "debug_out"), debug_stage, _stream(h2))
+    _lib.check(rc, "sd_xattn_chain_f16")
+
+
 def softmax_(x, *, rows, n, ld, scale):
     _lib.check(_lib.lib().sd_softmax_f16(_p(x), rows, n, ld, scale, _stream(x)), "sd_softmax_f16")
     return x

@@ -32,7 +32,7 @@ class _Cfg(dict):
 
 class HipUNet2DConditionModel:
     def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
-                 cfg_shared_prefix=False, fold_layernorm=False):
+                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True):
         """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
         (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
         Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
@@ -45,6 +45,7 @@ class HipUNet2DConditionModel:
         self.ctx_dim = cfg["cross_attention_dim"]
         self.use_graph = use_graph
         self.fold_layernorm = fold_layernorm
+        self.fuse_xchain = fuse_xchain      # C = 320 blocks: attn1.to_out ... norm3 in one launch (sd_xattn_chain_f16)
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
@@ -192,40 +193,64 @@ class HipUNet2DConditionModel:
                    epi=ops.EPI_PERM16_N)
         a = g.buf(M, C)
         g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C, vt_perm16=True)
-        h1 = g.buf(M, C)
-        g.conv(a, s[t + ".attn1.to_out.0.weight"], h1, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[t + ".attn1.to_out.0.bias"],
-               res=h, rowstats=fold)
-        if B != self.batch:
-            # end of the shared CFG prefix: from the first cross-attention on the two halves differ
-            B = self._B = self.batch
-            M = B * L
-            h1 = g.dup(h1, g.buf(M, C))
-            x = g.dup(x, g.buf(M, C))
-        # ---- cross attention (K, V^T of the context live in the per-prompt graph)
-        q2 = g.buf(M, C)
-        if fold:
-            wq2_f, sq2, tq2 = ln_fold(s[t + ".attn2.to_q.weight"], s[t + ".norm2.weight"], s[t + ".norm2.bias"])
-            g.conv(h1, wq2_f, q2, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=tq2, ln_stats=g.ln_stats(h1, rows=M, c=C), ln_colsum=sq2)
-        else:
-            n2 = g.buf(M, C)
-            g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)
-            g.conv(n2, s[t + ".attn2.to_q.weight"], q2, batch=M, in_h=1, in_w=1, c0=C, n=C)
         Lk, cd = self.ctx_len, self.ctx_dim
-        k2 = self.gc.buf(B * Lk, C)
-        self.gc.conv(self.ctx, s[t + ".attn2.to_k.weight"], k2, batch=B * Lk, in_h=1, in_w=1, c0=cd, n=C)
         ldv2 = (Lk + 15) // 16 * 16
-        vt2 = self.gc.buf(B, C, ldv2, zero=True)
-        self.gc.conv(s[t + ".attn2.to_v.weight"], self.ctx, vt2, batch=C, in_h=1, in_w=1, c0=cd, n=Lk, ldo=ldv2, nbatch_z=B,
-                     stride_w=Lk * cd, stride_out=C * ldv2, epi=ops.EPI_PERM16_N)
-        a2 = g.buf(M, C)
-        g.attention(q2, k2, vt2, a2, batch=B, heads=heads, lq=L, lk=Lk, d=d, ldq=C, ldk=C, ldv=ldv2, ldo=C, vt_perm16=True)
-        h2 = g.buf(M, C)
-        g.conv(a2, s[t + ".attn2.to_out.0.weight"], h2, batch=M, in_h=1, in_w=1, c0=C, n=C,
-               bias=s[t + ".attn2.to_out.0.bias"], res=h1, rowstats=fold)
+        xchain = self.fuse_xchain and not fold and C == 320 and L % 64 == 0 and Lk <= 96
+
+        def context_kv(Bf):
+            """K / V^T of the text context for this block (per-prompt graph)."""
+            k2 = self.gc.buf(Bf * Lk, C)
+            self.gc.conv(self.ctx, s[t + ".attn2.to_k.weight"], k2, batch=Bf * Lk, in_h=1, in_w=1, c0=cd, n=C)
+            vt2 = self.gc.buf(Bf, C, ldv2, zero=True)
+            self.gc.conv(s[t + ".attn2.to_v.weight"], self.ctx, vt2, batch=C, in_h=1, in_w=1, c0=cd, n=Lk, ldo=ldv2, nbatch_z=Bf,
+                         stride_w=Lk * cd, stride_out=C * ldv2, epi=ops.EPI_PERM16_N)
+            return k2, vt2
+
+        if xchain:
+            # everything between the self-attention output and the feed-forward is local to a token row: one launch
+            if B != self.batch:
+                # end of the shared CFG prefix: the two halves meet different text contexts from here on
+                B = self._B = self.batch
+                M = B * L
+                a = g.dup(a, g.buf(M, C))
+                h = g.dup(h, g.buf(M, C))
+                x = g.dup(x, g.buf(M, C))
+            k2, vt2 = context_kv(B)
+            h2, n3 = g.buf(M, C), g.buf(M, C)
+            g.xattn_chain(a, h, s[t + ".attn1.to_out.0.weight"], s[t + ".attn1.to_out.0.bias"], s[t + ".norm2.weight"], s[t + ".norm2.bias"],
+                          s[t + ".attn2.to_q.weight"], k2, vt2, s[t + ".attn2.to_out.0.weight"], s[t + ".attn2.to_out.0.bias"],
+                          s[t + ".norm3.weight"], s[t + ".norm3.bias"], h2, n3, rows=M, rows_per_sample=L, lk=Lk, ldv2=ldv2)
+        else:
+            h1 = g.buf(M, C)
+            g.conv(a, s[t + ".attn1.to_out.0.weight"], h1, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[t + ".attn1.to_out.0.bias"],
+                   res=h, rowstats=fold)
+            if B != self.batch:
+                # end of the shared CFG prefix: from the first cross-attention on the two halves differ
+                B = self._B = self.batch
+                M = B * L
+                h1 = g.dup(h1, g.buf(M, C))
+                x = g.dup(x, g.buf(M, C))
+            # ---- cross attention (K, V^T of the context live in the per-prompt graph)
+            q2 = g.buf(M, C)
+            if fold:
+                wq2_f, sq2, tq2 = ln_fold(s[t + ".attn2.to_q.weight"], s[t + ".norm2.weight"], s[t + ".norm2.bias"])
+                g.conv(h1, wq2_f, q2, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=tq2, ln_stats=g.ln_stats(h1, rows=M, c=C), ln_colsum=sq2)
+            else:
+                n2 = g.buf(M, C)
+                g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)
+                g.conv(n2, s[t + ".attn2.to_q.weight"], q2, batch=M, in_h=1, in_w=1, c0=C, n=C)
+            k2, vt2 = context_kv(B)
+            a2 = g.buf(M, C)
+            g.attention(q2, k2, vt2, a2, batch=B, heads=heads, lq=L, lk=Lk, d=d, ldq=C, ldk=C, ldv=ldv2, ldo=C, vt_perm16=True)
+            h2 = g.buf(M, C)
+            g.conv(a2, s[t + ".attn2.to_out.0.weight"], h2, batch=M, in_h=1, in_w=1, c0=C, n=C,
+                   bias=s[t + ".attn2.to_out.0.bias"], res=h1, rowstats=fold)
         # ---- feed-forward (GEGLU)
         wff, bff = geglu_interleave(s[t + ".ff.net.0.proj.weight"], s[t + ".ff.net.0.proj.bias"])
         f = g.buf(M, 4 * C)
-        if fold:
+        if xchain:
+            g.conv(n3, wff, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=bff, epi=ops.EPI_GEGLU)
+        elif fold:
             wff_f, sff, tff = ln_fold(wff, s[t + ".norm3.weight"], s[t + ".norm3.bias"], bff)
             g.conv(h2, wff_f, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=tff, epi=ops.EPI_GEGLU, ln_stats=g.ln_stats(h2, rows=M, c=C),
                    ln_colsum=sff)

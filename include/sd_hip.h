@@ -136,6 +136,22 @@ int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, in
 int sd_attention_wide_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk, int d,
                           int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
 
+/* The row-local middle of a BasicTransformerBlock at C = 320 (8 heads of 40) in ONE launch:
+ *   h1 = attn1_out Wo1^T + bo1 + h;  n2 = LayerNorm(h1; gamma2, beta2);  q2 = n2 Wq2^T;
+ *   a2 = softmax(q2 K2^T / sqrt(40)) V2 per head over the lk <= 96 text tokens;  h2 = a2 Wo2^T + bo2 + h1;  n3 = LayerNorm(h2; gamma3, beta3)
+ * attn1_out, h: fp16 [rows, 320];  weights fp16 [320, 320] (nn.Linear layout);  k2 fp16 [rows / rows_per_sample, lk, 320];
+ * vt2 fp16 [samples, 320, ldv2] = V2 transposed, keys in the SD_EPI_PERM16_N order (ldv2 >= 80, pad columns finite);
+ * outputs h2, n3: fp16 [rows, 320] (h2 is also used as scratch for h1).  rows_per_sample a multiple of 64.
+ * debug_out / debug_stage (tests): when debug_out != NULL the kernel stops after stage 1 (h1), 2 (n2), 3 (q2) or 4 (a2) and
+ * writes that [rows, 320] tensor there.
+ * replaces: attn1.to_out.0 + residual, norm2, attn2 (to_q, attention, to_out.0 + residual), norm3 of diffusers'
+ *           BasicTransformerBlock inside self.unet(...), utils/adaptive_mask_inpainting.py:1001-1007 -- six launches of the
+ *           unfused graph (sd_conv_gemm_f16 x3, sd_layernorm_f16 x2, sd_attention_f16). */
+int sd_xattn_chain_f16(const void* attn1_out, const void* h, const void* wo1, const void* bo1, const void* gamma2, const void* beta2,
+                       const void* wq2, const void* k2, const void* vt2, const void* wo2, const void* bo2, const void* gamma3,
+                       const void* beta3, void* h2, void* n3, int64_t rows, int rows_per_sample, int lk, int ldv2, float eps,
+                       void* debug_out, int debug_stage, void* stream);
+
 /* Row softmax in place over fp16 [rows, n] with scale (VAE mid-block attention, un-fused). */
 int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream);
 

@@ -262,6 +262,37 @@ def test_v_transposed_projection_in_the_perm32_layout(ops):
     close(out, ref)
 
 
+def test_xattn_chain_matches_the_unfused_chain_stage_by_stage(ops):
+    """sd_xattn_chain_f16 (attn1.to_out + residual -> LayerNorm2 -> to_q -> 77-key cross attention -> to_out + residual -> LayerNorm3 in one
+    launch) against torch fp32, every intermediate through the kernel's debug stages, then the two outputs."""
+    import torch.nn.functional as F
+    B, RPS, C, LK, heads = 2, 256, 320, 77, 8
+    M = B * RPS
+    a, h = rnd(M, C, seed=1), rnd(M, C, seed=2)
+    wo1, wq, wo2 = (rnd(C, C, seed=10 + i, scale=C**-0.5) for i in range(3))
+    bo1, bo2 = rnd(C, seed=20, scale=0.1), rnd(C, seed=21, scale=0.1)
+    g2, b2, g3, b3 = (1 + rnd(C, seed=30, scale=0.1)), rnd(C, seed=31, scale=0.1), (1 + rnd(C, seed=32, scale=0.1)), rnd(C, seed=33, scale=0.1)
+    k2, v2 = rnd(B, LK, C, seed=40), rnd(B, LK, C, seed=41)
+    vt2 = ops.perm16_columns(v2.transpose(1, 2).contiguous())                      # [B, C, 80]
+    f = lambda t: t.float()
+    h1 = (f(a) @ f(wo1).t() + f(bo1) + f(h)).half()                                  # the kernel keeps the residual stream in fp16, as the graph does
+    n2 = F.layer_norm(f(h1), (C,), f(g2), f(b2), 1e-5).half()
+    q2 = (f(n2) @ f(wq).t()).half()
+    a2 = so.attention_ref(q2.reshape(B, RPS, C), k2, v2, heads, 40**-0.5).reshape(M, C).half()
+    h2 = (f(a2) @ f(wo2).t() + f(bo2) + f(h1)).half()
+    n3 = F.layer_norm(f(h2), (C,), f(g3), f(b3), 1e-5)
+    dv = lambda t: t.to(DEV).contiguous()
+    args = [dv(t) for t in (a, h, wo1, bo1, g2, b2, wq, k2.reshape(B * LK, C), vt2, wo2, bo2, g3, b3)]
+    for stage, ref in ((1, h1), (2, n2), (3, q2), (4, a2)):
+        o_h2, o_n3, dbg = (torch.zeros(M, C, dtype=F16, device=DEV) for _ in range(3))
+        ops.xattn_chain(*args, o_h2, o_n3, rows=M, rows_per_sample=RPS, lk=LK, ldv2=vt2.shape[-1], debug_out=dbg, debug_stage=stage)
+        close(dbg, ref, tol=4e-3)
+    o_h2, o_n3 = torch.zeros(M, C, dtype=F16, device=DEV), torch.zeros(M, C, dtype=F16, device=DEV)
+    ops.xattn_chain(*args, o_h2, o_n3, rows=M, rows_per_sample=RPS, lk=LK, ldv2=vt2.shape[-1])
+    close(o_h2, h2, tol=4e-3)
+    close(o_n3, n3, tol=4e-3)
+
+
 def test_attention_peaked_scores_force_the_rescale_path(ops):
     """One key dominates from the 3rd key tile on: exercises the online-softmax rescale with a large max jump."""
     B, heads, d, L = 1, 1, 64, 256
