@@ -49,6 +49,7 @@ struct AttnArgs {
   int heads, lq, lk, d;
   int ldq, ldk, ldv, ldo;
   float scale_log2;   // scale * log2(e)
+  int no_spec;        // attention_sp_kernel: track the maximum on every key tile from the start (A/B aid, SD_ATTN_SPEC=0)
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -428,9 +429,6 @@ __global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
   }
 
   const int ntiles = a.lk / BKV;
-  issue_k(0, 0);
-  issue_v(0, 0);
-  if (ntiles > 1) issue_k(1, 1);
 
   // ---- per-lane LDS offsets (halves): row ql, chunk (2ks + hh) / (2st + hh), swizzled; stages and the 32-row tile add immediates
   int k_lane[3], v_lane[4];
@@ -451,8 +449,9 @@ __global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
     return g < 6 ? *reinterpret_cast<const half8*>(&Ks[(g & 1) * 32 * 64 + k_lane[g >> 1]])
                  : *reinterpret_cast<const half8*>(&Vs[((g - 6) & 1) * 32 * 64 + v_lane[(g - 6) >> 1]]);
   };
-  auto segment = [&](auto hvc, const _Float16* Ks, const _Float16* Vs) {
+  auto segment = [&](auto hvc, const _Float16* Ks, const _Float16* Vs, auto maxc) {
     constexpr int HV = decltype(hvc)::value, HM = 1 - HV;       // VALU half, matrix half
+    constexpr bool MAXON = decltype(maxc)::value;               // take the maximum of the S' tile this segment produces
     constexpr int NE = 32 * HQ;                                  // exp2 per segment
     half8 fr[3];                                                 // fragments are fetched two slots ahead
     fr[0] = frag(0, Ks, Vs);
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
         pf[sq][t * 2 + (r >> 3)][r & 7] = (_Float16)s[sq][t][r];
         pf[sq][t * 2 + (r >> 3)][(r & 7) + 1] = (_Float16)s[sq][t][r + 1];
       }
-      if constexpr (G >= 8) {                       // 16 HQ max3 over the fresh S' of the matrix half, 6 slots
+      if constexpr (G >= 8 && MAXON) {              // 16 HQ max3 over the fresh S' of the matrix half, 6 slots
         constexpr int M0 = (G - 8) * 16 * HQ / 6, M1 = (G - 7) * 16 * HQ / 6;
 #pragma unroll
         for (int mi = M0; mi < M1; ++mi) {
@@ -501,11 +500,13 @@ __global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
     for (int j = 0; j < HQ; ++j)
 #pragma unroll
       for (int st = 0; st < 4; ++st) asm volatile("" : "+v"(pf[HV * HQ + j][st]));
+    if constexpr (MAXON) {
 #pragma unroll
-    for (int j = 0; j < HQ; ++j) {                  // the partner lane holds the other 32 keys of the query
-      const int sq = HM * HQ + j;
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxs[sq]), __float_as_uint(mxs[sq]), false, false);
-      mxs[sq] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      for (int j = 0; j < HQ; ++j) {                // the partner lane holds the other 32 keys of the query
+        const int sq = HM * HQ + j;
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxs[sq]), __float_as_uint(mxs[sq]), false, false);
+        mxs[sq] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
     }
   };
   // running maximum: the accumulators already hold score - m.  m only moves when a score exceeds it by more than 2^6 (or on
@@ -529,57 +530,96 @@ __global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
     }
   };
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // S'_A(0) and its maximum, outside the pipeline
+  // One pass over all key tiles.  FULL = false (first attempt): the running maximum is set from key tile 0 and then left alone --
+  // no max3 / lane exchange / rescale test on the other 63 tiles (34 of ~165 VALU instructions per tile in a VALU-bound kernel).
+  // That is exact unless a later score exceeds tile 0's maximum by 2^16 and the fp16 weight overflows; then the denominator comes
+  // out non-finite, the workgroup notices (below) and repeats the pass with FULL = true: maximum tracked on every tile.
+  auto run_pass = [&](auto fullc) {
+    constexpr bool FULL = decltype(fullc)::value;
+    issue_k(0, 0);
+    issue_v(0, 0);
+    if (ntiles > 1) issue_k(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // S'_A(0) and its maximum, outside the pipeline
 #pragma unroll
-  for (int ks = 0; ks < 3; ++ks)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const half8 kf = *reinterpret_cast<const half8*>(&Kbuf[0][t * 32 * 64 + k_lane[ks]]);
-#pragma unroll
-      for (int j = 0; j < HQ; ++j) s[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j][ks], ks == 0 ? zero16 : s[j][t], 0, 0, 0);
-    }
-#pragma unroll
-  for (int j = 0; j < HQ; ++j) {
-    float mx = fmaxf(s[j][0][0], s[j][1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[j][0][r]), s[j][1][r]);
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-    mxs[j] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-  }
-  auto tile_body = [&](int t, auto s0c) {           // K(t), V^T(t) live in stage S0 = t % 3
-    constexpr int S0 = decltype(s0c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of K(t+1), V^T(t) (issued one tile ago) have landed
-    __builtin_amdgcn_s_barrier();                     // ... everyone's; and every wave is done with K(t-1), V^T(t-2)
-    if (t + 2 < ntiles) issue_k(S2, t + 2);
-    if (t + 1 < ntiles) issue_v(S1, t + 1);
-    maxfix(0, t == 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // segment 1: softmax A(t)  ||  S'_B(t) = K(t) Q_B^T, O_B += V(t-1)^T P_B(t-1)   (t = 0: P_B = 0 and the stage is zero-filled)
-    segment(std::integral_constant<int, 0>{}, Kbuf[S0], Vbuf[S2]);
-    maxfix(1, t == 0);
-    __builtin_amdgcn_sched_barrier(0);
-    // segment 2: softmax B(t)  ||  S'_A(t+1) = K(t+1) Q_A^T, O_A += V(t)^T P_A(t)    (after the last tile S'_A is never used)
-    segment(std::integral_constant<int, 1>{}, Kbuf[S1], Vbuf[S0]);
-  };
-  for (int t = 0; t < ntiles; t += 3) {
-    tile_body(t, std::integral_constant<int, 0>{});
-    if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 1>{});
-    if (t + 2 < ntiles) tile_body(t + 2, std::integral_constant<int, 2>{});
-  }
-  // O_B of the last tile
-  {
-    const int ls = (ntiles - 1) % 3;
-    const _Float16* Vs = ls == 0 ? Vbuf[0] : ls == 1 ? Vbuf[1] : Vbuf[2];
-#pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const half8 vf = *reinterpret_cast<const half8*>(&Vs[t * 32 * 64 + v_lane[st]]);
+        const half8 kf = *reinterpret_cast<const half8*>(&Kbuf[0][t * 32 * 64 + k_lane[ks]]);
 #pragma unroll
-        for (int j = 0; j < HQ; ++j) o[HQ + j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[HQ + j][st], o[HQ + j][t], 0, 0, 0);
+        for (int j = 0; j < HQ; ++j) s[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j][ks], ks == 0 ? zero16 : s[j][t], 0, 0, 0);
       }
+#pragma unroll
+    for (int j = 0; j < HQ; ++j) {
+      float mx = fmaxf(s[j][0][0], s[j][1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[j][0][r]), s[j][1][r]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mxs[j] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    auto tile_body = [&](int t, auto s0c, auto firstc) {   // K(t), V^T(t) live in stage S0 = t % 3
+      constexpr int S0 = decltype(s0c)::value, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;
+      constexpr bool FIRST = decltype(firstc)::value;      // tile 0: the maximum of both halves is always taken
+      constexpr bool MAXA = FULL;                           // S'_A(t+1), produced in segment 2
+      constexpr bool MAXB = FULL || FIRST;                  // S'_B(t), produced in segment 1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of K(t+1), V^T(t) (issued one tile ago) have landed
+      __builtin_amdgcn_s_barrier();                     // ... everyone's; and every wave is done with K(t-1), V^T(t-2)
+      if (t + 2 < ntiles) issue_k(S2, t + 2);
+      if (t + 1 < ntiles) issue_v(S1, t + 1);
+      if constexpr (FULL || FIRST) maxfix(0, FIRST);
+      __builtin_amdgcn_sched_barrier(0);
+      // segment 1: softmax A(t)  ||  S'_B(t) = K(t) Q_B^T, O_B += V(t-1)^T P_B(t-1)   (t = 0: P_B = 0 and the stage holds finite data)
+      segment(std::integral_constant<int, 0>{}, Kbuf[S0], Vbuf[S2], std::integral_constant<bool, MAXB>{});
+      if constexpr (FULL || FIRST) maxfix(1, FIRST);
+      __builtin_amdgcn_sched_barrier(0);
+      // segment 2: softmax B(t)  ||  S'_A(t+1) = K(t+1) Q_A^T, O_A += V(t)^T P_A(t)    (after the last tile S'_A is never used)
+      segment(std::integral_constant<int, 1>{}, Kbuf[S1], Vbuf[S0], std::integral_constant<bool, MAXA>{});
+    };
+    tile_body(0, std::integral_constant<int, 0>{}, std::true_type{});
+    for (int t = 1; t < ntiles; t += 3) {
+      tile_body(t, std::integral_constant<int, 1>{}, std::false_type{});
+      if (t + 1 < ntiles) tile_body(t + 1, std::integral_constant<int, 2>{}, std::false_type{});
+      if (t + 2 < ntiles) tile_body(t + 2, std::integral_constant<int, 0>{}, std::false_type{});
+    }
+    // O_B of the last tile
+    {
+      const int ls = (ntiles - 1) % 3;
+      const _Float16* Vs = ls == 0 ? Vbuf[0] : ls == 1 ? Vbuf[1] : Vbuf[2];
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half8 vf = *reinterpret_cast<const half8*>(&Vs[t * 32 * 64 + v_lane[st]]);
+#pragma unroll
+          for (int j = 0; j < HQ; ++j) o[HQ + j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[HQ + j][st], o[HQ + j][t], 0, 0, 0);
+        }
+    }
+  };
+  if (a.no_spec) {
+    run_pass(std::true_type{});
+  } else {
+    run_pass(std::false_type{});
+    bool bad = false;
+#pragma unroll
+    for (int sq = 0; sq < NQ; ++sq) bad |= !(o[sq][1][4] < 3.0e38f);       // inf / NaN denominator (row 40 of O^T; every lane checks its own)
+    if (__syncthreads_or(bad ? 1 : 0)) {
+      // a weight overflowed fp16 somewhere in this workgroup: start over with the maximum tracked on every tile
+#pragma unroll
+      for (int sq = 0; sq < NQ; ++sq) {
+        m_run[sq] = 0.0f;
+        if (hh) qf[sq][2][0] = (_Float16)0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o[sq][t][r] = 0.0f; s[sq][t][r] = 0.0f; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[sq][st][j] = (_Float16)0.0f;
+      }
+      run_pass(std::true_type{});
+    }
   }
 
   // ---- normalise by the ones row (row 40 = register 4 of the second 32-row tile, hh = 0 lane) and store
@@ -801,18 +841,19 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.vt = (const _Float16*)vt; a.out = (_Float16*)out;
   a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.scale_log2 = scale * 1.4426950408889634f;
+  static const int spec_env = [] { const char* e = getenv("SD_ATTN_SPEC"); return e ? atoi(e) : 1; }();
+  a.no_spec = !spec_env;
   hipStream_t s = (hipStream_t)stream;
   // software-pipelined kernel: d = 40, whole key tiles (at least two), V^T key-permuted; by default only when 256-query blocks
   // fill the chip.  vt_perm16 bit 1 forces it wherever it is legal, bit 2 forbids it (tests / A-B timing); SD_ATTN_V=1 forbids
-  // it process-wide, SD_ATTN_V=4 selects the 128-queries-per-wave variant.
+  // it process-wide.
   static const int sp_mode = [] { const char* e = getenv("SD_ATTN_V"); return e ? atoi(e) : 2; }();
   const bool sp_legal = d == 40 && (vt_perm16 & 1) && lk % BKV == 0 && lk >= 2 * BKV;
   const bool sp_auto = sp_mode >= 2 && !(vt_perm16 & 4) && (long long)batch * heads * ((lq + 255) / 256) >= 512;
   if (sp_legal && ((vt_perm16 & 2) || sp_auto)) {
-    const int hq = sp_mode == 4 ? 2 : 1;
-    dim3 g2((unsigned)((lq + 256 * hq - 1) / (256 * hq)), (unsigned)heads, (unsigned)batch);
-    if (hq == 2) hipLaunchKernelGGL((attention_sp_kernel<2>), g2, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attention_sp_kernel<1>), g2, dim3(256), 0, s, a);
+    // (HQ = 2, 128 queries per wave, measured slower -- 585 vs 487 us -- and is not instantiated: it needs 460 registers)
+    dim3 g2((unsigned)((lq + 255) / 256), (unsigned)heads, (unsigned)batch);
+    hipLaunchKernelGGL((attention_sp_kernel<1>), g2, dim3(256), 0, s, a);
     return check_launch("attention_sp_kernel");
   }
   vt_perm16 &= 1;
@@ -860,6 +901,7 @@ extern "C" int sd_attention_wide_f16(const void* q, const void* k, const void* v
   a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.vt = (const _Float16*)vt; a.out = (_Float16*)out;
   a.heads = heads; a.lq = lq; a.lk = lk; a.d = d; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.no_spec = 0;
   const size_t lds = (size_t)2 * BKV * d * sizeof(_Float16);          // K tile + V^T tile
   dim3 grid((unsigned)((lq + 63) / 64), (unsigned)heads, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
