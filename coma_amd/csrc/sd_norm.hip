@@ -582,3 +582,36 @@ extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0,
                      (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out, gn_pix());
   return check_launch("groupnorm (colstats) kernels");
 }
+
+// Only the per-(sample, channel) affine table (scale, shift) of a GroupNorm -- fp32 [batch][C][2] at the start of `stats` -- from the
+// producer's column sums (colstats0 != NULL) or from a statistics pass over the tensor; no apply pass.  For consumers that apply the
+// affine themselves (sd_xfront_f16).
+extern "C" int sd_groupnorm_table_f16(const void* x0, int c0, int batch, int hw, int groups, float eps, const void* gamma, const void* beta,
+                                      float* stats, const float* colstats0, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_GN_TABLE;
+    r.p[0] = (void*)x0; r.p[1] = (void*)gamma; r.p[2] = (void*)beta; r.p[3] = stats; r.p[4] = (void*)colstats0;
+    r.i[0] = c0; r.i[1] = batch; r.i[2] = hw; r.i[3] = groups; r.f[0] = eps;
+    return sd::plan_record(r);
+  }
+  if (!x0 || !gamma || !beta || !stats) return fail(COMA_E_INVALID, "sd_groupnorm_table_f16: null pointer");
+  const int C = c0;
+  if (batch <= 0 || hw <= 0 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || C > GN_MAX_C || C / groups > 256)
+    return fail(COMA_E_INVALID, "sd_groupnorm_table_f16: bad shape C=%d groups=%d", C, groups);
+  hipStream_t s = (hipStream_t)stream;
+  const int total = batch * groups;
+  if (colstats0) {
+    if (hw % 32) return fail(COMA_E_INVALID, "sd_groupnorm_table_f16: colstats need hw %% 32 == 0");
+    hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(total), dim3(256), 0, s, colstats0, (const float*)nullptr, c0, 0, hw, groups, eps,
+                       (const _Float16*)gamma, (const _Float16*)beta, stats);
+  } else {
+    const int nchunk = (hw + GN_PIX - 1) / GN_PIX;
+    float* partial = stats + (size_t)batch * C * 2;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), 0, s, (const _Float16*)x0, (const _Float16*)nullptr, c0, 0, hw, groups,
+                       partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, s, partial, nchunk, groups, C, (float)hw * (float)(C / groups), eps,
+                       (const _Float16*)gamma, (const _Float16*)beta, stats, total);
+  }
+  return check_launch("groupnorm table kernels");
+}

@@ -30,6 +30,8 @@
 //         are in flight while this head is multiplied; softmax in one pass (all keys at once), denominator from a synthetic ones row.
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "sd_plan.h"
 #include "../../include/sd_hip.h"
@@ -363,6 +365,222 @@ __global__ __launch_bounds__(NW * 64, 2) void xchain_kernel(Args g) {
   row_pass(g.h2, g.g3, g.b3, g.n3);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// xfront_kernel -- the row-local FRONT of a C = 320 transformer block in one launch:
+//     n  = GroupNorm(x) applied as the per-(sample, channel) affine table (no SiLU: Transformer2DModel.norm)
+//     h  = n @ Wpi^T + bpi                      (proj_in, a 1x1 convolution)
+//     n1 = LayerNorm1(h)
+//     q | k = n1 @ [Wq ; Wk]^T                  (attn1.to_q, to_k -> one [M, 640] tensor, what the attention kernel reads)
+//     V^T   = Wv @ n1^T per sample              (attn1.to_v, produced TRANSPOSED with the keys of every 16 in the SD_EPI_PERM16_N order)
+// replaces five launches of the r2 graph (GroupNorm apply, linear, LayerNorm, linear N = 640, batched V^T GEMM: 165 us at the 64 x 64
+// level).  Same tile machinery as xchain_kernel: T = LDS tile [64][320] (x -> n -> h -> n1), weight slices through two LDS stages;
+// each product's result is staged in the (then idle) weight stages and leaves as coalesced 16-byte stores.  V^T comes out of the MFMA
+// with the operand roles swapped (a lane owns a head-dim row and 4 consecutive tokens), staged as [320][64 tokens].
+struct FrontArgs {
+  const _Float16 *x, *wpi, *bpi, *g1, *b1, *wqk, *wv;
+  const float* gn_affine;          // [samples][320][2]
+  _Float16 *h, *qk, *vt;
+  int M, rows_per_sample, ldv;
+  float eps;
+};
+
+__global__ __launch_bounds__(NW * 64, 2) void xfront_kernel(FrontArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char xsmem[];
+  _Float16* const T = reinterpret_cast<_Float16*>(xsmem);
+  _Float16* const WB = reinterpret_cast<_Float16*>(xsmem + T_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * TM;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int my_row = wr * 32 + l31;
+  const int b = m0 / g.rows_per_sample, tok0 = m0 - b * g.rows_per_sample;
+
+  const unsigned tensor_bytes = (unsigned)((long long)g.M * C * 2);
+  auto load_tile = [&](const _Float16* src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, tensor_bytes);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int q = (wave * 10 + j) * 64 + lane;
+      const int row = q / 40, slot = q - row * 40;
+      const unsigned off = (m0 + row) < g.M ? (unsigned)(((long long)(m0 + row) * C + tswz(row, slot) * 8) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(T + (wave * 10 + j) * 512), 16, off, 0, 0, 0);
+    }
+#endif
+  };
+  constexpr int WPW = 20 / NW;
+  unsigned w_off[WPW];
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int p = wave + NW * j;
+    const int row = p * 16 + (lane >> 2), slot = lane & 3;
+    w_off[j] = (unsigned)((row * C + wswz(row, slot) * 8) * 2);
+  }
+  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, int buf, int s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16* dst = WB + buf * WB_STAGE;
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + (wave + NW * j) * 512), 16, w_off[j] + s * (BK * 2), 0, 0, 0);
+#endif
+  };
+  float16v acc[5];
+  // swapped = false: acc[j][.] = rows my_row x columns (wc, j) of T W^T (a lane owns a token row);
+  // swapped = true : the operand roles exchanged -- a lane owns weight row wc * 160 + 32 j + l31 and 4 consecutive tokens of tile wr
+  auto gemm = [&](const _Float16* w, auto swapc) {
+    constexpr bool SWAPPED = decltype(swapc)::value;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(w, (unsigned)(C * C * 2));
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    issue_w(rs, 0, 0);
+#pragma unroll 1
+    for (int s = 0; s < C / BK; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 1 < C / BK) issue_w(rs, (s + 1) & 1, s + 1);
+      const _Float16* Wb = WB + (s & 1) * WB_STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ks = 2 * s + kk;
+        const half8 af = *reinterpret_cast<const half8*>(&T[my_row * C + tswz(my_row, 2 * ks + hh) * 8]);
+        half8 wf[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int n = wc * 160 + j * 32 + l31;
+          wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          acc[j] = SWAPPED ? __builtin_amdgcn_mfma_f32_32x32x16_f16(af, wf[j], acc[j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  };
+  // token-major result -> fp16 into a swizzled [64][320] tile at `dst` (T itself or the idle weight stages)
+  auto write_rows = [&](_Float16* dst, const _Float16* bias) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int col = wc * 160 + j * 32 + 8 * rg + 4 * hh;
+        float v[4] = {acc[j][rg * 4 + 0], acc[j][rg * 4 + 1], acc[j][rg * 4 + 2], acc[j][rg * 4 + 3]};
+        if (bias) {
+          const half4 bv = *reinterpret_cast<const half4*>(bias + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+        }
+        *reinterpret_cast<half4*>(&dst[my_row * C + tswz(my_row, col >> 3) * 8 + (col & 7)]) =
+            half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+      }
+  };
+  // rows of a swizzled [64][320] tile -> global [M, ld] at column offset col0: 4 lanes per row, coalesced 16-byte stores
+  auto store_rows = [&](const _Float16* src, _Float16* out, int ld, int col0) {
+    const int row = tid >> 2, qtr = tid & 3;
+    if (m0 + row < g.M)
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int c = qtr * 10 + i;
+        *reinterpret_cast<half8*>(out + (long long)(m0 + row) * ld + col0 + c * 8) = *reinterpret_cast<const half8*>(&src[row * C + tswz(row, c) * 8]);
+      }
+  };
+
+  // ---- x -> T, GroupNorm affine in place
+  load_tile(g.x);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    const int row = tid >> 2, qtr = tid & 3;
+    const float* aff = g.gn_affine + (long long)b * C * 2;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int c = qtr * 10 + i;
+      half8* p = reinterpret_cast<half8*>(&T[row * C + tswz(row, c) * 8]);
+      const half8 xv = *p;
+      half8 y;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float4 sc = *reinterpret_cast<const float4*>(aff + (c * 8 + e) * 2);      // (scale, shift) of two channels
+        y[e] = (_Float16)((float)xv[e] * sc.x + sc.y);
+        y[e + 1] = (_Float16)((float)xv[e + 1] * sc.z + sc.w);
+      }
+      *p = y;
+    }
+  }
+  __syncthreads();
+  // ---- h = n Wpi^T + bpi -> T; h to memory (the residual of the block), n1 = LayerNorm1(h) -> T
+  gemm(g.wpi, std::false_type{});
+  write_rows(T, g.bpi);
+  __syncthreads();
+  {
+    const int row = tid >> 2, qtr = tid & 3;
+    const bool ok = m0 + row < g.M;
+    float sum = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int c = qtr * 10 + i;
+      const half8 xv = *reinterpret_cast<const half8*>(&T[row * C + tswz(row, c) * 8]);
+      if (ok) *reinterpret_cast<half8*>(g.h + (long long)(m0 + row) * C + c * 8) = xv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float f = (float)xv[e]; sum += f; sq += f * f; }
+    }
+    sum += __shfl_xor(sum, 1); sq += __shfl_xor(sq, 1);
+    sum += __shfl_xor(sum, 2); sq += __shfl_xor(sq, 2);
+    const float mean = sum * (1.0f / C);
+    const float rstd = rsqrtf(fmaxf(sq * (1.0f / C) - mean * mean, 0.0f) + g.eps);
+    __builtin_amdgcn_sched_barrier(0);               // second sweep re-reads the row from LDS instead of holding it in 40 registers
+#pragma unroll 2
+    for (int i = 0; i < 10; ++i) {
+      const int c = qtr * 10 + i;
+      half8* p = reinterpret_cast<half8*>(&T[row * C + tswz(row, c) * 8]);
+      const half8 xv = *p;
+      const half8 gm = *reinterpret_cast<const half8*>(g.g1 + c * 8), bt = *reinterpret_cast<const half8*>(g.b1 + c * 8);
+      half8 y;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (_Float16)(((float)xv[e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+      *p = y;
+    }
+  }
+  __syncthreads();
+  // ---- q and k: each product staged in the weight stages, stored, then the stages are handed back
+#pragma unroll 1
+  for (int part = 0; part < 2; ++part) {
+    gemm(g.wqk + (long long)part * C * C, std::false_type{});
+    write_rows(WB, nullptr);
+    __syncthreads();
+    store_rows(WB, g.qk, 2 * C, part * C);
+    __syncthreads();
+  }
+  // ---- V^T: lane owns head-dim row dd = 160 wc + 32 j + l31 and tokens 32 wr + 8 rg + 4 hh .. + 3; staged as [320][64 tokens] (rows of
+  // 128 B, swz64-style chunks) with every 16 tokens in the order (0-3, 8-11, 4-7, 12-15)
+  gemm(g.wv, std::true_type{});
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int dd = wc * 160 + j * 32 + l31;
+      const int t = wr * 32 + 8 * rg + 4 * hh;                        // first of 4 consecutive tokens, t % 4 == 0
+      const int tq = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);     // its position in the permuted order
+      *reinterpret_cast<half4*>(&WB[dd * 64 + (((tq >> 3) ^ (dd >> 1)) & 7) * 8 + (tq & 7)]) =
+          half4{(_Float16)acc[j][rg * 4 + 0], (_Float16)acc[j][rg * 4 + 1], (_Float16)acc[j][rg * 4 + 2], (_Float16)acc[j][rg * 4 + 3]};
+    }
+  __syncthreads();
+  {
+    _Float16* vout = g.vt + (long long)b * C * g.ldv + tok0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int q = i * (NW * 64) + tid;                               // 320 rows x 8 chunks
+      const int dd = q >> 3, c = q & 7;
+      *reinterpret_cast<half8*>(vout + (long long)dd * g.ldv + c * 8) = *reinterpret_cast<const half8*>(&WB[dd * 64 + ((c ^ (dd >> 1)) & 7) * 8]);
+    }
+  }
+}
+
 }  // namespace xc
 }  // namespace sd
 
@@ -401,4 +619,34 @@ extern "C" int sd_xattn_chain_f16(const void* attn1_out, const void* h, const vo
   }
   hipLaunchKernelGGL(xc::xchain_kernel, dim3((unsigned)(rows / xc::TM)), dim3(xc::NW * 64), xc::LDS_BYTES, (hipStream_t)stream, g);
   return check_launch("xchain_kernel");
+}
+
+extern "C" int sd_xfront_f16(const void* x, const float* gn_affine, const void* wpi, const void* bpi, const void* gamma1, const void* beta1,
+                             const void* wqk, const void* wv, void* h, void* qk, void* vt, int64_t rows, int rows_per_sample, int ldv, float eps,
+                             void* stream) {
+  using namespace sd;
+  if (plan_recording()) {
+    PlanRec r{};
+    r.kind = PK_XFRONT;
+    const void* ps[11] = {x, gn_affine, wpi, bpi, gamma1, beta1, wqk, wv, h, qk, vt};
+    for (int k = 0; k < 11; ++k) r.p[k] = const_cast<void*>(ps[k]);
+    r.i[0] = rows; r.i[1] = rows_per_sample; r.i[2] = ldv; r.f[0] = eps;
+    return plan_record(r);
+  }
+  if (!x || !gn_affine || !wpi || !bpi || !gamma1 || !beta1 || !wqk || !wv || !h || !qk || !vt) return fail(COMA_E_INVALID, "sd_xfront_f16: null pointer");
+  if (rows <= 0 || rows_per_sample <= 0 || rows % rows_per_sample || rows_per_sample % xc::TM || ldv < rows_per_sample || ldv % 8 ||
+      rows * xc::C * 4 >= 0x80000000LL)
+    return fail(COMA_E_INVALID, "sd_xfront_f16: bad sizes (C = 320, rows per sample a multiple of 64, ldv >= rows per sample)");
+  xc::FrontArgs g;
+  g.x = (const _Float16*)x; g.gn_affine = gn_affine; g.wpi = (const _Float16*)wpi; g.bpi = (const _Float16*)bpi; g.g1 = (const _Float16*)gamma1;
+  g.b1 = (const _Float16*)beta1; g.wqk = (const _Float16*)wqk; g.wv = (const _Float16*)wv; g.h = (_Float16*)h; g.qk = (_Float16*)qk;
+  g.vt = (_Float16*)vt; g.M = (int)rows; g.rows_per_sample = rows_per_sample; g.ldv = ldv; g.eps = eps;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xc::xfront_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, xc::LDS_BYTES) != hipSuccess)
+      return fail(COMA_E_LAUNCH, "sd_xfront_f16: cannot reserve %d bytes of LDS", xc::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(xc::xfront_kernel, dim3((unsigned)(rows / xc::TM)), dim3(xc::NW * 64), xc::LDS_BYTES, (hipStream_t)stream, g);
+  return check_launch("xfront_kernel");
 }

@@ -144,6 +144,18 @@ class LaunchGraph:
                  flops=3 * 2 * rows * c * c + 4 * rows * lk * c, tag=f"xchain rows={rows} C={c} lk={lk}", nbytes=2 * (4 * rows * c + 3 * c * c))
         return h2, n3
 
+    def xfront(self, x, gamma, beta, wpi, bpi, g1, b1, wqk, wv, h, qk, vt, *, batch, hw, gn_eps):
+        """GroupNorm table (from the producer's column sums when it left them) + the fused front of a C = 320 transformer block."""
+        c = 320
+        stats = self.gn_scratch(batch, hw)
+        cs0 = self._colstats.get(x.data_ptr()) if hw % 32 == 0 else None
+        self.add(lambda: ops.groupnorm_table(x, gamma, beta, stats, batch=batch, hw=hw, c0=c, eps=gn_eps, colstats0=cs0),
+                 tag=f"groupnorm(table) B={batch} hw={hw} C={c}")
+        rows = batch * hw
+        self.add(lambda: ops.xfront(x, stats, wpi, bpi, g1, b1, wqk, wv, h, qk, vt, rows=rows, rows_per_sample=hw, ldv=vt.shape[-1]),
+                 flops=4 * 2 * rows * c * c, tag=f"xfront rows={rows} C={c}", nbytes=2 * (5 * rows * c + 4 * c * c))
+        return h, qk, vt
+
     def attention_wide(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
         self.add(lambda: ops.attention_wide(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
                                             scale=d ** -0.5),

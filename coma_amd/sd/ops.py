@@ -147,6 +147,21 @@ def xattn_chain(a, h, wo1, bo1, g2, b2, wq, k2, vt2, wo2, bo2, g3, b3, h2, n3, *
     _lib.check(rc, "sd_xattn_chain_f16")
 
 
+def groupnorm_table(x0, gamma, beta, stats, *, batch, hw, c0, groups=32, eps=1e-5, colstats0=None):
+    """(scale, shift) per (sample, channel) -> stats[: batch * c0 * 2] (fp32), nothing applied."""
+    rc = _lib.lib().sd_groupnorm_table_f16(_p(x0, "x0"), c0, batch, hw, groups, eps, _p(gamma), _p(beta), _p(stats, "stats", torch.float32),
+                                           _p(colstats0, "colstats0", torch.float32), _stream(x0))
+    _lib.check(rc, "sd_groupnorm_table_f16")
+    return stats
+
+
+def xfront(x, gn_affine, wpi, bpi, g1, b1, wqk, wv, h, qk, vt, *, rows, rows_per_sample, ldv, eps=1e-5):
+    """GroupNorm affine -> proj_in -> LayerNorm1 -> q | k -> V^T (perm16) in one launch (C = 320); see sd_xfront_f16."""
+    rc = _lib.lib().sd_xfront_f16(_p(x, "x"), _p(gn_affine, "gn_affine", torch.float32), _p(wpi), _p(bpi), _p(g1), _p(b1), _p(wqk), _p(wv),
+                                  _p(h, "h"), _p(qk, "qk"), _p(vt, "vt"), rows, rows_per_sample, ldv, eps, _stream(h))
+    _lib.check(rc, "sd_xfront_f16")
+
+
 def softmax_(x, *, rows, n, ld, scale):
     _lib.check(_lib.lib().sd_softmax_f16(_p(x), rows, n, ld, scale, _stream(x)), "sd_softmax_f16")
     return x

@@ -32,7 +32,7 @@ class _Cfg(dict):
 
 class HipUNet2DConditionModel:
     def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
-                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True):
+                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True, fuse_xfront=True):
         """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
         (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
         Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
@@ -46,6 +46,7 @@ class HipUNet2DConditionModel:
         self.use_graph = use_graph
         self.fold_layernorm = fold_layernorm
         self.fuse_xchain = fuse_xchain      # C = 320 blocks: attn1.to_out ... norm3 in one launch (sd_xattn_chain_f16)
+        self.fuse_xfront = fuse_xfront      # C = 320 blocks: norm, proj_in, norm1, to_q | to_k, to_v^T in one launch (sd_xfront_f16)
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
@@ -168,29 +169,34 @@ class HipUNet2DConditionModel:
         # come out of the producing GEMM's epilogue, (mean, rstd) from a tiny finalise launch, and the normalised tensors are
         # never written.  Tiny feature maps keep the LayerNorm kernel: their producers want split-K, which has no statistics.
         fold = self.fold_layernorm and M >= self.fold_min_rows
-        gn = g.buf(M, C)
-        g.groupnorm(x, s[p + ".norm.weight"], s[p + ".norm.bias"], gn, batch=B, hw=L, c0=C, eps=1e-6, silu=False)
-        h = g.buf(M, C)
-        g.conv(gn, conv_weight(s[p + ".proj_in.weight"]), h, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".proj_in.bias"], rowstats=fold)
-        # ---- self attention
         wqk = torch.cat([s[t + ".attn1.to_q.weight"], s[t + ".attn1.to_k.weight"]]).contiguous()
         wv = s[t + ".attn1.to_v.weight"]
+        h = g.buf(M, C)
         qk = g.buf(M, 2 * C)
         ldv = (L + 15) // 16 * 16
         vt = g.buf(B, C, ldv, zero=True)         # V^T with the keys of every 16 in the order the attention kernel's MFMA operand wants
-        if fold:
-            st = g.ln_stats(h, rows=M, c=C)
-            wqk_f, sqk, tqk = ln_fold(wqk, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
-            g.conv(h, wqk_f, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C, bias=tqk, ln_stats=st, ln_colsum=sqk)
-            wv_f, sv, tv = ln_fold(wv, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
-            g.conv(wv_f, h, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv, bias=tv,
-                   epi=ops.EPI_PERM16_N | ops.EPI_BIAS_ROWS, ln_stats=st, ln_colsum=sv, stride_ln_stats=2 * L)   # statistics per key
+        if self.fuse_xfront and not fold and C == 320 and L % 64 == 0:
+            # everything before the self-attention is local to a token row once the GroupNorm statistics exist: one launch
+            g.xfront(x, s[p + ".norm.weight"], s[p + ".norm.bias"], conv_weight(s[p + ".proj_in.weight"]), s[p + ".proj_in.bias"],
+                     s[t + ".norm1.weight"], s[t + ".norm1.bias"], wqk, wv, h, qk, vt, batch=B, hw=L, gn_eps=1e-6)
         else:
-            n1 = g.buf(M, C)
-            g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
-            g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
-            g.conv(wv, n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
-                   epi=ops.EPI_PERM16_N)
+            gn = g.buf(M, C)
+            g.groupnorm(x, s[p + ".norm.weight"], s[p + ".norm.bias"], gn, batch=B, hw=L, c0=C, eps=1e-6, silu=False)
+            g.conv(gn, conv_weight(s[p + ".proj_in.weight"]), h, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".proj_in.bias"], rowstats=fold)
+            # ---- self attention
+            if fold:
+                st = g.ln_stats(h, rows=M, c=C)
+                wqk_f, sqk, tqk = ln_fold(wqk, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
+                g.conv(h, wqk_f, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C, bias=tqk, ln_stats=st, ln_colsum=sqk)
+                wv_f, sv, tv = ln_fold(wv, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
+                g.conv(wv_f, h, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv, bias=tv,
+                       epi=ops.EPI_PERM16_N | ops.EPI_BIAS_ROWS, ln_stats=st, ln_colsum=sv, stride_ln_stats=2 * L)   # statistics per key
+            else:
+                n1 = g.buf(M, C)
+                g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
+                g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
+                g.conv(wv, n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
+                       epi=ops.EPI_PERM16_N)
         a = g.buf(M, C)
         g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C, vt_perm16=True)
         Lk, cd = self.ctx_len, self.ctx_dim

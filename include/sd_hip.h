@@ -136,6 +136,23 @@ int sd_attention_f16(const void* q, const void* k, const void* vt, void* out, in
 int sd_attention_wide_f16(const void* q, const void* k, const void* vt, void* out, int batch, int heads, int lq, int lk, int d,
                           int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
 
+/* Only the per-(sample, channel) affine table of a GroupNorm: fp32 [batch][c0][2] = (scale, shift) at the start of `stats` (same
+ * scratch size as sd_groupnorm_f16), from the producer's column sums (colstats0 != NULL, hw % 32 == 0) or from a statistics pass over
+ * x0; nothing is applied.  For consumers that apply the affine themselves (sd_xfront_f16). */
+int sd_groupnorm_table_f16(const void* x0, int c0, int batch, int hw, int groups, float eps, const void* gamma, const void* beta,
+                           float* stats, const float* colstats0, void* stream);
+
+/* The row-local FRONT of a transformer block at C = 320 in ONE launch (five launches of the unfused graph):
+ *   n = x * scale + shift (gn_affine [samples][320][2], Transformer2DModel.norm without SiLU);  h = n Wpi^T + bpi (proj_in);
+ *   n1 = LayerNorm(h; gamma1, beta1);  qk[:, 0:320] = n1 Wq^T, qk[:, 320:640] = n1 Wk^T (wqk = [Wq ; Wk], fp16 [640, 320]);
+ *   vt[sample] = Wv n1^T, fp16 [320, ldv] with the tokens of every 16 in the SD_EPI_PERM16_N order (what sd_attention_f16 reads).
+ * x fp16 [rows, 320]; outputs h fp16 [rows, 320], qk fp16 [rows, 640], vt fp16 [samples, 320, ldv]; rows_per_sample a multiple of 64.
+ * replaces: Transformer2DModel.norm / proj_in and BasicTransformerBlock.norm1 / attn1.to_q / to_k / to_v inside self.unet(...),
+ *           utils/adaptive_mask_inpainting.py:1001-1007. */
+int sd_xfront_f16(const void* x, const float* gn_affine, const void* wpi, const void* bpi, const void* gamma1, const void* beta1,
+                  const void* wqk, const void* wv, void* h, void* qk, void* vt, int64_t rows, int rows_per_sample, int ldv, float eps,
+                  void* stream);
+
 /* The row-local middle of a BasicTransformerBlock at C = 320 (8 heads of 40) in ONE launch:
  *   h1 = attn1_out Wo1^T + bo1 + h;  n2 = LayerNorm(h1; gamma2, beta2);  q2 = n2 Wq2^T;
  *   a2 = softmax(q2 K2^T / sqrt(40)) V2 per head over the lk <= 96 text tokens;  h2 = a2 Wo2^T + bo2 + h1;  n3 = LayerNorm(h2; gamma3, beta3)

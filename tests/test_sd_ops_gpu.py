@@ -293,6 +293,33 @@ def test_xattn_chain_matches_the_unfused_chain_stage_by_stage(ops):
     close(o_n3, n3, tol=4e-3)
 
 
+def test_xfront_matches_the_unfused_front(ops):
+    """sd_groupnorm_table_f16 + sd_xfront_f16 (GroupNorm affine -> proj_in -> LayerNorm1 -> q | k -> V^T in the PERM16 key order, one
+    launch) against torch fp32; the GroupNorm table from a statistics pass and from producer column sums."""
+    import torch.nn.functional as F
+    B, L, C = 2, 256, 320
+    M = B * L
+    x = rnd(M, C, seed=1) * 2 + 0.5
+    gng, gnb = 1 + rnd(C, seed=2, scale=0.1), rnd(C, seed=3, scale=0.1)
+    wpi, wq, wk, wv = (rnd(C, C, seed=10 + i, scale=C**-0.5) for i in range(4))
+    bpi, g1, b1 = rnd(C, seed=20, scale=0.1), 1 + rnd(C, seed=21, scale=0.1), rnd(C, seed=22, scale=0.1)
+    f = lambda t: t.float()
+    n = F.group_norm(f(x).reshape(B, L, C).permute(0, 2, 1), 32, f(gng), f(gnb), 1e-6).permute(0, 2, 1).reshape(M, C).half()
+    h = (f(n) @ f(wpi).t() + f(bpi)).half()
+    n1 = F.layer_norm(f(h), (C,), f(g1), f(b1), 1e-5).half()
+    q, k = f(n1) @ f(wq).t(), f(n1) @ f(wk).t()
+    vt_ref = ops.perm16_columns((f(wv) @ f(n1).reshape(B, L, C).transpose(1, 2)))          # [B, C, L]
+    dv = lambda t: t.to(DEV).contiguous()
+    stats = torch.zeros(ops.gn_scratch_floats(B, L), dtype=torch.float32, device=DEV)
+    ops.groupnorm_table(dv(x), dv(gng), dv(gnb), stats, batch=B, hw=L, c0=C, eps=1e-6)
+    o_h, o_qk, o_vt = torch.zeros(M, C, dtype=F16, device=DEV), torch.zeros(M, 2 * C, dtype=F16, device=DEV), torch.zeros(B, C, L, dtype=F16, device=DEV)
+    ops.xfront(dv(x), stats, dv(wpi), dv(bpi), dv(g1), dv(b1), dv(torch.cat([wq, wk])), dv(wv), o_h, o_qk, o_vt, rows=M, rows_per_sample=L, ldv=L)
+    close(o_h, h, tol=4e-3)
+    close(o_qk[:, :C], q, tol=4e-3)
+    close(o_qk[:, C:], k, tol=4e-3)
+    close(o_vt, vt_ref, tol=4e-3)
+
+
 def test_attention_peaked_scores_force_the_rescale_path(ops):
     """One key dominates from the 3rd key tile on: exercises the online-softmax rescale with a large max jump."""
     B, heads, d, L = 1, 1, 64, 256
