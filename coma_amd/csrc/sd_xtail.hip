@@ -1,0 +1,316 @@
+// sd_xtail.hip -- the row-local TAIL of a transformer block at C = 320 as one kernel (gfx950):
+//
+//     f   = GEGLU(n3 @ W1^T + b1)               (ff.net.0: 320 -> 2 x 1280, value * gelu(gate))
+//     h3  = f @ W2^T + b2 + h2                  (ff.net.2 + residual)
+//     out = h3 @ Wpo^T + bpo + x                (Transformer2DModel.proj_out + the block's input as residual)
+//     + the per-32-row column sums / sums of squares of `out` (the GroupNorm statistics of the next ResNet block)
+//
+// replaces three launches of the UNet graph at the 64 x 64 level (GEGLU GEMM 178 us at 600 TF/s -- its erf epilogue is as long as
+// its K = 320 main loop --, K = 1280 GEMM 76 us, K = 320 GEMM 37 us) and the 168 MB hidden tensor between the first two; reached from
+// the reference through self.unet(...) (utils/adaptive_mask_inpainting.py:1001-1007).
+//
+// Workgroup = 8 waves, 128 token rows; the hidden dimension is walked in 10 chunks of 128:
+//   T  : LDS tile [128][320] fp16 -- n3 (the A operand of every chunk's first product), then h2 / h3, then x / out
+//   H  : LDS tile [128][128] fp16 -- the GEGLU output of the current chunk, A operand of the second product
+//   WB : two LDS stages for weight K-slices ([256][32] of W1 or [320][32] of W2 / Wpo), LDS-DMA, one barrier per slice
+//   acc1 (4 tiles: value, gate, value, gate of 64 hidden columns) lives per chunk, acc2 (5 tiles: this wave's 32 x 160 patch of the
+//   ff.net.2 output) accumulates over the 10 chunks: 144 accumulator registers.
+// The kernel is compute-bound (175 GFLOP per launch against 126 MB of HBM traffic), so one workgroup per CU (152 KB of LDS) is fine.
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "sd_gelu.h"
+#include "sd_plan.h"
+#include "../../include/sd_hip.h"
+
+namespace sd {
+
+using coma::check_launch;
+using coma::fail;
+
+namespace xt {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int C = 320, HID = 1280, TM = 128, NW = 8, BK = 32, CH = 128;     // CH hidden columns per chunk
+constexpr int T_BYTES = TM * C * 2;                    // 80 KB
+constexpr int WB_STAGE = C * BK;                       // halves (a W1 slice uses 256 of the 320 rows)
+constexpr int WB_BYTES = 2 * WB_STAGE * 2;             // 40 KB
+constexpr int H_BYTES = TM * CH * 2;                   // 32 KB
+constexpr int LDS_BYTES = T_BYTES + WB_BYTES + H_BYTES;
+constexpr unsigned OOB = 0x80000000u;
+
+struct Args {
+  const _Float16 *n3, *h2, *x, *w1, *b1, *w2, *b2, *wpo, *bpo;
+  _Float16* out;
+  float* colstats;       // [M/32][2][320] or nullptr
+  int M;
+};
+
+__device__ __forceinline__ int tswz(int row, int c) { return (c & ~7) | ((c ^ (row >> 1)) & 7); }   // 640-byte rows
+__device__ __forceinline__ int hswz(int row, int c) { return c ^ (row & 15); }                      // 256-byte rows (16 chunks)
+__device__ __forceinline__ int wswz(int row, int c) { return c ^ ((row >> 2) & 3); }                // 64-byte rows
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+__global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char xsmem[];
+  _Float16* const T = reinterpret_cast<_Float16*>(xsmem);
+  _Float16* const WB = reinterpret_cast<_Float16*>(xsmem + T_BYTES);
+  _Float16* const H = reinterpret_cast<_Float16*>(xsmem + T_BYTES + WB_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.x * TM;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int my_row = wr * 32 + l31;
+
+  const unsigned tensor_bytes = (unsigned)((long long)g.M * C * 2);
+  // [128 rows][40 chunks] = 80 pieces of 1 KiB, 10 per wave
+  auto load_tile = [&](const _Float16* src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, tensor_bytes);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int q = (wave * 10 + j) * 64 + lane;
+      const int row = q / 40, slot = q - row * 40;
+      const unsigned off = (m0 + row) < g.M ? (unsigned)(((long long)(m0 + row) * C + tswz(row, slot) * 8) * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(T + (wave * 10 + j) * 512), 16, off, 0, 0, 0);
+    }
+#endif
+  };
+  // weight slice [rows][32 k] of a row-major [n][ld] matrix starting at row r0, column k0: `pieces` pieces of 16 rows; wave w takes
+  // pieces w, w + 8, w + 16
+  const int p_row = lane >> 2, p_slot = lane & 3;
+  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, int buf, int r0, int ld, int k0, int pieces) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    _Float16* dst = WB + buf * WB_STAGE;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int p = wave + NW * j;
+      if (p < pieces) {
+        const int row = p * 16 + p_row;
+        const unsigned off = (unsigned)((((long long)(r0 + row)) * ld + k0 + wswz(row, p_slot) * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + p * 512), 16, off, 0, 0, 0);
+      }
+    }
+#endif
+  };
+
+  float16v acc1[4], acc2[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+
+  const __amdgpu_buffer_rsrc_t w1_rs = make_rsrc(g.w1, (unsigned)(2 * HID * C * 2));
+  const __amdgpu_buffer_rsrc_t w2_rs = make_rsrc(g.w2, (unsigned)(C * HID * 2));
+
+  load_tile(g.n3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#pragma unroll 1
+  for (int c = 0; c < HID / CH; ++c) {
+    // ---- first product of the chunk: acc1 = n3 (T) . W1[256 c .. 256 c + 255]^T, K = 320 in 10 slices
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[j][r] = 0.0f;
+    issue_w(w1_rs, 0, 256 * c, C, 0, 16);
+#pragma unroll 1
+    for (int s = 0; s < C / BK; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 1 < C / BK) issue_w(w1_rs, (s + 1) & 1, 256 * c, C, (s + 1) * BK, 16);
+      const _Float16* Wb = WB + (s & 1) * WB_STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ks = 2 * s + kk;
+        const half8 af = *reinterpret_cast<const half8*>(&T[my_row * C + tswz(my_row, 2 * ks + hh) * 8]);
+        half8 wf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = wc * 128 + j * 32 + l31;
+          wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc1[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                    // every wave is done with the weight stages (and with H of the previous chunk)
+    // first slice of the second product goes out now: it lands while the GEGLU arithmetic runs
+    issue_w(w2_rs, 0, 0, HID, c * CH, 20);
+    // ---- GEGLU: tiles (0, 1) and (2, 3) of this wave are (value, gate) of 32 hidden columns each -> H
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int col = wc * 64 + p * 32 + 8 * rg + 4 * hh;                     // hidden column within the chunk
+        const int wrow = 256 * c + wc * 128 + p * 64 + 8 * rg + 4 * hh;          // row of the interleaved W1 / b1 of the VALUE
+        const half4 bv = *reinterpret_cast<const half4*>(g.b1 + wrow), bg = *reinterpret_cast<const half4*>(g.b1 + wrow + 32);
+        half4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 av = {acc1[2 * p][rg * 4 + e] + (float)bv[e], acc1[2 * p][rg * 4 + e + 1] + (float)bv[e + 1]};
+          const f32x2 ag = {acc1[2 * p + 1][rg * 4 + e] + (float)bg[e], acc1[2 * p + 1][rg * 4 + e + 1] + (float)bg[e + 1]};
+          const f32x2 r = av * gelu_erf2(ag);
+          o4[e] = (_Float16)r.x;
+          o4[e + 1] = (_Float16)r.y;
+        }
+        *reinterpret_cast<half4*>(&H[my_row * CH + hswz(my_row, col >> 3) * 8 + (col & 7)]) = o4;
+      }
+    __syncthreads();                                 // H complete and visible (LDS writes need their own wait before a barrier)
+    // ---- second product: acc2 += H . W2[:, 128 c .. 128 c + 127]^T, K = 128 in 4 slices
+#pragma unroll 1
+    for (int s = 0; s < CH / BK; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // slice s landed; (s = 0) H is complete
+      if (s + 1 < CH / BK) issue_w(w2_rs, (s + 1) & 1, 0, HID, c * CH + (s + 1) * BK, 20);
+      const _Float16* Wb = WB + (s & 1) * WB_STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ks = 2 * s + kk;
+        const half8 af = *reinterpret_cast<const half8*>(&H[my_row * CH + hswz(my_row, 2 * ks + hh) * 8]);
+        half8 wf[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int n = wc * 160 + j * 32 + l31;
+          wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc2[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                    // weight stages and H free again
+  }
+
+  // quad (j, rg) of acc2 = 4 consecutive columns col(j, rg) of row my_row
+  auto quad_col = [&](int j, int rg) { return wc * 160 + j * 32 + 8 * rg + 4 * hh; };
+  auto quad_ptr = [&](int j, int rg) {
+    const int col = quad_col(j, rg);
+    return &T[my_row * C + tswz(my_row, col >> 3) * 8 + (col & 7)];
+  };
+  auto write_tile = [&](const _Float16* bias) {       // T <- fp16(acc2 + bias + T)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        _Float16* p = quad_ptr(j, rg);
+        const half4 bv = *reinterpret_cast<const half4*>(bias + quad_col(j, rg));
+        const half4 tv = *reinterpret_cast<const half4*>(p);
+        half4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(acc2[j][rg * 4 + e] + (float)bv[e] + (float)tv[e]);
+        *reinterpret_cast<half4*>(p) = o4;
+      }
+  };
+  // ---- h3 = acc2 + b2 + h2 -> T
+  load_tile(g.h2);                                    // n3 is no longer needed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  write_tile(g.b2);
+  __syncthreads();
+  // ---- third product: acc2 = h3 (T) . Wpo^T
+  {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.wpo, (unsigned)(C * C * 2));
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+    issue_w(rs, 0, 0, C, 0, 20);
+#pragma unroll 1
+    for (int s = 0; s < C / BK; ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 1 < C / BK) issue_w(rs, (s + 1) & 1, 0, C, (s + 1) * BK, 20);
+      const _Float16* Wb = WB + (s & 1) * WB_STAGE;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ks = 2 * s + kk;
+        const half8 af = *reinterpret_cast<const half8*>(&T[my_row * C + tswz(my_row, 2 * ks + hh) * 8]);
+        half8 wf[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int n = wc * 160 + j * 32 + l31;
+          wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc2[j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  // ---- out = acc2 + bpo + x -> T, then coalesced stores and the GroupNorm column statistics of the next block
+  load_tile(g.x);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  write_tile(g.bpo);
+  __syncthreads();
+  {
+    const int row = tid >> 2, qtr = tid & 3;
+    if (m0 + row < g.M)
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const int c = qtr * 10 + i;
+        *reinterpret_cast<half8*>(g.out + (long long)(m0 + row) * C + c * 8) = *reinterpret_cast<const half8*>(&T[row * C + tswz(row, c) * 8]);
+      }
+    if (g.colstats && tid < 160) {                    // (32-row block rb, 8-column chunk c): sums of the STORED fp16 values, rows in order
+      const int rb = tid / 40, c = tid - rb * 40;
+      float s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] = 0.0f; s2[e] = 0.0f; }
+      for (int r = 0; r < 32; ++r) {
+        const int row2 = rb * 32 + r;
+        const half8 v = *reinterpret_cast<const half8*>(&T[row2 * C + tswz(row2, c) * 8]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s1[e] += f; s2[e] += f * f; }
+      }
+      float* cs = g.colstats + ((long long)(m0 / 32 + rb) * 2) * C + c * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs[e] = s1[e]; cs[C + e] = s2[e]; }
+    }
+  }
+}
+
+}  // namespace xt
+}  // namespace sd
+
+extern "C" int sd_xtail_f16(const void* n3, const void* h2, const void* x, const void* w1, const void* b1, const void* w2, const void* b2,
+                            const void* wpo, const void* bpo, void* out, float* colstats, int64_t rows, void* stream) {
+  using namespace sd;
+  if (plan_recording()) {
+    PlanRec r{};
+    r.kind = PK_XTAIL;
+    const void* ps[11] = {n3, h2, x, w1, b1, w2, b2, wpo, bpo, out, colstats};
+    for (int k = 0; k < 11; ++k) r.p[k] = const_cast<void*>(ps[k]);
+    r.i[0] = rows;
+    return plan_record(r);
+  }
+  if (!n3 || !h2 || !x || !w1 || !b1 || !w2 || !b2 || !wpo || !bpo || !out) return fail(COMA_E_INVALID, "sd_xtail_f16: null pointer");
+  if (rows <= 0 || rows % xt::TM || rows * xt::C * 2 >= 0x80000000LL)
+    return fail(COMA_E_INVALID, "sd_xtail_f16: bad sizes (C = 320, rows a multiple of 128, tensors below 2 GiB)");
+  xt::Args g;
+  g.n3 = (const _Float16*)n3; g.h2 = (const _Float16*)h2; g.x = (const _Float16*)x; g.w1 = (const _Float16*)w1; g.b1 = (const _Float16*)b1;
+  g.w2 = (const _Float16*)w2; g.b2 = (const _Float16*)b2; g.wpo = (const _Float16*)wpo; g.bpo = (const _Float16*)bpo; g.out = (_Float16*)out;
+  g.colstats = colstats; g.M = (int)rows;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xt::xtail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, xt::LDS_BYTES) != hipSuccess)
+      return fail(COMA_E_LAUNCH, "sd_xtail_f16: cannot reserve %d bytes of LDS", xt::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(xt::xtail_kernel, dim3((unsigned)(rows / xt::TM)), dim3(xt::NW * 64), xt::LDS_BYTES, (hipStream_t)stream, g);
+  return check_launch("xtail_kernel");
+}

@@ -156,6 +156,16 @@ class LaunchGraph:
                  flops=4 * 2 * rows * c * c, tag=f"xfront rows={rows} C={c}", nbytes=2 * (5 * rows * c + 4 * c * c))
         return h, qk, vt
 
+    def xtail(self, n3, h2, x, w1, b1, w2, b2, wpo, bpo, out, *, rows):
+        c = 320
+        cs = None
+        if self.fuse_gn_stats and rows >= 16384:        # the next GroupNorm takes its statistics from these column sums
+            cs = self.buf(rows // 32, 2, c, dtype=torch.float32, zero=True)
+            self._colstats[out.data_ptr()] = cs
+        self.add(lambda: ops.xtail(n3, h2, x, w1, b1, w2, b2, wpo, bpo, out, cs, rows=rows),
+                 flops=2 * rows * c * (8 * c + 4 * c + c), tag=f"xtail rows={rows} C={c}", nbytes=2 * (4 * rows * c + 13 * c * c))
+        return out
+
     def attention_wide(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
         self.add(lambda: ops.attention_wide(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
                                             scale=d ** -0.5),

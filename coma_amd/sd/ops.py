@@ -162,6 +162,13 @@ def xfront(x, gn_affine, wpi, bpi, g1, b1, wqk, wv, h, qk, vt, *, rows, rows_per
     _lib.check(rc, "sd_xfront_f16")
 
 
+def xtail(n3, h2, x, w1, b1, w2, b2, wpo, bpo, out, colstats=None, *, rows):
+    """ff.net.0 (GEGLU) -> ff.net.2 + residual -> proj_out + residual (+ GroupNorm column sums of the result) in one launch (C = 320)."""
+    rc = _lib.lib().sd_xtail_f16(_p(n3, "n3"), _p(h2, "h2"), _p(x, "x"), _p(w1), _p(b1), _p(w2), _p(b2), _p(wpo), _p(bpo), _p(out, "out"),
+                                 _p(colstats, "colstats", torch.float32), rows, _stream(out))
+    _lib.check(rc, "sd_xtail_f16")
+
+
 def softmax_(x, *, rows, n, ld, scale):
     _lib.check(_lib.lib().sd_softmax_f16(_p(x), rows, n, ld, scale, _stream(x)), "sd_softmax_f16")
     return x

@@ -32,7 +32,7 @@ class _Cfg(dict):
 
 class HipUNet2DConditionModel:
     def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
-                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True, fuse_xfront=True):
+                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True, fuse_xfront=True, fuse_xtail=True):
         """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
         (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
         Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
@@ -47,6 +47,7 @@ class HipUNet2DConditionModel:
         self.fold_layernorm = fold_layernorm
         self.fuse_xchain = fuse_xchain      # C = 320 blocks: attn1.to_out ... norm3 in one launch (sd_xattn_chain_f16)
         self.fuse_xfront = fuse_xfront      # C = 320 blocks: norm, proj_in, norm1, to_q | to_k, to_v^T in one launch (sd_xfront_f16)
+        self.fuse_xtail = fuse_xtail        # C = 320 blocks: ff (GEGLU, Linear) + residual, proj_out + residual in one launch (sd_xtail_f16)
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
@@ -253,6 +254,12 @@ class HipUNet2DConditionModel:
                    bias=s[t + ".attn2.to_out.0.bias"], res=h1, rowstats=fold)
         # ---- feed-forward (GEGLU)
         wff, bff = geglu_interleave(s[t + ".ff.net.0.proj.weight"], s[t + ".ff.net.0.proj.bias"])
+        if xchain and self.fuse_xtail and M % 128 == 0:
+            # ... and so is everything after it: feed-forward + residual + proj_out + residual in one launch, the hidden tensor never exists
+            out = g.buf(M, C)
+            g.xtail(n3, h2, x, wff, bff, s[t + ".ff.net.2.weight"], s[t + ".ff.net.2.bias"], conv_weight(s[p + ".proj_out.weight"]),
+                    s[p + ".proj_out.bias"], out, rows=M)
+            return out
         f = g.buf(M, 4 * C)
         if xchain:
             g.conv(n3, wff, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=bff, epi=ops.EPI_GEGLU)

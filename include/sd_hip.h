@@ -153,6 +153,16 @@ int sd_xfront_f16(const void* x, const float* gn_affine, const void* wpi, const 
                   const void* wqk, const void* wv, void* h, void* qk, void* vt, int64_t rows, int rows_per_sample, int ldv, float eps,
                   void* stream);
 
+/* The row-local TAIL of a transformer block at C = 320 in ONE launch (three launches and a 4x-wide hidden tensor in the unfused graph):
+ *   f = GEGLU(n3 W1^T + b1) (W1 fp16 [2560, 320], b1 [2560]: value / gate rows interleaved per 32 as for SD_EPI_GEGLU);
+ *   h3 = f W2^T + b2 + h2 (W2 fp16 [320, 1280]);  out = h3 Wpo^T + bpo + x (Wpo fp16 [320, 320]).
+ * n3, h2, x, out: fp16 [rows, 320], rows a multiple of 128.  colstats (optional): fp32 [rows / 32][2][320], per 32-row block the
+ * column sums and sums of squares of the stored `out` (the layout of sd_conv_gemm_desc.colstats: the next GroupNorm's statistics).
+ * replaces: BasicTransformerBlock.ff (GEGLU, Linear) + residual and Transformer2DModel.proj_out + residual inside self.unet(...),
+ *           utils/adaptive_mask_inpainting.py:1001-1007. */
+int sd_xtail_f16(const void* n3, const void* h2, const void* x, const void* w1, const void* b1, const void* w2, const void* b2,
+                 const void* wpo, const void* bpo, void* out, float* colstats, int64_t rows, void* stream);
+
 /* The row-local middle of a BasicTransformerBlock at C = 320 (8 heads of 40) in ONE launch:
  *   h1 = attn1_out Wo1^T + bo1 + h;  n2 = LayerNorm(h1; gamma2, beta2);  q2 = n2 Wq2^T;
  *   a2 = softmax(q2 K2^T / sqrt(40)) V2 per head over the lk <= 96 text tokens;  h2 = a2 Wo2^T + bo2 + h1;  n3 = LayerNorm(h2; gamma3, beta3)

@@ -320,6 +320,35 @@ def test_xfront_matches_the_unfused_front(ops):
     close(o_vt, vt_ref, tol=4e-3)
 
 
+def test_xtail_matches_the_unfused_tail(ops):
+    """sd_xtail_f16 (GEGLU feed-forward + residual -> proj_out + residual, one launch, + column sums for the next GroupNorm)
+    against torch fp32 with the intermediate roundings of the unfused graph (fp16 hidden tensor, fp16 h3)."""
+    import torch.nn.functional as F
+    from coma_amd.sd.weights import geglu_interleave
+    M, C = 384, 320
+    n3, h2, x = rnd(M, C, seed=1), rnd(M, C, seed=2), rnd(M, C, seed=3)
+    w1, b1 = rnd(8 * C, C, seed=4, scale=C**-0.5), rnd(8 * C, seed=5, scale=0.1)
+    w2, b2 = rnd(C, 4 * C, seed=6, scale=(4 * C)**-0.5), rnd(C, seed=7, scale=0.1)
+    wpo, bpo = rnd(C, C, seed=8, scale=C**-0.5), rnd(C, seed=9, scale=0.1)
+    f = lambda t: t.float()
+    y = f(n3) @ f(w1).t() + f(b1)
+    hid = (y[:, :4 * C] * F.gelu(y[:, 4 * C:])).half()
+    h3 = (f(hid) @ f(w2).t() + f(b2) + f(h2)).half()
+    ref = f(h3) @ f(wpo).t() + f(bpo) + f(x)
+    dv = lambda t: t.to(DEV).contiguous()
+    w1i, b1i = geglu_interleave(w1, b1)
+    out = torch.zeros(M, C, dtype=F16, device=DEV)
+    cs = torch.zeros(M // 32, 2, C, dtype=torch.float32, device=DEV)
+    ops.xtail(dv(n3), dv(h2), dv(x), dv(w1i), dv(b1i), dv(w2), dv(b2), dv(wpo), dv(bpo), out, cs, rows=M)
+    close(out, ref, tol=4e-3)
+    o = out.float().cpu().reshape(M // 32, 32, C)
+    assert torch.allclose(cs[:, 0].cpu(), o.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(cs[:, 1].cpu(), (o * o).sum(1), rtol=1e-4, atol=1e-3)
+    out2 = torch.zeros(M, C, dtype=F16, device=DEV)                 # without the statistics output
+    ops.xtail(dv(n3), dv(h2), dv(x), dv(w1i), dv(b1i), dv(w2), dv(b2), dv(wpo), dv(bpo), out2, None, rows=M)
+    assert torch.equal(out, out2)
+
+
 def test_attention_peaked_scores_force_the_rescale_path(ops):
     """One key dominates from the 3rd key tile on: exercises the online-softmax rescale with a large max jump."""
     B, heads, d, L = 1, 1, 64, 256
