@@ -12,10 +12,12 @@
 // Workgroup = 8 waves, 128 token rows; the hidden dimension is walked in 10 chunks of 128:
 //   T  : LDS tile [128][320] fp16 -- n3 (the A operand of every chunk's first product), then h2 / h3, then x / out
 //   H  : LDS tile [128][128] fp16 -- the GEGLU output of the current chunk, A operand of the second product
-//   WB : two LDS stages for weight K-slices ([256][32] of W1 or [320][32] of W2 / Wpo), LDS-DMA, one barrier per slice
+//   WB : 48 KB of weight K-slices by LDS-DMA, one barrier per slice: three stages of [256][32] (W1: a slice is 8 MFMAs per wave, so it
+//        is requested two slices ahead) or two of [320][32] (W2 / Wpo); the first slices of every product are requested under the
+//        previous phase (W2 under the GEGLU arithmetic, the next chunk's W1 under the last W2 slice)
 //   acc1 (4 tiles: value, gate, value, gate of 64 hidden columns) lives per chunk, acc2 (5 tiles: this wave's 32 x 160 patch of the
 //   ff.net.2 output) accumulates over the 10 chunks: 144 accumulator registers.
-// The kernel is compute-bound (175 GFLOP per launch against 126 MB of HBM traffic), so one workgroup per CU (152 KB of LDS) is fine.
+// The kernel is compute-bound (175 GFLOP per launch against 126 MB of HBM traffic), so one workgroup per CU (160 KB of LDS) is fine.
 #include <hip/hip_fp16.h>
 
 #include <type_traits>
@@ -39,8 +41,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int C = 320, HID = 1280, TM = 128, NW = 8, BK = 32, CH = 128;     // CH hidden columns per chunk
 constexpr int T_BYTES = TM * C * 2;                    // 80 KB
-constexpr int WB_STAGE = C * BK;                       // halves (a W1 slice uses 256 of the 320 rows)
-constexpr int WB_BYTES = 2 * WB_STAGE * 2;             // 40 KB
+constexpr int W1_STAGE = 256 * BK;                     // halves: three 16 KB stages for the [256][32] slices of W1
+constexpr int W2_STAGE = 12288;                        // halves: two stages (at 0 and 24 KB) for the [320][32] slices of W2 / Wpo
+constexpr int WB_BYTES = 3 * W1_STAGE * 2;             // 48 KB
 constexpr int H_BYTES = TM * CH * 2;                   // 32 KB
 constexpr int LDS_BYTES = T_BYTES + WB_BYTES + H_BYTES;
 constexpr unsigned OOB = 0x80000000u;
@@ -93,9 +96,8 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
   // weight slice [rows][32 k] of a row-major [n][ld] matrix starting at row r0, column k0: `pieces` pieces of 16 rows; wave w takes
   // pieces w, w + 8, w + 16
   const int p_row = lane >> 2, p_slot = lane & 3;
-  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, int buf, int r0, int ld, int k0, int pieces) {
+  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, _Float16* dst, int r0, int ld, int k0, int pieces) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    _Float16* dst = WB + buf * WB_STAGE;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int p = wave + NW * j;
@@ -116,25 +118,36 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
 
   const __amdgpu_buffer_rsrc_t w1_rs = make_rsrc(g.w1, (unsigned)(2 * HID * C * 2));
   const __amdgpu_buffer_rsrc_t w2_rs = make_rsrc(g.w2, (unsigned)(C * HID * 2));
+  const __amdgpu_buffer_rsrc_t wpo_rs = make_rsrc(g.wpo, (unsigned)(C * C * 2));
+  // The weight region (48 KB) is THREE stages of [256][32] for the first product -- a slice is only 8 MFMAs per wave, so a slice
+  // must be requested two slices ahead to cover the L2 latency -- and TWO stages of [320][32] (at 0 and 24 KB) for the second and
+  // third products.  The stages overlap; the schedule below only ever requests a slice into bytes no wave can still be reading:
+  //   chunk parity 0: W1 slice s -> stage s % 3,       W2 slice k -> stage (k + 1) & 1, next chunk's W1 slice 0 -> stage 2
+  //   chunk parity 1: W1 slice s -> stage (s + 2) % 3, W2 slice k -> stage k & 1,       next chunk's W1 slice 0 -> stage 0
+  auto issue_w1 = [&](int c, int sl, int stage) { issue_w(w1_rs, WB + stage * W1_STAGE, 256 * c, C, sl * BK, 16); };     // 2 DMAs per wave
+  auto issue_w2 = [&](const __amdgpu_buffer_rsrc_t& rs, int stage, int ld, int k0) { issue_w(rs, WB + stage * W2_STAGE, 0, ld, k0, 20); };
 
   load_tile(g.n3);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  issue_w1(0, 0, 0);
+  issue_w1(0, 1, 1);
 
-#pragma unroll 1
-  for (int c = 0; c < HID / CH; ++c) {
-    // ---- first product of the chunk: acc1 = n3 (T) . W1[256 c .. 256 c + 255]^T, K = 320 in 10 slices
+  auto chunk = [&](int c, auto phi_c, bool last) {
+    constexpr int PHI = decltype(phi_c)::value;
+    // ---- first product of the chunk: acc1 = n3 (T) . W1[256 c .. 256 c + 255]^T, K = 320 in 10 slices, two slices in flight
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[j][r] = 0.0f;
-    issue_w(w1_rs, 0, 256 * c, C, 0, 16);
+    int st = PHI ? 2 : 0;
 #pragma unroll 1
     for (int s = 0; s < C / BK; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (s + 1 < C / BK) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // slice s landed (slice s + 1 may still be in flight)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (s + 1 < C / BK) issue_w(w1_rs, (s + 1) & 1, 256 * c, C, (s + 1) * BK, 16);
-      const _Float16* Wb = WB + (s & 1) * WB_STAGE;
+      const int st2 = st == 0 ? 2 : st - 1;            // (st + 2) % 3: the stage slice s - 1 has just left
+      if (s + 2 < C / BK) issue_w1(c, s + 2, st2);
+      else if (s + 1 == C / BK) issue_w2(w2_rs, PHI ? 0 : 1, HID, c * CH);      // first slice of the second product
+      const _Float16* Wb = WB + st * W1_STAGE;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ks = 2 * s + kk;
@@ -148,10 +161,11 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc1[j], 0, 0, 0);
       }
+      st = st == 2 ? 0 : st + 1;
     }
-    __builtin_amdgcn_s_barrier();                    // every wave is done with the weight stages (and with H of the previous chunk)
-    // first slice of the second product goes out now: it lands while the GEGLU arithmetic runs
-    issue_w(w2_rs, 0, 0, HID, c * CH, 20);
+    __builtin_amdgcn_s_barrier();                    // every wave is done with the W1 stages, with T (last chunk) and with H of the previous chunk
+    if (last) load_tile(g.h2);                       // n3 is no longer needed: the residual of the second product lands under the GEGLU
+    issue_w2(w2_rs, PHI ? 1 : 0, HID, c * CH + BK);  // second slice; both land while the GEGLU arithmetic runs
     // ---- GEGLU: tiles (0, 1) and (2, 3) of this wave are (value, gate) of 32 hidden columns each -> H
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -171,14 +185,19 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
         }
         *reinterpret_cast<half4*>(&H[my_row * CH + hswz(my_row, col >> 3) * 8 + (col & 7)]) = o4;
       }
-    __syncthreads();                                 // H complete and visible (LDS writes need their own wait before a barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                 // H complete and visible, W2 slices 0 and 1 (and h2) landed
     // ---- second product: acc2 += H . W2[:, 128 c .. 128 c + 127]^T, K = 128 in 4 slices
 #pragma unroll 1
     for (int s = 0; s < CH / BK; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                  // slice s landed; (s = 0) H is complete
-      if (s + 1 < CH / BK) issue_w(w2_rs, (s + 1) & 1, 0, HID, c * CH + (s + 1) * BK, 20);
-      const _Float16* Wb = WB + (s & 1) * WB_STAGE;
+      if (s >= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // slice s landed, every wave is done with slice s - 1
+        if (s + 1 < CH / BK) issue_w2(w2_rs, PHI ? ((s + 1) & 1) : (s & 1), HID, c * CH + (s + 1) * BK);
+        else if (!last) issue_w1(c + 1, 0, PHI ? 0 : 2);           // first W1 slice of the next chunk
+        else issue_w2(wpo_rs, 0, C, 0);                            // (last chunk has parity 1: stage 0 is free) first slice of proj_out
+      }
+      const _Float16* Wb = WB + (PHI ? (s & 1) : ((s + 1) & 1)) * W2_STAGE;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ks = 2 * s + kk;
@@ -194,6 +213,13 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
       }
     }
     __builtin_amdgcn_s_barrier();                    // weight stages and H free again
+    if (!last) issue_w1(c + 1, 1, PHI ? 1 : 0);      // second W1 slice of the next chunk
+    else issue_w2(wpo_rs, 1, C, BK);
+  };
+#pragma unroll 1
+  for (int c2 = 0; c2 < HID / CH / 2; ++c2) {
+    chunk(2 * c2, std::integral_constant<int, 0>{}, false);
+    chunk(2 * c2 + 1, std::integral_constant<int, 1>{}, c2 + 1 == HID / CH / 2);
   }
 
   // quad (j, rg) of acc2 = 4 consecutive columns col(j, rg) of row my_row
@@ -216,42 +242,35 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
         *reinterpret_cast<half4*>(p) = o4;
       }
   };
-  // ---- h3 = acc2 + b2 + h2 -> T
-  load_tile(g.h2);                                    // n3 is no longer needed
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // ---- h3 = acc2 + b2 + h2 -> T (h2 arrived under the last chunk)
   write_tile(g.b2);
   __syncthreads();
-  // ---- third product: acc2 = h3 (T) . Wpo^T
-  {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.wpo, (unsigned)(C * C * 2));
+  // ---- third product: acc2 = h3 (T) . Wpo^T; its first two slices were requested during the last chunk
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+  for (int j = 0; j < 5; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
-    issue_w(rs, 0, 0, C, 0, 20);
+    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
 #pragma unroll 1
-    for (int s = 0; s < C / BK; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (s + 1 < C / BK) issue_w(rs, (s + 1) & 1, 0, C, (s + 1) * BK, 20);
-      const _Float16* Wb = WB + (s & 1) * WB_STAGE;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ks = 2 * s + kk;
-        const half8 af = *reinterpret_cast<const half8*>(&T[my_row * C + tswz(my_row, 2 * ks + hh) * 8]);
-        half8 wf[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const int n = wc * 160 + j * 32 + l31;
-          wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc2[j], 0, 0, 0);
-      }
-    }
+  for (int s = 0; s < C / BK; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (s >= 1 && s + 1 < C / BK) issue_w2(wpo_rs, (s + 1) & 1, C, (s + 1) * BK);
+    const _Float16* Wb = WB + (s & 1) * W2_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ks = 2 * s + kk;
+      const half8 af = *reinterpret_cast<const half8*>(&T[my_row * C + tswz(my_row, 2 * ks + hh) * 8]);
+      half8 wf[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int n = wc * 160 + j * 32 + l31;
+        wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc2[j], 0, 0, 0);
+    }
   }
+  __builtin_amdgcn_s_barrier();
   // ---- out = acc2 + bpo + x -> T, then coalesced stores and the GroupNorm column statistics of the next block
   load_tile(g.x);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
