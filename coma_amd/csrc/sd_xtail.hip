@@ -15,9 +15,14 @@
 //   WB : 48 KB of weight K-slices by LDS-DMA, one barrier per slice: three stages of [256][32] (W1: a slice is 8 MFMAs per wave, so it
 //        is requested two slices ahead) or two of [320][32] (W2 / Wpo); the first slices of every product are requested under the
 //        previous phase (W2 under the GEGLU arithmetic, the next chunk's W1 under the last W2 slice)
-//   acc1 (4 tiles: value, gate, value, gate of 64 hidden columns) lives per chunk, acc2 (5 tiles: this wave's 32 x 160 patch of the
-//   ff.net.2 output) accumulates over the 10 chunks: 144 accumulator registers.
-// The kernel is compute-bound (175 GFLOP per launch against 126 MB of HBM traffic), so one workgroup per CU (160 KB of LDS) is fine.
+//   acc1 (4 tiles: two row tiles x (value, gate) of 32 hidden columns -- the first product runs on a 2 x 4 wave grid, wave tile
+//   64 x 64, one fragment read per MFMA) lives per chunk; acc2 (5 tiles: this wave's 32 x 160 patch of the ff.net.2 output, 4 x 2 wave
+//   grid) accumulates over the 10 chunks: 144 accumulator registers.
+// Where a workgroup's ~ 243 k cycles go (shader-clock stamps, profiles/r03_notes.md 10): per chunk first product 10.0 k (160 MFMAs per SIMD =
+// 5.1 k: the 32 / 64-row wave tiles read one LDS fragment per MFMA, the LDS port is as busy as the matrix pipe and the two do not overlap
+// across the per-slice barrier), GEGLU 3.9 k (VALU), 1.6 k wait, second product 4.6 k; third product 16.6 k, final residual + store 16 k.
+// One workgroup per CU (160 KB of LDS, 8 waves); a 4-wave form with 64 x 128 / 64 x 160 wave tiles (0.7 reads per MFMA, accumulators in
+// AGPRs) measured 25 % slower.
 #include <hip/hip_fp16.h>
 
 #include <type_traits>
@@ -40,6 +45,8 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int C = 320, HID = 1280, TM = 128, NW = 8, BK = 32, CH = 128;     // CH hidden columns per chunk
+constexpr int RT = TM / 32 / (NW / 2);                 // 32-row MFMA tiles per wave (waves: NW / 2 row groups x 2 column groups)
+constexpr int W1_DMA = 16 / NW, W2_DMA = 24 / NW;      // DMA instructions per wave for a W1 / a (padded) W2 or Wpo slice
 constexpr int T_BYTES = TM * C * 2;                    // 80 KB
 constexpr int W1_STAGE = 256 * BK;                     // halves: three 16 KB stages for the [256][32] slices of W1
 constexpr int W2_STAGE = 12288;                        // halves: two stages (at 0 and 24 KB) for the [320][32] slices of W2 / Wpo
@@ -66,7 +73,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
                                            __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-__global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
+__global__ __launch_bounds__(NW * 64, NW / 4) void xtail_kernel(Args g) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char xsmem[];
   _Float16* const T = reinterpret_cast<_Float16*>(xsmem);
   _Float16* const WB = reinterpret_cast<_Float16*>(xsmem + T_BYTES);
@@ -77,44 +84,55 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * TM;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int my_row = wr * 32 + l31;
+  int my_row[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) my_row[i] = (wr * RT + i) * 32 + l31;
+  // the first product uses another wave grid: (NW / 4) row groups x 4 column groups, wave tile (RT1 * 32) rows x 64 W1 rows = (value, gate)
+  // of 32 hidden columns -- RT1 + 2 fragment reads per 2 RT1 MFMAs instead of 1 + 4 per 4
+  constexpr int RT1 = TM / 32 / (NW / 4);
+  const int wr1 = wave >> 2, wc1 = wave & 3;
+  int row1[RT1];
+#pragma unroll
+  for (int i = 0; i < RT1; ++i) row1[i] = (wr1 * RT1 + i) * 32 + l31;
 
   const unsigned tensor_bytes = (unsigned)((long long)g.M * C * 2);
-  // [128 rows][40 chunks] = 80 pieces of 1 KiB, 10 per wave
+  // [128 rows][40 chunks] = 80 pieces of 1 KiB, 80 / NW per wave
   auto load_tile = [&](const _Float16* src) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, tensor_bytes);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const int q = (wave * 10 + j) * 64 + lane;
+    for (int j = 0; j < 80 / NW; ++j) {
+      const int q = (wave * (80 / NW) + j) * 64 + lane;
       const int row = q / 40, slot = q - row * 40;
       const unsigned off = (m0 + row) < g.M ? (unsigned)(((long long)(m0 + row) * C + tswz(row, slot) * 8) * 2) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(T + (wave * 10 + j) * 512), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(T + (wave * (80 / NW) + j) * 512), 16, off, 0, 0, 0);
     }
 #endif
   };
   // weight slice [rows][32 k] of a row-major [n][ld] matrix starting at row r0, column k0: `pieces` pieces of 16 rows; wave w takes
-  // pieces w, w + 8, w + 16
+  // pieces w, w + NW, ...
   const int p_row = lane >> 2, p_slot = lane & 3;
-  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, _Float16* dst, int r0, int ld, int k0, int pieces) {
+  auto issue_w = [&](const __amdgpu_buffer_rsrc_t& rs, _Float16* dst, int r0, int ld, int k0, int pieces, int nrows) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 24 / NW; ++j) {
       const int p = wave + NW * j;
       if (p < pieces) {
         const int row = p * 16 + p_row;
-        const unsigned off = (unsigned)((((long long)(r0 + row)) * ld + k0 + wswz(row, p_slot) * 8) * 2);
+        const unsigned off = row < nrows ? (unsigned)((((long long)(r0 + row)) * ld + k0 + wswz(row, p_slot) * 8) * 2) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + p * 512), 16, off, 0, 0, 0);
       }
     }
 #endif
   };
 
-  float16v acc1[4], acc2[5];
+  float16v acc1[RT1][2], acc2[RT][5];
 #pragma unroll
-  for (int j = 0; j < 5; ++j)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
 
   const __amdgpu_buffer_rsrc_t w1_rs = make_rsrc(g.w1, (unsigned)(2 * HID * C * 2));
   const __amdgpu_buffer_rsrc_t w2_rs = make_rsrc(g.w2, (unsigned)(C * HID * 2));
@@ -124,8 +142,10 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
   // third products.  The stages overlap; the schedule below only ever requests a slice into bytes no wave can still be reading:
   //   chunk parity 0: W1 slice s -> stage s % 3,       W2 slice k -> stage (k + 1) & 1, next chunk's W1 slice 0 -> stage 2
   //   chunk parity 1: W1 slice s -> stage (s + 2) % 3, W2 slice k -> stage k & 1,       next chunk's W1 slice 0 -> stage 0
-  auto issue_w1 = [&](int c, int sl, int stage) { issue_w(w1_rs, WB + stage * W1_STAGE, 256 * c, C, sl * BK, 16); };     // 2 DMAs per wave
-  auto issue_w2 = [&](const __amdgpu_buffer_rsrc_t& rs, int stage, int ld, int k0) { issue_w(rs, WB + stage * W2_STAGE, 0, ld, k0, 20); };
+  auto issue_w1 = [&](int c, int sl, int stage) { issue_w(w1_rs, WB + stage * W1_STAGE, 256 * c, C, sl * BK, 16, 256); };     // 16 / NW DMAs per wave
+  // [320][32] slices are padded to 24 pieces (rows >= 320 out of bounds: zeros into the 4 KB behind the slice) so that every wave
+  // issues the same number of DMAs (W2_DMA) and one s_waitcnt immediate serves all of them
+  auto issue_w2 = [&](const __amdgpu_buffer_rsrc_t& rs, int stage, int ld, int k0) { issue_w(rs, WB + stage * W2_STAGE, 0, ld, k0, 24, C); };
 
   load_tile(g.n3);
   issue_w1(0, 0, 0);
@@ -135,13 +155,15 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
     constexpr int PHI = decltype(phi_c)::value;
     // ---- first product of the chunk: acc1 = n3 (T) . W1[256 c .. 256 c + 255]^T, K = 320 in 10 slices, two slices in flight
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < RT1; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[j][r] = 0.0f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.0f;
     int st = PHI ? 2 : 0;
 #pragma unroll 1
     for (int s = 0; s < C / BK; ++s) {
-      if (s + 1 < C / BK) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // slice s landed (slice s + 1 may still be in flight)
+      if (s + 1 < C / BK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W1_DMA) : "memory");     // slice s landed (slice s + 1 may still be in flight)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       const int st2 = st == 0 ? 2 : st - 1;            // (st + 2) % 3: the stage slice s - 1 has just left
@@ -151,39 +173,42 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ks = 2 * s + kk;
-        const half8 af = *reinterpret_cast<const half8*>(&T[my_row * C + tswz(my_row, 2 * ks + hh) * 8]);
-        half8 wf[4];
+        half8 af[RT1], wf[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = wc * 128 + j * 32 + l31;
+        for (int i = 0; i < RT1; ++i) af[i] = *reinterpret_cast<const half8*>(&T[row1[i] * C + tswz(row1[i], 2 * ks + hh) * 8]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = wc1 * 64 + j * 32 + l31;
           wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc1[j], 0, 0, 0);
+        for (int i = 0; i < RT1; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc1[i][j], 0, 0, 0);
       }
       st = st == 2 ? 0 : st + 1;
     }
     __builtin_amdgcn_s_barrier();                    // every wave is done with the W1 stages, with T (last chunk) and with H of the previous chunk
     if (last) load_tile(g.h2);                       // n3 is no longer needed: the residual of the second product lands under the GEGLU
     issue_w2(w2_rs, PHI ? 1 : 0, HID, c * CH + BK);  // second slice; both land while the GEGLU arithmetic runs
-    // ---- GEGLU: tiles (0, 1) and (2, 3) of this wave are (value, gate) of 32 hidden columns each -> H
+    // ---- GEGLU: tiles (i, 0) and (i, 1) of this wave are (value, gate) of the same 32 hidden columns -> H
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int i = 0; i < RT1; ++i)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int col = wc * 64 + p * 32 + 8 * rg + 4 * hh;                     // hidden column within the chunk
-        const int wrow = 256 * c + wc * 128 + p * 64 + 8 * rg + 4 * hh;          // row of the interleaved W1 / b1 of the VALUE
+        const int col = wc1 * 32 + 8 * rg + 4 * hh;                              // hidden column within the chunk
+        const int wrow = 256 * c + wc1 * 64 + 8 * rg + 4 * hh;                   // row of the interleaved W1 / b1 of the VALUE
         const half4 bv = *reinterpret_cast<const half4*>(g.b1 + wrow), bg = *reinterpret_cast<const half4*>(g.b1 + wrow + 32);
         half4 o4;
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-          const f32x2 av = {acc1[2 * p][rg * 4 + e] + (float)bv[e], acc1[2 * p][rg * 4 + e + 1] + (float)bv[e + 1]};
-          const f32x2 ag = {acc1[2 * p + 1][rg * 4 + e] + (float)bg[e], acc1[2 * p + 1][rg * 4 + e + 1] + (float)bg[e + 1]};
+          const f32x2 av = {acc1[i][0][rg * 4 + e] + (float)bv[e], acc1[i][0][rg * 4 + e + 1] + (float)bv[e + 1]};
+          const f32x2 ag = {acc1[i][1][rg * 4 + e] + (float)bg[e], acc1[i][1][rg * 4 + e + 1] + (float)bg[e + 1]};
           const f32x2 r = av * gelu_erf2(ag);
           o4[e] = (_Float16)r.x;
           o4[e + 1] = (_Float16)r.y;
         }
-        *reinterpret_cast<half4*>(&H[my_row * CH + hswz(my_row, col >> 3) * 8 + (col & 7)]) = o4;
+        *reinterpret_cast<half4*>(&H[row1[i] * CH + hswz(row1[i], col >> 3) * 8 + (col & 7)]) = o4;
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                 // H complete and visible, W2 slices 0 and 1 (and h2) landed
@@ -201,15 +226,18 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ks = 2 * s + kk;
-        const half8 af = *reinterpret_cast<const half8*>(&H[my_row * CH + hswz(my_row, 2 * ks + hh) * 8]);
-        half8 wf[5];
+        half8 af[RT], wf[5];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const half8*>(&H[my_row[i] * CH + hswz(my_row[i], 2 * ks + hh) * 8]);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           const int n = wc * 160 + j * 32 + l31;
           wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc2[j], 0, 0, 0);
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc2[i][j], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_barrier();                    // weight stages and H free again
@@ -224,51 +252,62 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
 
   // quad (j, rg) of acc2 = 4 consecutive columns col(j, rg) of row my_row
   auto quad_col = [&](int j, int rg) { return wc * 160 + j * 32 + 8 * rg + 4 * hh; };
-  auto quad_ptr = [&](int j, int rg) {
+  auto quad_ptr = [&](int i, int j, int rg) {
     const int col = quad_col(j, rg);
-    return &T[my_row * C + tswz(my_row, col >> 3) * 8 + (col & 7)];
+    return &T[my_row[i] * C + tswz(my_row[i], col >> 3) * 8 + (col & 7)];
   };
   auto write_tile = [&](const _Float16* bias) {       // T <- fp16(acc2 + bias + T)
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        _Float16* p = quad_ptr(j, rg);
-        const half4 bv = *reinterpret_cast<const half4*>(bias + quad_col(j, rg));
-        const half4 tv = *reinterpret_cast<const half4*>(p);
-        half4 o4;
+      for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(acc2[j][rg * 4 + e] + (float)bv[e] + (float)tv[e]);
-        *reinterpret_cast<half4*>(p) = o4;
-      }
+        for (int rg = 0; rg < 4; ++rg) {
+          _Float16* p = quad_ptr(i, j, rg);
+          const half4 bv = *reinterpret_cast<const half4*>(bias + quad_col(j, rg));
+          const half4 tv = *reinterpret_cast<const half4*>(p);
+          half4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = (_Float16)(acc2[i][j][rg * 4 + e] + (float)bv[e] + (float)tv[e]);
+          *reinterpret_cast<half4*>(p) = o4;
+        }
   };
   // ---- h3 = acc2 + b2 + h2 -> T (h2 arrived under the last chunk)
   write_tile(g.b2);
   __syncthreads();
-  // ---- third product: acc2 = h3 (T) . Wpo^T; its first two slices were requested during the last chunk
+  // ---- third product: acc2 = h3 (T) . Wpo^T, three stages (0, 24 KB, 48 KB = the idle H tile); slices 0 and 1 were requested during
+  // the last chunk
 #pragma unroll
-  for (int j = 0; j < 5; ++j)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.0f;
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
+  int st3 = 0;
 #pragma unroll 1
   for (int s = 0; s < C / BK; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (s + 1 < C / BK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W2_DMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (s >= 1 && s + 1 < C / BK) issue_w2(wpo_rs, (s + 1) & 1, C, (s + 1) * BK);
-    const _Float16* Wb = WB + (s & 1) * W2_STAGE;
+    if (s + 2 < C / BK) issue_w2(wpo_rs, st3 == 0 ? 2 : st3 - 1, C, (s + 2) * BK);
+    const _Float16* Wb = WB + st3 * W2_STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ks = 2 * s + kk;
-      const half8 af = *reinterpret_cast<const half8*>(&T[my_row * C + tswz(my_row, 2 * ks + hh) * 8]);
-      half8 wf[5];
+      half8 af[RT], wf[5];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) af[i] = *reinterpret_cast<const half8*>(&T[my_row[i] * C + tswz(my_row[i], 2 * ks + hh) * 8]);
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const int n = wc * 160 + j * 32 + l31;
         wf[j] = *reinterpret_cast<const half8*>(&Wb[n * BK + wswz(n, 2 * kk + hh) * 8]);
       }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af, acc2[j], 0, 0, 0);
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], af[i], acc2[i][j], 0, 0, 0);
     }
+    st3 = st3 == 2 ? 0 : st3 + 1;
   }
   __builtin_amdgcn_s_barrier();
   // ---- out = acc2 + bpo + x -> T, then coalesced stores and the GroupNorm column statistics of the next block
@@ -278,13 +317,15 @@ __global__ __launch_bounds__(NW * 64, 2) void xtail_kernel(Args g) {
   write_tile(g.bpo);
   __syncthreads();
   {
-    const int row = tid >> 2, qtr = tid & 3;
-    if (m0 + row < g.M)
+    const int qtr = tid & 3;
 #pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        const int c = qtr * 10 + i;
-        *reinterpret_cast<half8*>(g.out + (long long)(m0 + row) * C + c * 8) = *reinterpret_cast<const half8*>(&T[row * C + tswz(row, c) * 8]);
-      }
+    for (int row = tid >> 2; row < TM; row += NW * 16)
+      if (m0 + row < g.M)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          const int c = qtr * 10 + i;
+          *reinterpret_cast<half8*>(g.out + (long long)(m0 + row) * C + c * 8) = *reinterpret_cast<const half8*>(&T[row * C + tswz(row, c) * 8]);
+        }
     if (g.colstats && tid < 160) {                    // (32-row block rb, 8-column chunk c): sums of the STORED fp16 values, rows in order
       const int rb = tid / 40, c = tid - rb * 40;
       float s1[8], s2[8];
