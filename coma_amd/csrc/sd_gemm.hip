@@ -74,6 +74,8 @@ struct GemmArgs {
   const float* ln_stats;      // [rows][2] = (mean, rstd)
   const float* ln_colsum;     // [N] (or [M] with SD_EPI_BIAS_ROWS): sum_k (gamma o W)[n, k]
   float* rowstats;            // producer side: [N/32][M][2] per-row (sum, sum of squares) of every stored 32-column tile
+  _Float16* out_t;            // optional: columns >= n_split leave transposed per sample, keys in the PERM16 order (sd_conv_gemm_desc.out_t)
+  int n_split, ldo_t, rps;
 };
 
 __device__ __forceinline__ void dbg_stamp(const GemmArgs& g, int slot) {
@@ -155,6 +157,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
             *reinterpret_cast<float4*>(part + (long long)row * g.N + col) = accq(i, j, q);
         }
     }
+    return;
+  }
+  if (g.out_t && n0 >= g.n_split) {
+    // this workgroup's columns are the transposed tail (a whole number of N tiles by contract): tile by tile through the wave's staging
+    // area, read back COLUMN-wise -- lane = (channel c, half hf): 16 keys of one channel = one 16-key group, stored as two 16-byte
+    // vectors in the order (0-3, 8-11, 4-7, 12-15).  No bias, no residual.
+    const int c = lane & 31, hf = lane >> 5;
+    const int cv = g.N - g.n_split;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mbase = m0 + wr * (TM * 32) + i * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(stage + qrow(q) * EP_STRIDE + qcol(q)) = accq(i, j, q);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (mbase < g.M) {
+          float v[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v[t] = stage[(hf * 16 + t) * EP_STRIDE + c];
+          half8 lo, hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            lo[e] = (_Float16)v[e];
+            lo[4 + e] = (_Float16)v[8 + e];
+            hi[e] = (_Float16)v[4 + e];
+            hi[4 + e] = (_Float16)v[12 + e];
+          }
+          const int b = mbase / g.rps;
+          const int ch = n0 - g.n_split + wc * (TN * 32) + j * 32 + c;
+          _Float16* dst = g.out_t + ((long long)b * cv + ch) * g.ldo_t + (mbase - b * g.rps) + hf * 16;
+          *reinterpret_cast<half8*>(dst) = lo;
+          *reinterpret_cast<half8*>(dst + 8) = hi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     return;
   }
   _Float16* outp = g.out + z * g.so;
@@ -892,12 +933,15 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
     const sd_conv_gemm_desc& d = *d_in;
     sd::PlanRec r{};
     r.kind = sd::PK_CONV;
-    void* ps[12] = {(void*)d.a0, (void*)d.a1, (void*)d.w, (void*)d.bias, (void*)d.bias_bn, (void*)d.res, d.out, d.workspace, d.colstats,
-                    (void*)d.ln_stats, (void*)d.ln_colsum, d.rowstats};
-    for (int k = 0; k < 12; ++k) r.p[k] = ps[k];
+    void* ps[13] = {(void*)d.a0, (void*)d.a1, (void*)d.w, (void*)d.bias, (void*)d.bias_bn, (void*)d.res, d.out, d.workspace, d.colstats,
+                    (void*)d.ln_stats, (void*)d.ln_colsum, d.rowstats, d.out_t};
+    for (int k = 0; k < 13; ++k) r.p[k] = ps[k];
     const int64_t is[23] = {d.c0, d.c1, d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.taps, d.stride, d.upsample, d.pad, d.n, d.ldbb, d.ldr, d.ldo,
                             d.epi, d.nbatch_z, d.stride_a, d.stride_w, d.stride_out, d.stride_res, (int64_t)d.workspace_bytes, d.stride_ln_stats};
     for (int k = 0; k < 23; ++k) r.i[k] = is[k];
+    if (d.out_t && (d.n_split < 0 || d.n_split >= (1 << 20) || d.ldo_t < 0 || d.ldo_t >= (1 << 20) || d.rows_per_sample < 0 || d.rows_per_sample >= (1 << 20)))
+      return sd::fail(COMA_E_INVALID, "sd_conv_gemm_f16: out_t sizes out of range");
+    r.i[23] = (int64_t)d.n_split | ((int64_t)d.ldo_t << 20) | ((int64_t)d.rows_per_sample << 40);    // three 20-bit fields
     return sd::plan_record(r);
   }
   if (!d_in) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
@@ -1016,6 +1060,16 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   g.partial = (float*)d->workspace;
   g.colstats = (float*)d->colstats;
   g.ln_stats = d->ln_stats; g.ln_colsum = d->ln_colsum; g.rowstats = d->rowstats; g.sln = d->stride_ln_stats;
+  g.out_t = (_Float16*)d->out_t; g.n_split = d->n_split; g.ldo_t = d->ldo_t; g.rps = d->rows_per_sample;
+  if (g.out_t) {
+    if (geglu || nz != 1 || d->taps != 1 || d->c1 > 0 || d->bias || d->bias_bn || d->res || d->colstats || d->rowstats || d->ln_stats ||
+        (d->epi & ~SD_EPI_TUNING_MASK) || d->n_split <= 0 || d->n_split % 640 || (d->n - d->n_split) <= 0 || (d->n - d->n_split) % 640 ||
+        g.M % 32 || d->rows_per_sample <= 0 || d->rows_per_sample % 32 || g.M % d->rows_per_sample || d->ldo_t % 8 || d->ldo_t < d->rows_per_sample ||
+        g.ldo < d->n_split || g.ldo % 8)
+      return fail(COMA_E_INVALID, "sd_conv_gemm_f16: out_t needs a plain linear (no bias / residual / GEGLU / statistics / batching), n_split and "
+                                  "n - n_split multiples of 640, M and rows_per_sample multiples of 32, ldo >= n_split, ldo_t >= rows_per_sample, both % 8 == 0");
+    if (d->n_split % bn) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: out_t: the %d-column tile of this shape does not divide n_split = %d", bn, d->n_split);
+  }
   if ((g.ln_stats == nullptr) != (g.ln_colsum == nullptr)) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: ln_stats and ln_colsum come together");
   if (g.ln_stats && (d->bias_bn || d->colstats || d->c1 > 0 || d->taps != 1))
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a folded LayerNorm needs a single-source 1x1 / linear GEMM without per-sample bias / colstats");
@@ -1034,7 +1088,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
-  if (!g.colstats && !g.rowstats && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
+  if (!g.colstats && !g.rowstats && !g.out_t && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((mid8 ? 256 : 512) / blocks);         // the 8-wave 128 x 320 tile is resident once per CU, the others twice
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;

@@ -32,7 +32,7 @@ class _Cfg(dict):
 
 class HipUNet2DConditionModel:
     def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
-                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True, fuse_xfront=True, fuse_xtail=True):
+                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True, fuse_xfront=True, fuse_xtail=True, fuse_qkv=True):
         """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
         (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
         Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
@@ -47,6 +47,7 @@ class HipUNet2DConditionModel:
         self.fold_layernorm = fold_layernorm
         self.fuse_xchain = fuse_xchain      # C = 320 blocks: attn1.to_out ... norm3 in one launch (sd_xattn_chain_f16)
         self.fuse_xfront = fuse_xfront      # C = 320 blocks: norm, proj_in, norm1, to_q | to_k, to_v^T in one launch (sd_xfront_f16)
+        self.fuse_qkv = fuse_qkv            # C = 640 / 1280 blocks: to_q | to_k | to_v one GEMM, V^T written transposed by its epilogue (sd_conv_gemm_desc.out_t)
         self.fuse_xtail = fuse_xtail        # C = 320 blocks: ff (GEGLU, Linear) + residual, proj_out + residual in one launch (sd_xtail_f16)
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
@@ -195,9 +196,14 @@ class HipUNet2DConditionModel:
             else:
                 n1 = g.buf(M, C)
                 g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
-                g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
-                g.conv(wv, n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
-                       epi=ops.EPI_PERM16_N)
+                if self.fuse_qkv and C % 640 == 0 and L % 32 == 0:
+                    # to_q | to_k | to_v in one launch: the V columns leave transposed per sample in the key order of the attention kernel
+                    g.conv(n1, torch.cat([wqk, wv]).contiguous(), qk, batch=M, in_h=1, in_w=1, c0=C, n=3 * C, ldo=2 * C, out_t=vt, n_split=2 * C,
+                           ldo_t=ldv, rows_per_sample=L)
+                else:
+                    g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
+                    g.conv(wv, n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
+                           epi=ops.EPI_PERM16_N)
         a = g.buf(M, C)
         g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C, vt_perm16=True)
         Lk, cd = self.ctx_len, self.ctx_dim

@@ -80,6 +80,14 @@ typedef struct sd_conv_gemm_desc {
   int64_t stride_ln_stats; /* floats between the ln_stats of consecutive z problems (nbatch_z > 1) */
   float* rowstats;         /* optional fp32 [n/32][M][2]: per row and 32-column tile the sum and sum of squares of the stored output --
                               the raw material of the consumer's LayerNorm statistics; n % 32 == 0, no split-K */
+  /* Optional second output: columns [n_split, n) of the product leave TRANSPOSED, per sample, in the key order of
+   * sd_attention_f16(vt_perm16 = 1): out_t fp16 [M / rows_per_sample][n - n_split][ldo_t], element (b, c, pos) = product row
+   * b * rows_per_sample + key(pos), column n_split + c, where every group of 16 positions holds the keys (0-3, 8-11, 4-7, 12-15).
+   * Columns [0, n_split) go to `out` as usual (ldo >= n_split).  This is to_q | to_k | to_v of a self-attention in ONE launch: V^T is
+   * what the attention kernel's PV product wants as its LDS operand.  Plain linear only (taps = 1, no bias / residual / GEGLU /
+   * statistics / batching / split-K); n_split and n - n_split multiples of 640, M and rows_per_sample multiples of 32, ldo_t % 8 == 0. */
+  void* out_t;
+  int n_split, ldo_t, rows_per_sample;
 } sd_conv_gemm_desc;
 
 int sd_conv_gemm_f16(const sd_conv_gemm_desc* desc, void* stream);

@@ -349,6 +349,29 @@ def test_xtail_matches_the_unfused_tail(ops):
     assert torch.equal(out, out2)
 
 
+def test_linear_with_transposed_tail_is_qkv_in_one_launch(ops):
+    """sd_conv_gemm_desc.out_t: columns [n_split, n) of a linear leave transposed per sample in the PERM16 key order (to_q | to_k | to_v of a
+    self-attention in one launch) -- against the two launches it replaces, bit for bit, and against torch fp32; both tile families."""
+    for (B, L, C) in ((2, 4096, 640), (4, 256, 1280), (2, 64, 1280)):
+        M = B * L
+        x = rnd(M, C, seed=1)
+        wqk, wv = rnd(2 * C, C, seed=2, scale=C**-0.5), rnd(C, C, seed=3, scale=C**-0.5)
+        dv = lambda t: t.to(DEV).contiguous()
+        xd, wqkd, wvd = dv(x), dv(wqk), dv(wv)
+        qk0 = torch.zeros(M, 2 * C, dtype=F16, device=DEV)
+        vt0 = torch.zeros(B, C, L, dtype=F16, device=DEV)
+        ops.conv_gemm(xd, wqkd, qk0, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
+        ops.conv_gemm(wvd, xd, vt0, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=L, nbatch_z=B, stride_w=L * C, stride_out=C * L, epi=ops.EPI_PERM16_N)
+        qk1 = torch.zeros(M, 2 * C, dtype=F16, device=DEV)
+        vt1 = torch.zeros(B, C, L, dtype=F16, device=DEV)
+        ops.conv_gemm(xd, dv(torch.cat([wqk, wv])), qk1, batch=M, in_h=1, in_w=1, c0=C, n=3 * C, ldo=2 * C, out_t=vt1, n_split=2 * C, ldo_t=L,
+                      rows_per_sample=L)
+        assert torch.equal(qk0, qk1)
+        ref = ops.perm16_columns(wv.float() @ x.float().reshape(B, L, C).transpose(1, 2))
+        close(vt1, ref, tol=4e-3)
+        close(vt1, vt0.float().cpu(), tol=2e-3)          # (the batched launch accumulates in another tile / K order: equal up to fp16 rounding)
+
+
 def test_attention_peaked_scores_force_the_rescale_path(ops):
     """One key dominates from the 3rd key tile on: exercises the online-softmax rescale with a large max jump."""
     B, heads, d, L = 1, 1, 64, 256
