@@ -66,6 +66,7 @@ class ComA_Occupancy:
         self._pristine = True       # nothing has been accumulated into _grid and nobody outside has seen it
         self._field_all = None      # max over ALL humans computed by the fused pass, valid until the grid is exposed
         self._needs_norm = False    # a reduction has happened: outside readers must see counts / row sums
+        self._zero_pending = False  # reset() was called: the grid is logically zero, the memset happens only if somebody needs it
         self.cache_count = 0
         self.used_count = 0
         self.cache = dict()
@@ -90,17 +91,21 @@ class ComA_Occupancy:
 
     @spatial_occupancy_grids.setter
     def spatial_occupancy_grids(self, value):
-        self._pending, self._pristine, self._field_all, self._needs_norm = [], False, None, False
+        self._pending, self._pristine, self._field_all, self._needs_norm, self._zero_pending = [], False, None, False, False
         self._grid = value
 
     def reset(self):
-        """Back to the state after construction (extension: lets a long-lived object be re-used)."""
-        self._grid.zero_()
+        """Back to the state after construction (extension: lets a long-lived object be re-used).  The 4 H R^3-byte memset is deferred:
+        the fused pass writes every cell of the grid anyway; any other reader or writer zeroes it first (_materialize)."""
+        self._zero_pending = True
         self._pending, self._pristine, self._field_all, self._needs_norm = [], True, None, False
         self.cache, self.used, self.cache_count, self.used_count = dict(), dict(), 0, 0
 
     def _materialize(self):
         """Make _grid hold what the reference's attribute would hold right now."""
+        if self._zero_pending and not (self._pending and self._pristine and self._fusable()):
+            self._grid.zero_()
+            self._zero_pending = False
         if self._pending:
             if self._pristine and self._fusable():
                 self._field_all = self._fused(None)
@@ -242,6 +247,7 @@ class ComA_Occupancy:
                                     _lib.ptr(rowsum), _lib.ptr(out), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
         _lib.check(rc, "coma_occupancy_fused")
         self._pending, self._pristine = [], False          # only once the pass has been accepted: a refusal loses nothing
+        self._zero_pending = False                         # every cell of every row has just been written
         return out
 
     def _reduce(self, human_indices):

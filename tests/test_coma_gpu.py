@@ -425,6 +425,32 @@ def test_occupancy_config5_share_properties(dev, hip_lib):
     assert (_np(field)[None] >= norm_rows).all()
 
 
+def test_occupancy_reset_defers_the_memset_without_leaking_old_counts():
+    """reset() only marks the grid as zero: the fused pass overwrites every cell, every other route zeroes first."""
+    from utils.coma_occupancy import ComA_Occupancy
+    DEV = "cuda:0"
+    H, R = 24, 32
+    mk = lambda: ComA_Occupancy(scale_tolerance=2.0, human_res=H, obj_res=1, normal_res=0, spatial_res=R, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    qa = (torch.rand([7, H, 3], generator=g) * 2.4 - 1.2).to(DEV)
+    qb = (torch.rand([5, H, 3], generator=g) * 2.4 - 1.2).to(DEV)
+    for lazy in (True, False):                              # fused pass / atomic splat after the reset
+        occ, ref = mk(), mk()
+        occ.accumulate_device(qa)
+        occ.return_aggregated_spatial_grids()
+        occ.reset()
+        occ.accumulate_device(qb, lazy=lazy)
+        ref.accumulate_device(qb, lazy=lazy)
+        fa, fb = occ.return_aggregated_spatial_grids(), ref.return_aggregated_spatial_grids()
+        assert torch.equal(torch.nan_to_num(fa, nan=-7.0), torch.nan_to_num(fb, nan=-7.0))
+        assert torch.equal(torch.nan_to_num(occ.spatial_occupancy_grids, nan=-7.0), torch.nan_to_num(ref.spatial_occupancy_grids, nan=-7.0))
+    occ = mk()
+    occ.accumulate_device(qa)
+    occ.return_aggregated_spatial_grids()
+    occ.reset()
+    assert float(occ.spatial_occupancy_grids.abs().sum()) == 0.0           # nothing staged: a reader sees zeros
+
+
 def test_occupancy_falls_back_when_the_fused_pass_cannot_take_the_configuration(dev, hip_lib):
     """scale_tolerance is a free CLI float: a window wider than the fused kernel's 16 cells (tolerance > 7) must take the
     splat + reduce route with every staged sample kept."""
