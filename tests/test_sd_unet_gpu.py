@@ -140,3 +140,50 @@ def test_layernorm_fold_equals_the_unfused_graph(setup):
         rel, cos = _metrics(outs[-1], ref)
         assert rel <= 2e-2 and cos >= 0.999, (fold, rel, cos)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-2 * float(outs[0].abs().max())
+
+
+def test_row_tile_fusions_agree_with_the_unfused_graph(setup):
+    """The C = 320 row-tile kernels (sd_xfront_f16, sd_xattn_chain_f16, sd_xtail_f16) and the one-launch q | k | v projection
+    (sd_conv_gemm_desc.out_t) against the SAME network with every one of them switched off, at the 64 x 64 level where they are used
+    (batch 4): the two launch lists compute the same products with the same roundings except for accumulation order -> the outputs
+    agree far inside the fp32-reference tolerance, and each one matches the reference."""
+    state, _, _, _, _, UNet = setup
+    from coma_amd.sd import weights
+    B, hw = 4, 64
+    g = torch.Generator().manual_seed(21)
+    sample = torch.randn(B, 9, hw, hw, generator=g).half().float()
+    ctx = torch.randn(B, 77, 768, generator=g).half().float()
+    t = torch.tensor([981.0, 621.0, 301.0, 21.0])
+    outs, n_launch = [], []
+    for on in (True, False):
+        unet = UNet(state, batch=B, height=hw, width=hw, device=DEV, use_graph=True, fuse_xchain=on, fuse_xfront=on, fuse_xtail=on, fuse_qkv=on)
+        outs.append(unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0].clone())
+        n_launch.append(len(unet.g.launches))
+        del unet
+        torch.cuda.empty_cache()
+    assert n_launch[0] < n_launch[1] - 50, n_launch            # the fused list really is the short one
+    rel, cos = _metrics(outs[0], outs[1])
+    assert rel <= 5e-3 and cos >= 0.9999, (rel, cos)
+    ref = so.unet_ref(state, sample, t, ctx, weights.UNET_CFG)
+    for o in outs:
+        rel, cos = _metrics(o, ref)
+        assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+
+
+def test_unet_ragged_resolution_matches_fp32_reference(setup):
+    """A latent that is neither square nor a multiple of 64 tokens anywhere (24 x 40 -> 12 x 20 -> 6 x 10 -> 3 x 5: attention over
+    960 / 240 / 60 / 15 tokens, GEMMs with M = 30 ... 1920 rows): every ragged-edge path of the kernels (partial tiles, key padding,
+    small GroupNorms) and the fall-back of the row-tile fusions, against the fp32 reference."""
+    state, _, _, _, _, UNet = setup
+    from coma_amd.sd import weights
+    B, h, w = 2, 24, 40
+    g = torch.Generator().manual_seed(31)
+    sample = torch.randn(B, 9, h, w, generator=g).half().float()
+    ctx = torch.randn(B, 77, 768, generator=g).half().float()
+    t = torch.tensor([741.0, 41.0])
+    unet = UNet(state, batch=B, height=h, width=w, device=DEV, use_graph=True)
+    out = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
+    assert tuple(out.shape) == (B, 4, h, w)
+    ref = so.unet_ref(state, sample, t, ctx, weights.UNET_CFG)
+    rel, cos = _metrics(out, ref)
+    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
