@@ -44,26 +44,27 @@ def test_mask_adapt_matches_numpy_box_dilation(hip_lib):
         assert np.array_equal(m[:, :, :3], exp.astype(np.float16).astype(np.float32)) and float(np.abs(m[:, :, 3:]).max()) == 0.0
 
 
-@pytest.mark.parametrize("B,HW,steps", [(2, 128, 3), (1, 512, 2)])
-def test_fixed_mask_loop_matches_fp32_restatement(hip_lib, B, HW, steps):
-    """The whole fixed-mask loop (config 2's shape in the second case: 512 x 512 image, 64 x 64 latents, CFG batch 2) against the
-    fp32 restatement of utils/adaptive_mask_inpainting.py:988-1022 step by step."""
+@pytest.mark.parametrize("B,IH,IW,steps", [(2, 128, 128, 3), (1, 512, 512, 2), (1, 192, 320, 3)])
+def test_fixed_mask_loop_matches_fp32_restatement(hip_lib, B, IH, IW, steps):
+    """The whole fixed-mask loop (config 2's shape in the second case: 512 x 512 image, 64 x 64 latents, CFG batch 2; the third case is a
+    non-square image whose latent, 24 x 40, is ragged against every tile size) against the fp32 restatement of
+    utils/adaptive_mask_inpainting.py:988-1022 step by step."""
     from coma_amd.sd import weights
     from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline
-    L = HW // 8
-    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=B, height=HW, width=HW, device=DEV, seed=0)
+    LH, LW = IH // 8, IW // 8
+    pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=B, height=IH, width=IW, device=DEV, seed=0)
     g = torch.Generator().manual_seed(5)
-    image = (torch.rand(B, 3, HW, HW, generator=g) * 2 - 1)
-    mask = torch.zeros(B, 1, HW, HW)
-    mask[:, :, HW // 4:3 * HW // 4, HW // 4:3 * HW // 4] = 1
+    image = (torch.rand(B, 3, IH, IW, generator=g) * 2 - 1)
+    mask = torch.zeros(B, 1, IH, IW)
+    mask[:, :, IH // 4:3 * IH // 4, IW // 4:3 * IW // 4] = 1
     pe, ne = torch.randn(B, 77, 768, generator=g).half().float(), torch.randn(B, 77, 768, generator=g).half().float()
-    lat0 = torch.randn(B, 4, L, L, generator=g)
+    lat0 = torch.randn(B, 4, LH, LW, generator=g)
     guidance = 11.0
     out = pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps,
                guidance_scale=guidance, latents=lat0, output_type="latent", use_adaptive_mask=False).images
     # fp32 restatement of the same loop with the pipeline's own masked-image latents (VAE parity is tested separately)
     ustate = weights.random_state(weights.unet_shapes(), seed=0)
-    masked_lat = pipe._last_masked_lat.float().cpu().reshape(B, L, L, 4).permute(0, 3, 1, 2) if hasattr(pipe, "_last_masked_lat") else None
+    masked_lat = pipe._last_masked_lat.float().cpu().reshape(B, LH, LW, 4).permute(0, 3, 1, 2) if hasattr(pipe, "_last_masked_lat") else None
     if masked_lat is None:
         pytest.skip("pipeline does not expose masked latents")
     mask_lat = mask[:, :, ::8, ::8]
