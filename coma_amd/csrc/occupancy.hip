@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __r
   const int h = blockIdx.x;
   const double inv = 1.0 / voxel;
   unsigned hits = 0;
+  const float t2_f = (float)t2, t2_band = (float)(t2 * 0x1p-18);
+  const bool pre_ok = t2 > 1e-30 && t2 < 1e30;        // (the error bound above assumes neither under- nor overflow in f32)
   for (int s = threadIdx.x; s < S; s += 256) {
     const float* qp = q + ((int64_t)s * H + h) * 3;
     const double qc[3] = {(double)qp[0], (double)qp[1], (double)qp[2]};
@@ -185,16 +187,55 @@ __global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __r
 #pragma unroll
     for (int c = 0; c < 3; ++c) axis_range(qc[c], thres, cen[c * R], inv, R, lo[c], n[c]);
     if (n[0] <= 0 || n[1] <= 0 || n[2] <= 0) continue;
-    for (int ix = lo[0]; ix < lo[0] + n[0]; ++ix) {
+    // exact count of one x-plane: the reference's predicate, (dx*dx + dy*dy) + dz*dz < t2 in f64, every product rounded on its own
+    auto plane_exact = [&](int ix) {
       const double dx = cen[ix] - qc[0];
+      unsigned c = 0;
       for (int iy = lo[1]; iy < lo[1] + n[1]; ++iy) {
         const double dy = cen[R + iy] - qc[1];
         const double dxy = dx * dx + dy * dy;
         for (int iz = lo[2]; iz < lo[2] + n[2]; ++iz) {
           const double dz = cen[2 * R + iz] - qc[2];
-          hits += (dxy + dz * dz) < t2 ? 1u : 0u;
+          c += (dxy + dz * dz) < t2 ? 1u : 0u;
         }
       }
+      return c;
+    };
+    if (W <= 8 && pre_ok) {
+      // The usual case (a reach of up to 8 cells per axis) is decided in f32 wherever f32 can decide it.  The offsets are formed in f64 as
+      // above and THEN rounded; with dy2 = fl(dyf^2), dzt = fl(fl(dzf^2) - fl(t2)) kept in registers (cells past the range carry +inf),
+      // a cell costs d = fl(fl(dx2 + dy2) + dzt), its sign bit and a running minimum of |d| -- no compare-to-scalar, no dependent LDS
+      // read (the plain loops ran at ~ 380 cycles per test per wave).  |d - (R - t2)| <= 2^-24 (6 R + 2 t2) for the exact squared
+      // distance R (three squares of values with 2^-24 relative error, their product roundings, two sums, the rounding of t2 and of the
+      // difference), and the f64 value of the predicate differs from R by 2^-51 R: below R = 2 t2 that is < 2^-20 t2, above it far less
+      // than R - t2.  So sign(d) IS the predicate whenever |d| > 2^-18 t2; a plane holding a cell inside that band (about one plane in
+      // 10^4 per lane) is recounted exactly.
+      float dy2[8], dzt[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float dy = (float)(cen[R + min(lo[1] + k, R - 1)] - qc[1]), dz = (float)(cen[2 * R + min(lo[2] + k, R - 1)] - qc[2]);
+        dy2[k] = k < min(n[1], W) ? dy * dy : __builtin_inff();          // (a hit lies in the first W cells of a range: see below)
+        dzt[k] = k < min(n[2], W) ? dz * dz - t2_f : __builtin_inff();
+      }
+      for (int ix = lo[0]; ix < lo[0] + n[0]; ++ix) {
+        const float dx = (float)(cen[ix] - qc[0]);
+        const float dx2 = dx * dx;
+        unsigned cnt = 0;
+        float near = __builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dxy = dx2 + dy2[j];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float d = dxy + dzt[k];
+            cnt += __float_as_uint(d) >> 31;
+            near = fminf(near, fabsf(d));
+          }
+        }
+        hits += near > t2_band ? cnt : plane_exact(ix);
+      }
+    } else {
+      for (int ix = lo[0]; ix < lo[0] + n[0]; ++ix) hits += plane_exact(ix);
     }
     // hits can only lie in the first W cells of a conservative range (it is at most one cell wider than W on its far side)
     for (int ix = lo[0]; ix < lo[0] + min(n[0], W); ++ix) atomicAdd(&hist[ix], 1u);
