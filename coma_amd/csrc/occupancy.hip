@@ -317,7 +317,15 @@ __global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
       nxt = OccItem{r.x, r.y, r.z, r.pack | (it & 0xffff0000u)};
     }
   };
+  // bounds of the row after next are requested a whole row early: the chain plane_off -> items -> record is three dependent global
+  // loads, and with the store queues full each of them costs microseconds
+  unsigned p0 = 0, p1 = 0;
+  auto bounds_ahead = [&](int hh) {
+    p0 = plane_off[(int64_t)hh * (R + 1) + x0];
+    p1 = plane_off[(int64_t)hh * (R + 1) + x0 + np];
+  };
   if (h_lo < h_hi) { bounds(h_lo); fetch(h_lo, o0); }
+  if (h_lo + 1 < h_hi) bounds_ahead(h_lo + 1);
   __syncthreads();
   for (int h = h_lo; h < h_hi; ++h) {
     const unsigned b0 = o0, b1 = o1;
@@ -386,7 +394,8 @@ __global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
       }
       __syncthreads();
     }
-    if (h + 1 < h_hi) { bounds(h + 1); fetch(h + 1, o0); }
+    if (h + 1 < h_hi) { o0 = p0; o1 = p1; fetch(h + 1, o0); }
+    if (h + 2 < h_hi) bounds_ahead(h + 2);
     // ---- sweep: normalise, store the slab of row h, fold into the running maximum, leave the counters zero
     const float rs = rowsum[h];
     const bool sel = !select || select[h];
