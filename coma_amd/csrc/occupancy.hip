@@ -139,6 +139,8 @@ __global__ __launch_bounds__(256) void occupancy_norm_max4_kernel(float* __restr
 // monotone, so "sqrt(x) < thres" is EXACTLY "x < T2" with T2 = the smallest double whose square root is >= thres (found on the
 // host by stepping ulps) -- same bits, no f64 sqrt per candidate.
 constexpr int kFusedThreads = 512;
+constexpr int kFusedWavesPerSimd = 4;                            // __launch_bounds__ below: <= 128 VGPRs, two workgroups of 8 waves per CU
+constexpr int kFusedResident = 256 * (kFusedWavesPerSimd * 4 / (kFusedThreads / 64));   // workgroups the chip holds at once
 constexpr int kFusedMaxChunks = 5;                               // 8-cell chunks per thread -> slabs of <= 20480 cells
 constexpr int kFusedMaxCells = kFusedThreads * kFusedMaxChunks * 8;
 constexpr int kFusedMaxWindow = 16;                              // candidate cells per axis the fused pass accepts (scale_tolerance <= 7)
@@ -146,7 +148,6 @@ constexpr size_t occ_align256(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr int kFusedListCap = 512;                               // items of one (row, slab) staged per round (8 KB of LDS)
 
 // per (row, sample): the position (f32, as given) and where its candidate window starts along y and z
-struct OccRec { float x, y, z; unsigned pack; };                 // pack: lo_y | lo_z << 8
 // a (sample, x-plane) incidence as the fused pass stages it in LDS: the record + the plane
 struct OccItem { float x, y, z; unsigned pack; };                // pack: lo_y | lo_z << 8 | plane << 16
 
@@ -167,7 +168,7 @@ __device__ __forceinline__ void axis_range(double qc, double thres, double c0, d
 // atomics).  Order inside a bucket is whatever the atomics give; the counts do not depend on it.
 __global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __restrict__ q, int S, int H, int R, int W,
                                                                 const double* __restrict__ centers, double voxel, double thres,
-                                                                double t2, OccRec* __restrict__ rec, unsigned* __restrict__ items,
+                                                                double t2, OccItem* __restrict__ items,
                                                                 unsigned* __restrict__ plane_off, float* __restrict__ rowsum) {
   __shared__ unsigned part[4];
   __shared__ unsigned hist[256], base[257];
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __r
   for (int p = threadIdx.x; p <= R; p += 256) plane_off[(int64_t)h * (R + 1) + p] = base[p];
   hist[threadIdx.x] = 0u;                                         // now the per-plane cursors
   __syncthreads();
-  unsigned* row_items = items + (int64_t)h * S * W;
+  OccItem* row_items = items + (int64_t)h * S * W;
   for (int s = threadIdx.x; s < S; s += 256) {
     const float* qp = q + ((int64_t)s * H + h) * 3;
     const float fx = qp[0], fy = qp[1], fz = qp[2];
@@ -263,16 +264,18 @@ __global__ __launch_bounds__(256) void occupancy_rowprep_kernel(const float* __r
     axis_range((double)fy, thres, cen[R], inv, R, lo[1], n[1]);
     axis_range((double)fz, thres, cen[2 * R], inv, R, lo[2], n[2]);
     const bool empty = n[0] <= 0 || n[1] <= 0 || n[2] <= 0;
-    rec[(int64_t)h * S + s] = OccRec{fx, fy, fz, empty ? 0u : ((unsigned)lo[1] | ((unsigned)lo[2] << 8))};
     if (empty) continue;
-    for (int ix = lo[0]; ix < lo[0] + min(n[0], W); ++ix) row_items[base[ix] + atomicAdd(&hist[ix], 1u)] = (unsigned)s | ((unsigned)ix << 16);
+    // one complete 16-byte incidence per (sample, x-plane): the fused pass reads its slab's bucket with ONE coalesced load per item
+    // (r3 first kept 4-byte (sample | plane) words + one record per (row, sample): a dependent gather, i.e. one more global latency per row)
+    const unsigned yz = (unsigned)lo[1] | ((unsigned)lo[2] << 8);
+    for (int ix = lo[0]; ix < lo[0] + min(n[0], W); ++ix) row_items[base[ix] + atomicAdd(&hist[ix], 1u)] = OccItem{fx, fy, fz, yz | ((unsigned)ix << 16)};
   }
 }
 
 // pass 2.  Counters are 16-bit halves of LDS words (a cell sees at most S < 65536 hits per row), so a 128 x 128 plane is 32 KB
 // and three workgroups share a CU: one's candidate tests (VALU / LDS) run under another's slab stores (HBM).
-__global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
-    const OccRec* __restrict__ rec, const unsigned* __restrict__ items, const unsigned* __restrict__ plane_off, const float* __restrict__ rowsum,
+__global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_fused_kernel(
+    const OccItem* __restrict__ items, const unsigned* __restrict__ plane_off, const float* __restrict__ rowsum,
     const uint8_t* __restrict__ select, int S, int H, int R, int P, int W, int groups, int write_raw,
     const double* __restrict__ centers, double voxel, double thres, double t2, float* __restrict__ counts,
     float* __restrict__ partial) {
@@ -312,9 +315,8 @@ __global__ __launch_bounds__(kFusedThreads, 4) void occupancy_fused_kernel(
   auto fetch = [&](int hh, unsigned i0) {
     const unsigned i = i0 + threadIdx.x;
     if (i < o1) {
-      const unsigned it = items[(int64_t)hh * S * W + i];                       // sample | plane << 16
-      const OccRec r = rec[(int64_t)hh * S + (it & 0xffffu)];
-      nxt = OccItem{r.x, r.y, r.z, r.pack | (it & 0xffff0000u)};
+      const float4 v = reinterpret_cast<const float4*>(items)[(int64_t)hh * S * W + i];
+      nxt.x = v.x; nxt.y = v.y; nxt.z = v.z; nxt.pack = __float_as_uint(v.w);
     }
   };
   // bounds of the row after next are requested a whole row early: the chain plane_off -> items -> record is three dependent global
@@ -480,9 +482,8 @@ extern "C" int coma_occupancy_reduce(float* counts, const uint8_t* select, int H
 }
 
 
-// workspace layout: [rec: H * S records | items: H * S * window words | plane_off: H * (R + 1) words | partial maxima: groups * R^3 f32]
-static size_t occ_ws_rec(int S, int H) { return occ_align256((size_t)S * H * sizeof(OccRec)); }
-static size_t occ_ws_items(int S, int H, int window) { return occ_align256((size_t)S * H * window * sizeof(unsigned)); }
+// workspace layout: [items: H * S * window 16-byte incidences | plane_off: H * (R + 1) words | partial maxima: groups * R^3 f32]
+static size_t occ_ws_items(int S, int H, int window) { return occ_align256((size_t)S * H * window * sizeof(OccItem)); }
 static size_t occ_ws_off(int H, int R) { return occ_align256((size_t)H * (R + 1) * sizeof(unsigned)); }
 static int occ_pow2_window(int window) {
   if (window > 2 && (window & (window - 1))) { int w2 = 1; while (w2 < window) w2 <<= 1; window = w2; }   // cell decode by shifts
@@ -496,9 +497,9 @@ extern "C" size_t coma_occupancy_fused_workspace_bytes(int S, int H, int R, int 
   const int P = kFusedMaxCells / (R * R);
   if (P < 1) return 0;
   const int slabs = (R + P - 1) / P;
-  int groups = (768 + slabs - 1) / slabs;   // three resident workgroups per CU (80 VGPRs, <= 50 KB of LDS each)
+  int groups = (kFusedResident + slabs - 1) / slabs;   // every workgroup resident at once: one round, no tail
   if (groups > H) groups = H;
-  return occ_ws_rec(S, H) + occ_ws_items(S, H, window) + occ_ws_off(H, R) + (size_t)groups * R3 * sizeof(float) + 256;
+  return occ_ws_items(S, H, window) + occ_ws_off(H, R) + (size_t)groups * R3 * sizeof(float) + 256;
 }
 
 extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const double* centers, double voxel, double thres,
@@ -514,25 +515,24 @@ extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const d
   const size_t need = coma_occupancy_fused_workspace_bytes(S, H, R, window);
   if (workspace_bytes < need) return fail(COMA_E_INVALID, "coma_occupancy_fused: workspace %zu < %zu bytes", workspace_bytes, need);
   const int slabs = (R + P - 1) / P;
-  int groups = (768 + slabs - 1) / slabs;   // three resident workgroups per CU (80 VGPRs, <= 50 KB of LDS each)
+  int groups = (kFusedResident + slabs - 1) / slabs;   // every workgroup resident at once: one round, no tail
   if (groups > H) groups = H;
   const size_t lds = (((size_t)P * RR * 2 + 15) / 16) * 16 + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double);
   if (S >= 65536) return fail(COMA_E_INVALID, "coma_occupancy_fused: S=%d >= 65536 samples per call (16-bit counters)", S);
   hipStream_t st = (hipStream_t)stream;
   unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
-  OccRec* rec = reinterpret_cast<OccRec*>(wsb);
-  unsigned* items = reinterpret_cast<unsigned*>(wsb + occ_ws_rec(S, H));
-  unsigned* plane_off = reinterpret_cast<unsigned*>(wsb + occ_ws_rec(S, H) + occ_ws_items(S, H, window));
-  float* partial = reinterpret_cast<float*>(wsb + occ_ws_rec(S, H) + occ_ws_items(S, H, window) + occ_ws_off(H, R));
+  OccItem* items = reinterpret_cast<OccItem*>(wsb);
+  unsigned* plane_off = reinterpret_cast<unsigned*>(wsb + occ_ws_items(S, H, window));
+  float* partial = reinterpret_cast<float*>(wsb + occ_ws_items(S, H, window) + occ_ws_off(H, R));
   hipLaunchKernelGGL(occupancy_rowprep_kernel, dim3((unsigned)H), dim3(256), 0, st, q, S, H, R, window, centers, voxel, thres, thres_sq_cut,
-                     rec, items, plane_off, rowsum);
+                     items, plane_off, rowsum);
   static size_t lds_set = 0;                                     // the attribute is per function, not per launch: set it when it grows
   if (lds > lds_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupancy_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(COMA_E_LAUNCH, "coma_occupancy_fused: cannot reserve %zu bytes of LDS", lds);
     lds_set = lds;
   }
-  hipLaunchKernelGGL(occupancy_fused_kernel, dim3((unsigned)slabs, (unsigned)groups), dim3(kFusedThreads), lds, st, rec, items, plane_off, rowsum, select,
+  hipLaunchKernelGGL(occupancy_fused_kernel, dim3((unsigned)slabs, (unsigned)groups), dim3(kFusedThreads), lds, st, items, plane_off, rowsum, select,
                      S, H, R, P, window, groups, write_raw, centers, voxel, thres, thres_sq_cut, counts, partial);
   const int64_t R3 = (int64_t)R * RR;
   hipLaunchKernelGGL(occupancy_groupmax_kernel, dim3((unsigned)((R3 + 255) / 256)), dim3(256), 0, st, partial, groups, R3, out);
