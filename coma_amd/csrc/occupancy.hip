@@ -328,6 +328,8 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
   };
   if (h_lo < h_hi) { bounds(h_lo); fetch(h_lo, o0); }
   if (h_lo + 1 < h_hi) bounds_ahead(h_lo + 1);
+  float rs_next = h_lo < h_hi ? rowsum[h_lo] : 1.0f;             // row sum and selection flag of a row are requested a row early as well
+  bool sel_next = h_lo < h_hi ? (!select || select[h_lo]) : false;
   __syncthreads();
   for (int h = h_lo; h < h_hi; ++h) {
     const unsigned b0 = o0, b1 = o1;
@@ -399,8 +401,9 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
     if (h + 1 < h_hi) { o0 = p0; o1 = p1; fetch(h + 1, o0); }
     if (h + 2 < h_hi) bounds_ahead(h + 2);
     // ---- sweep: normalise, store the slab of row h, fold into the running maximum, leave the counters zero
-    const float rs = rowsum[h];
-    const bool sel = !select || select[h];
+    const float rs = rs_next;                                       // (requested a row ago)
+    const bool sel = sel_next;
+    if (h + 1 < h_hi) { rs_next = rowsum[h + 1]; sel_next = !select || select[h + 1]; }
     float4* dst = reinterpret_cast<float4*>(counts + (int64_t)h * R * RR + (int64_t)x0 * RR);
 #pragma unroll
     for (int k = 0; k < kFusedMaxChunks; ++k) {
