@@ -284,10 +284,12 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
   const int x0 = blockIdx.x * P;
   const int np = min(P, R - x0);                                 // planes of this slab
   const int cells = np * RR;                                     // multiple of 4 whenever RR is (checked on the host)
-  unsigned* cnt = reinterpret_cast<unsigned*>(smem);
+  // two counter buffers: while the slab of row h is swept out of one, the candidate tests of row h + 1 run into the other
+  unsigned* cnt_cur = reinterpret_cast<unsigned*>(smem);
   const size_t cnt_bytes = (((size_t)P * RR * 2 + 15) / 16) * 16;
-  OccItem* list = reinterpret_cast<OccItem*>(smem + cnt_bytes);
-  double* cen = reinterpret_cast<double*>(smem + cnt_bytes + (size_t)kFusedListCap * sizeof(OccItem));   // [3][R]
+  unsigned* cnt_nxt = reinterpret_cast<unsigned*>(smem + cnt_bytes);
+  OccItem* list = reinterpret_cast<OccItem*>(smem + 2 * cnt_bytes);
+  double* cen = reinterpret_cast<double*>(smem + 2 * cnt_bytes + (size_t)kFusedListCap * sizeof(OccItem));   // [3][R]
   for (int i = threadIdx.x; i < 3 * R; i += kFusedThreads) cen[i] = centers[i];
   const int g = blockIdx.y;
   const int h_lo = (int)((int64_t)H * g / groups), h_hi = (int)((int64_t)H * (g + 1) / groups);
@@ -297,14 +299,11 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
   for (int k = 0; k < kFusedMaxChunks; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) mx[k][e] = -__builtin_inff();
-  for (int i = threadIdx.x; i < n8; i += kFusedThreads) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+  for (int i = threadIdx.x; i < 2 * (int)(cnt_bytes / 16); i += kFusedThreads) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   const int WW = W * W;
   const int w_shift = __builtin_ctz(W);
   const float t2_f = (float)t2, t2_band = (float)(t2 * 0x1p-18);      // f32 pre-decision of the candidate tests (see occupancy_rowprep_kernel)
-  const bool pre_ok = t2 > 1e-30 && t2 < 1e30;
-  // The incidences of the NEXT row (its first kFusedListCap) are fetched BEFORE this row's slab is stored: a wave's loads return
-  // in order behind its own stores (vmcnt), so a load issued after the sweep would wait for the whole slab to reach HBM and
-  // serialise the test phase with the store drain (measured in r2: 13.8 k cycles per row and plane instead of ~7 k).
+  const bool fast = W == 8 && t2 > 1e-30 && t2 < 1e30;
   static_assert(kFusedListCap == kFusedThreads, "one incidence per thread and round");
   OccItem nxt = {0.f, 0.f, 0.f, 0u};
   unsigned o0 = 0, o1 = 0;                                       // [o0, o1): incidences of (row, slab) inside the row's list
@@ -319,70 +318,60 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
       nxt.x = v.x; nxt.y = v.y; nxt.z = v.z; nxt.pack = __float_as_uint(v.w);
     }
   };
-  // bounds of the row after next are requested a whole row early: the chain plane_off -> items -> record is three dependent global
-  // loads, and with the store queues full each of them costs microseconds
+  // Everything a row needs from global memory is requested one or two rows early -- the chain plane_off -> items is two dependent
+  // loads, and with the store queues full each costs microseconds: (p0, p1) are the bounds of the row after the one (o0, o1) describe.
   unsigned p0 = 0, p1 = 0;
   auto bounds_ahead = [&](int hh) {
     p0 = plane_off[(int64_t)hh * (R + 1) + x0];
     p1 = plane_off[(int64_t)hh * (R + 1) + x0 + np];
   };
-  if (h_lo < h_hi) { bounds(h_lo); fetch(h_lo, o0); }
-  if (h_lo + 1 < h_hi) bounds_ahead(h_lo + 1);
-  float rs_next = h_lo < h_hi ? rowsum[h_lo] : 1.0f;             // row sum and selection flag of a row are requested a row early as well
-  bool sel_next = h_lo < h_hi ? (!select || select[h_lo]) : false;
-  __syncthreads();
-  for (int h = h_lo; h < h_hi; ++h) {
-    const unsigned b0 = o0, b1 = o1;
-    for (unsigned i0 = b0; i0 < b1; i0 += kFusedListCap) {
-      if (i0 > b0) fetch(h, i0);
-      const int n_items = (int)min((unsigned)kFusedListCap, b1 - i0);
-      if ((int)threadIdx.x < n_items) list[threadIdx.x] = nxt;
-      __syncthreads();
-      if (W == 8 && pre_ok) {
-        // ---- candidate tests, usual window: a lane takes one (incidence, y-row) = 8 consecutive z-cells.  The x / y offsets are formed once,
-        // the predicate is decided in f32 exactly as in the preparation pass (offsets in f64, then rounded; sign of
-        // fl(fl(dx2 + dy2) + fl(dz2 - t2)) unless it lies inside the 2^-18 t2 band, where the cell is re-evaluated in f64), and the hits of
-        // two cells that share a counter word leave as ONE LDS atomic: 10 LDS reads and <= 5 atomics per 8 cells instead of 32 and <= 8.
-        const int total = n_items << 3;
-        for (int w = threadIdx.x; w < total; w += kFusedThreads) {
-          const OccItem m = list[w >> 3];
-          const int iy = (int)(m.pack & 0xffu) + (w & 7), iz0 = (int)((m.pack >> 8) & 0xffu), ix = (int)(m.pack >> 16);
-          if (iy >= R) continue;
-          const double dx = cen[ix] - (double)m.x, dy = cen[R + iy] - (double)m.y;
-          const float dxf = (float)dx, dyf = (float)dy;
-          const float dxy = dxf * dxf + dyf * dyf;
-          unsigned hm = 0, amb = 0;
-          const double mz = (double)m.z;
+  // candidate tests of the staged incidences list[0 .. n_items) into counter buffer `c`, trips t = t0, t0 + dt, ... of kFusedThreads lanes
+  auto tests = [&](unsigned* c, int n_items, int t0, int dt) {
+    if (fast) {
+      // usual window: a lane takes one (incidence, y-row) = 8 consecutive z-cells.  The x / y offsets are formed once, the predicate
+      // is decided in f32 exactly as in the preparation pass (offsets in f64, then rounded; sign of fl(fl(dx2 + dy2) + fl(dz2 - t2))
+      // unless it lies inside the 2^-18 t2 band, where the cell is re-evaluated in f64), and the hits of two cells that share a
+      // counter word leave as ONE LDS atomic: 10 LDS reads and <= 5 atomics per 8 cells instead of 32 and <= 8.
+      const int total = n_items << 3;
+      for (int w = threadIdx.x + t0 * kFusedThreads; w < total; w += dt * kFusedThreads) {
+        const OccItem m = list[w >> 3];
+        const int iy = (int)(m.pack & 0xffu) + (w & 7), iz0 = (int)((m.pack >> 8) & 0xffu), ix = (int)(m.pack >> 16);
+        if (iy >= R) continue;
+        const double dx = cen[ix] - (double)m.x, dy = cen[R + iy] - (double)m.y;
+        const float dxf = (float)dx, dyf = (float)dy;
+        const float dxy = dxf * dxf + dyf * dyf;
+        unsigned hm = 0, amb = 0;
+        const double mz = (double)m.z;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {                                              // branch-free: the eight LDS reads and chains overlap
-            const float dzf = (float)(cen[2 * R + min(iz0 + k, R - 1)] - mz);
-            const float d = dxy + (dzf * dzf - t2_f);
-            hm |= (__float_as_uint(d) >> 31) << k;
-            amb |= (fabsf(d) <= t2_band ? 1u : 0u) << k;
-          }
-          if (amb) {                                                                  // (rare) the reference's own arithmetic for those cells
-            for (int k = 0; k < 8; ++k)
-              if ((amb >> k) & 1u) {
-                const double dz = cen[2 * R + min(iz0 + k, R - 1)] - mz;
-                hm = (hm & ~(1u << k)) | ((((dx * dx + dy * dy) + dz * dz) < t2 ? 1u : 0u) << k);
-              }
-          }
-          hm &= iz0 + 8 <= R ? 0xffu : (0xffu >> (iz0 + 8 - R));                      // cells past the grid edge
-          if (hm) {
-            const int cell = (ix - x0) * RR + iy * R + iz0;
-            const unsigned hs = hm << (cell & 1);                                      // bit 2 j (+ 1): low (high) half of word j
-            unsigned* wp = cnt + (cell >> 1);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-              const unsigned v = ((hs >> (2 * j)) & 1u) | (((hs >> (2 * j + 1)) & 1u) << 16);
-              if (v) atomicAdd(wp + j, v);
+        for (int k = 0; k < 8; ++k) {                                              // branch-free: the eight LDS reads and chains overlap
+          const float dzf = (float)(cen[2 * R + min(iz0 + k, R - 1)] - mz);
+          const float d = dxy + (dzf * dzf - t2_f);
+          hm |= (__float_as_uint(d) >> 31) << k;
+          amb |= (fabsf(d) <= t2_band ? 1u : 0u) << k;
+        }
+        if (amb) {                                                                  // (rare) the reference's own arithmetic for those cells
+          for (int k = 0; k < 8; ++k)
+            if ((amb >> k) & 1u) {
+              const double dz = cen[2 * R + min(iz0 + k, R - 1)] - mz;
+              hm = (hm & ~(1u << k)) | ((((dx * dx + dy * dy) + dz * dz) < t2 ? 1u : 0u) << k);
             }
+        }
+        hm &= iz0 + 8 <= R ? 0xffu : (0xffu >> (iz0 + 8 - R));                      // cells past the grid edge
+        if (hm) {
+          const int cell = (ix - x0) * RR + iy * R + iz0;
+          const unsigned hs = hm << (cell & 1);                                      // bit 2 j (+ 1): low (high) half of word j
+          unsigned* wp = c + (cell >> 1);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const unsigned v = ((hs >> (2 * j)) & 1u) | (((hs >> (2 * j + 1)) & 1u) << 16);
+            if (v) atomicAdd(wp + j, v);
           }
         }
-      } else {
-      // ---- candidate tests: (incidence, window cell), every lane busy; W is a power of two (host), so the decode is shifts
+      }
+    } else {
+      // (incidence, window cell), every lane busy; W is a power of two (host), so the decode is shifts
       const int total = n_items << (2 * w_shift);
-      for (int w = threadIdx.x; w < total; w += kFusedThreads) {
+      for (int w = threadIdx.x + t0 * kFusedThreads; w < total; w += dt * kFusedThreads) {
         const OccItem m = list[w >> (2 * w_shift)];
         const int wc = w & (WW - 1);
         const int iy = (int)(m.pack & 0xffu) + (wc >> w_shift), iz = (int)((m.pack >> 8) & 0xffu) + (wc & (W - 1));
@@ -391,26 +380,66 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
           const double dx = cen[ix] - (double)m.x, dy = cen[R + iy] - (double)m.y, dz = cen[2 * R + iz] - (double)m.z;
           if (((dx * dx + dy * dy) + dz * dz) < t2) {
             const int cell = (ix - x0) * RR + iy * R + iz;
-            atomicAdd(&cnt[cell >> 1], 1u << ((cell & 1) * 16));
+            atomicAdd(&c[cell >> 1], 1u << ((cell & 1) * 16));
           }
         }
       }
-      }
+    }
+  };
+  // every round of row hh ([b0, b1), the first kFusedListCap incidences already in `nxt`) into `c`, nothing overlapped
+  auto all_rounds = [&](unsigned* c, int hh, unsigned b0, unsigned b1) {
+    for (unsigned i0 = b0; i0 < b1; i0 += kFusedListCap) {
+      if (i0 > b0) fetch(hh, i0);
+      const int n_items = (int)min((unsigned)kFusedListCap, b1 - i0);
+      if ((int)threadIdx.x < n_items) list[threadIdx.x] = nxt;
+      __syncthreads();
+      tests(c, n_items, 0, 1);
       __syncthreads();
     }
-    if (h + 1 < h_hi) { o0 = p0; o1 = p1; fetch(h + 1, o0); }
-    if (h + 2 < h_hi) bounds_ahead(h + 2);
+  };
+  float rs_next = 1.0f;
+  bool sel_next = false;
+  if (h_lo < h_hi) {
+    bounds(h_lo);
+    fetch(h_lo, o0);
+    if (h_lo + 1 < h_hi) bounds_ahead(h_lo + 1);
+    rs_next = rowsum[h_lo];                                      // row sum and selection flag: requested a row early as well
+    sel_next = !select || select[h_lo];
+  }
+  __syncthreads();
+  if (h_lo < h_hi) {
+    all_rounds(cnt_cur, h_lo, o0, o1);                           // the first row has nothing to hide under
+    if (h_lo + 1 < h_hi) { o0 = p0; o1 = p1; fetch(h_lo + 1, o0); }
+    if (h_lo + 2 < h_hi) bounds_ahead(h_lo + 2);
+  }
+  // Invariant at the top of iteration h: cnt_cur holds the complete counts of row h and cnt_nxt is zero; (o0, o1) and `nxt` describe
+  // row h + 1 (its bounds and its first incidences), (p0, p1) row h + 2.
+  for (int h = h_lo; h < h_hi; ++h) {
+    const bool have_next = h + 1 < h_hi;
+    const unsigned nb0 = o0, nb1 = o1;
+    // A row whose slab bucket fits one round (the usual case) is tested UNDER this row's sweep: a wave that has handed its stores to a
+    // full memory pipeline stalls at the next store, so test trips are placed between the store chunks of the same wave -- the queue
+    // drains while the wave computes.  (The sweep alone ran at the store rate, the tests came on top: 1.7 M + 3.7 M cycles per
+    // workgroup at the config-5 share, profiles/r03_notes.md 13.)
+    const bool overlap = have_next && nb1 - nb0 <= (unsigned)kFusedListCap;
+    const int n_over = overlap ? (int)(nb1 - nb0) : 0;
+    if ((int)threadIdx.x < n_over) list[threadIdx.x] = nxt;
+    __syncthreads();
+    if (overlap) {
+      if (h + 2 < h_hi) { o0 = p0; o1 = p1; fetch(h + 2, o0); }
+      if (h + 3 < h_hi) bounds_ahead(h + 3);
+    }
     // ---- sweep: normalise, store the slab of row h, fold into the running maximum, leave the counters zero
-    const float rs = rs_next;                                       // (requested a row ago)
+    const float rs = rs_next;
     const bool sel = sel_next;
-    if (h + 1 < h_hi) { rs_next = rowsum[h + 1]; sel_next = !select || select[h + 1]; }
+    if (have_next) { rs_next = rowsum[h + 1]; sel_next = !select || select[h + 1]; }
     float4* dst = reinterpret_cast<float4*>(counts + (int64_t)h * R * RR + (int64_t)x0 * RR);
 #pragma unroll
     for (int k = 0; k < kFusedMaxChunks; ++k) {
       const int i = threadIdx.x + k * kFusedThreads;
       if (i < n8) {
-        const uint4 c4 = reinterpret_cast<uint4*>(cnt)[i];
-        reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+        const uint4 c4 = reinterpret_cast<uint4*>(cnt_cur)[i];
+        reinterpret_cast<uint4*>(cnt_cur)[i] = make_uint4(0, 0, 0, 0);
         const unsigned w[4] = {c4.x, c4.y, c4.z, c4.w};
         float c[8], v[8];
 #pragma unroll
@@ -425,8 +454,15 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
           for (int e = 0; e < 8; ++e) mx[k][e] = (v[e] > mx[k][e] || v[e] != v[e]) ? v[e] : mx[k][e];
         }
       }
+      if (n_over) tests(cnt_nxt, n_over, k, kFusedMaxChunks);      // trips k, k + 4, ... of the next row
     }
     __syncthreads();
+    if (have_next && !overlap) {                                   // a crowded (row, slab): all its rounds now, as for the first row
+      all_rounds(cnt_nxt, h + 1, nb0, nb1);
+      if (h + 2 < h_hi) { o0 = p0; o1 = p1; fetch(h + 2, o0); }
+      if (h + 3 < h_hi) bounds_ahead(h + 3);
+    }
+    unsigned* t = cnt_cur; cnt_cur = cnt_nxt; cnt_nxt = t;
   }
   float4* pout = reinterpret_cast<float4*>(partial + (int64_t)g * R * RR + (int64_t)x0 * RR);
 #pragma unroll
@@ -520,7 +556,7 @@ extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const d
   const int slabs = (R + P - 1) / P;
   int groups = (kFusedResident + slabs - 1) / slabs;   // every workgroup resident at once: one round, no tail
   if (groups > H) groups = H;
-  const size_t lds = (((size_t)P * RR * 2 + 15) / 16) * 16 + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double);
+  const size_t lds = 2 * ((((size_t)P * RR * 2 + 15) / 16) * 16) + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double);   // two counter buffers
   if (S >= 65536) return fail(COMA_E_INVALID, "coma_occupancy_fused: S=%d >= 65536 samples per call (16-bit counters)", S);
   hipStream_t st = (hipStream_t)stream;
   unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
