@@ -290,6 +290,9 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
   unsigned* cnt_nxt = reinterpret_cast<unsigned*>(smem + cnt_bytes);
   OccItem* list = reinterpret_cast<OccItem*>(smem + 2 * cnt_bytes);
   double* cen = reinterpret_cast<double*>(smem + 2 * cnt_bytes + (size_t)kFusedListCap * sizeof(OccItem));   // [3][R]
+  // quotients count / rowsum of the row being swept for counts 0 .. 255 (nearly every cell): the sweep looked like a store loop but
+  // was bound by its 32 correctly rounded f32 divisions per thread and row; one division per thread and a table read per cell instead
+  float* qt = reinterpret_cast<float*>(smem + 2 * cnt_bytes + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double));
   for (int i = threadIdx.x; i < 3 * R; i += kFusedThreads) cen[i] = centers[i];
   const int g = blockIdx.y;
   const int h_lo = (int)((int64_t)H * g / groups), h_hi = (int)((int64_t)H * (g + 1) / groups);
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
     const bool overlap = have_next && nb1 - nb0 <= (unsigned)kFusedListCap;
     const int n_over = overlap ? (int)(nb1 - nb0) : 0;
     if ((int)threadIdx.x < n_over) list[threadIdx.x] = nxt;
+    if (threadIdx.x < 256) qt[threadIdx.x] = (float)threadIdx.x / rs_next;      // rs_next is still row h's sum here (0 / 0 = NaN as in the reference)
     __syncthreads();
     if (overlap) {
       if (h + 2 < h_hi) { o0 = p0; o1 = p1; fetch(h + 2, o0); }
@@ -441,11 +445,16 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
         const uint4 c4 = reinterpret_cast<uint4*>(cnt_cur)[i];
         reinterpret_cast<uint4*>(cnt_cur)[i] = make_uint4(0, 0, 0, 0);
         const unsigned w[4] = {c4.x, c4.y, c4.z, c4.w};
+        unsigned cu[8];
         float c[8], v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { c[2 * e] = (float)(w[e] & 0xffffu); c[2 * e + 1] = (float)(w[e] >> 16); }
+        for (int e = 0; e < 4; ++e) { cu[2 * e] = w[e] & 0xffffu; cu[2 * e + 1] = w[e] >> 16; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = c[e] / rs;               // 0/0 = NaN as in the reference
+        for (int e = 0; e < 8; ++e) {
+          c[e] = (float)cu[e];
+          // the same correctly rounded quotient either way
+          v[e] = cu[e] < 256u ? qt[cu[e]] : c[e] / rs;
+        }
         const bool second = i * 8 + 4 < cells;
         dst[2 * i] = write_raw ? make_float4(c[0], c[1], c[2], c[3]) : make_float4(v[0], v[1], v[2], v[3]);
         if (second) dst[2 * i + 1] = write_raw ? make_float4(c[4], c[5], c[6], c[7]) : make_float4(v[4], v[5], v[6], v[7]);
@@ -556,7 +565,7 @@ extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const d
   const int slabs = (R + P - 1) / P;
   int groups = (kFusedResident + slabs - 1) / slabs;   // every workgroup resident at once: one round, no tail
   if (groups > H) groups = H;
-  const size_t lds = 2 * ((((size_t)P * RR * 2 + 15) / 16) * 16) + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double);   // two counter buffers
+  const size_t lds = 2 * ((((size_t)P * RR * 2 + 15) / 16) * 16) + (size_t)kFusedListCap * sizeof(OccItem) + (size_t)3 * R * sizeof(double) + 256 * sizeof(float);   // two counter buffers, quotient table
   if (S >= 65536) return fail(COMA_E_INVALID, "coma_occupancy_fused: S=%d >= 65536 samples per call (16-bit counters)", S);
   hipStream_t st = (hipStream_t)stream;
   unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
