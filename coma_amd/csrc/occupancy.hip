@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
   for (int i = threadIdx.x; i < 3 * R; i += kFusedThreads) cen[i] = centers[i];
   const int g = blockIdx.y;
   const int h_lo = (int)((int64_t)H * g / groups), h_hi = (int)((int64_t)H * (g + 1) / groups);
-  const int n8 = (cells + 7) >> 3;                               // 8-cell chunks; cells % 4 == 0, so a chunk is whole or its first half
+  const int n4 = cells >> 2;                                     // quads of cells (cells % 4 == 0, checked on the host)
   float mx[kFusedMaxChunks][8];
 #pragma unroll
   for (int k = 0; k < kFusedMaxChunks; ++k)
@@ -440,11 +440,16 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
     float4* dst = reinterpret_cast<float4*>(counts + (int64_t)h * R * RR + (int64_t)x0 * RR);
 #pragma unroll
     for (int k = 0; k < kFusedMaxChunks; ++k) {
-      const int i = threadIdx.x + k * kFusedThreads;
-      if (i < n8) {
-        const uint4 c4 = reinterpret_cast<uint4*>(cnt_cur)[i];
-        reinterpret_cast<uint4*>(cnt_cur)[i] = make_uint4(0, 0, 0, 0);
-        const unsigned w[4] = {c4.x, c4.y, c4.z, c4.w};
+      // a thread owns two QUADS of cells per chunk, a = tid + 1024 k and b = a + 512: every store instruction of a wave then covers
+      // 1 KB of contiguous memory (8 consecutive cells per thread made two half-used instructions of it)
+      const int a = threadIdx.x + k * 2 * kFusedThreads, b = a + kFusedThreads;
+      if (a < n4) {
+        const bool second = b < n4;
+        const uint2 ca = reinterpret_cast<uint2*>(cnt_cur)[a];
+        const uint2 cb = second ? reinterpret_cast<uint2*>(cnt_cur)[b] : make_uint2(0, 0);
+        reinterpret_cast<uint2*>(cnt_cur)[a] = make_uint2(0, 0);
+        if (second) reinterpret_cast<uint2*>(cnt_cur)[b] = make_uint2(0, 0);
+        const unsigned w[4] = {ca.x, ca.y, cb.x, cb.y};
         unsigned cu[8];
         float c[8], v[8];
 #pragma unroll
@@ -455,9 +460,8 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
           // the same correctly rounded quotient either way
           v[e] = cu[e] < 256u ? qt[cu[e]] : c[e] / rs;
         }
-        const bool second = i * 8 + 4 < cells;
-        dst[2 * i] = write_raw ? make_float4(c[0], c[1], c[2], c[3]) : make_float4(v[0], v[1], v[2], v[3]);
-        if (second) dst[2 * i + 1] = write_raw ? make_float4(c[4], c[5], c[6], c[7]) : make_float4(v[4], v[5], v[6], v[7]);
+        dst[a] = write_raw ? make_float4(c[0], c[1], c[2], c[3]) : make_float4(v[0], v[1], v[2], v[3]);
+        if (second) dst[b] = write_raw ? make_float4(c[4], c[5], c[6], c[7]) : make_float4(v[4], v[5], v[6], v[7]);
         if (sel) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) mx[k][e] = (v[e] > mx[k][e] || v[e] != v[e]) ? v[e] : mx[k][e];
@@ -476,11 +480,9 @@ __global__ __launch_bounds__(kFusedThreads, kFusedWavesPerSimd) void occupancy_f
   float4* pout = reinterpret_cast<float4*>(partial + (int64_t)g * R * RR + (int64_t)x0 * RR);
 #pragma unroll
   for (int k = 0; k < kFusedMaxChunks; ++k) {
-    const int i = threadIdx.x + k * kFusedThreads;
-    if (i < n8) {
-      pout[2 * i] = make_float4(mx[k][0], mx[k][1], mx[k][2], mx[k][3]);
-      if (i * 8 + 4 < cells) pout[2 * i + 1] = make_float4(mx[k][4], mx[k][5], mx[k][6], mx[k][7]);
-    }
+    const int a = threadIdx.x + k * 2 * kFusedThreads, b = a + kFusedThreads;
+    if (a < n4) pout[a] = make_float4(mx[k][0], mx[k][1], mx[k][2], mx[k][3]);
+    if (b < n4) pout[b] = make_float4(mx[k][4], mx[k][5], mx[k][6], mx[k][7]);
   }
 }
 
