@@ -425,6 +425,30 @@ def test_occupancy_config5_share_properties(dev, hip_lib):
     assert (_np(field)[None] >= norm_rows).all()
 
 
+@pytest.mark.parametrize("tol", [0.4, 1.0, 2.5, 3.0, 4.5, 7.0])
+def test_occupancy_fused_pass_equals_the_atomic_route_for_every_window(tol):
+    """scale_tolerance sets the candidate window (3 ... 16 cells, rounded up to 4 / 8 / 16 by the kernel): the fused pass -- its f32
+    pre-decided row-of-8 tests at a window of 8, the generic per-cell tests otherwise, single- and multi-round rows -- against the
+    splat + reduce route (global atomics, plain f64 tests) bit for bit, raw counts and field; samples clustered so that some
+    (row, slab) buckets exceed one round of 512 incidences."""
+    from utils.coma_occupancy import ComA_Occupancy
+    DEV = "cuda:0"
+    H, R, S = 12, 32, 700
+    mk = lambda: ComA_Occupancy(scale_tolerance=tol, human_res=H, obj_res=1, normal_res=0, spatial_res=R, device=DEV)
+    g = torch.Generator().manual_seed(int(tol * 10))
+    centre = torch.rand([1, H, 3], generator=g) * 1.6 - 0.8
+    q = torch.cat([centre + 0.05 * torch.randn([S - 100, H, 3], generator=g),            # crowded buckets
+                   torch.rand([100, H, 3], generator=g) * 2.8 - 1.4]).to(DEV).contiguous()  # + uniform ones, some outside the grid
+    a, b = mk(), mk()
+    a.accumulate_device(q)                      # staged -> fused pass
+    b.accumulate_device(q, lazy=False)          # atomic splat
+    fa, fb = a.return_aggregated_spatial_grids(), b.return_aggregated_spatial_grids()
+    assert torch.equal(torch.nan_to_num(fa, nan=-7.0), torch.nan_to_num(fb, nan=-7.0))
+    ga, gb = a.spatial_occupancy_grids, b.spatial_occupancy_grids
+    assert torch.equal(torch.nan_to_num(ga, nan=-7.0), torch.nan_to_num(gb, nan=-7.0))
+    assert float(torch.nan_to_num(ga, nan=0.0).sum()) > 0
+
+
 def test_occupancy_reset_defers_the_memset_without_leaking_old_counts():
     """reset() only marks the grid as zero: the fused pass overwrites every cell, every other route zeroes first."""
     from utils.coma_occupancy import ComA_Occupancy
