@@ -127,17 +127,18 @@ __global__ __launch_bounds__(256) void occupancy_norm_max4_kernel(float* __restr
 // Structure B of SURVEY.md 8d: splat + normalise + max over humans in one pass, the grid written ONCE.
 // replaces: utils/coma_occupancy.py:272-312 end to end (aggregate every cached sample into a zero grid, then
 //           return_aggregated_spatial_grids): afterwards counts holds the NORMALISED grid exactly as the reference leaves it.
-//   pass 1  occupancy_rowprep_kernel   one workgroup per human vertex: per sample the candidate range along x and the
-//                                       number of hits (-> row sum, exact integer), one 16-byte record per (vertex, sample)
-//   pass 2  occupancy_fused_kernel     workgroup = (slab of P x-planes, row group): for every row of the group the slab lives in
-//                                       LDS as u32 counters, the row's samples that reach the slab are compacted, their
-//                                       (W x W) candidate windows tested at full lane occupancy, then one sweep converts /
-//                                       normalises / stores the slab (coalesced 16-byte stores) and folds it into a running
-//                                       maximum each thread keeps in registers for its own cells
+//   pass 1  occupancy_rowprep_kernel   one workgroup per human vertex: the number of hits of every sample (-> row sum, exact integer) and
+//                                       the row's (sample, x-plane) incidences bucketed by plane, 16 bytes each
+//   pass 2  occupancy_fused_kernel     workgroup = (slab of P x-planes, row group), all resident at once: for every row of the group the
+//                                       slab lives in LDS as 16-bit counters (two buffers), the incidences of its bucket are tested a
+//                                       y-row of 8 z-cells per lane -- the tests of row h + 1 between the store chunks of row h --, then
+//                                       one sweep converts / normalises (quotient table) / stores the slab (1 KB per wave store) and
+//                                       folds it into a running maximum each thread keeps in registers for its own cells
 //   pass 3  occupancy_groupmax_kernel  NaN-propagating max over the row groups
 // The distance test is the reference's: d = sqrt((dx^2 + dy^2) + dz^2) < thres in f64.  sqrt is correctly rounded, hence
 // monotone, so "sqrt(x) < thres" is EXACTLY "x < T2" with T2 = the smallest double whose square root is >= thres (found on the
-// host by stepping ulps) -- same bits, no f64 sqrt per candidate.
+// host by stepping ulps) -- same bits, no f64 sqrt per candidate.  Where f32 can decide "x < T2" it does (error bound at the tests below);
+// a candidate too close to T2 for that is evaluated with the f64 expression above.
 constexpr int kFusedThreads = 512;
 constexpr int kFusedWavesPerSimd = 4;                            // __launch_bounds__ below: <= 128 VGPRs, two workgroups of 8 waves per CU
 constexpr int kFusedResident = 256 * (kFusedWavesPerSimd * 4 / (kFusedThreads / 64));   // workgroups the chip holds at once
