@@ -1,3 +1,6 @@
+OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
+                        "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "
+                        "the grid written once + the incidences; the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
 #!/usr/bin/env python3
 """bench.py -- throughput of ComA's dense hot path on MI355X (contract: see the round brief).
 
@@ -373,15 +376,15 @@ def bench_occupancy(args, dev, world, rank):
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
 #   profiles/r03_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
-#   profiles/r03_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91577e6 KiB, WRITE_SIZE 3.71307e6 KiB per launch
-#   profiles/r03_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.10 GB + 2 * FETCH 0.21 GB, rowprep 2 * 0.21 + 0.09 GB,
+#   profiles/r03_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91545e6 KiB, WRITE_SIZE 3.71218e6 KiB per launch
+#   profiles/r03_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.12 GB, rowprep 2 * 0.21 + 0.23 GB,
 #                                        groupmax 0.06 GB
-UNET_GEMM_PMC_TRAFFIC_BYTES = int(162.60e6)
-OCCUPANCY_PMC_TRAFFIC_BYTES = int(12.09e9)   # fused + rowprep 12.03 GB + groupmax 0.06 GB
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(162.64e6)
+OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.96e9)   # fused 11.02 + 0.25, rowprep 0.42 + 0.23, groupmax 0.04 GB
 OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.50 GB) + occupancy_fused (11.11 GB written, "
                         "0.42 GB fetched) + occupancy_groupmax (0.06 GB) at H=1310, R=128, S=2000: the grid written once + the bucketed incidences; "
                         "the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
-CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91577e6 + 3.71307e6) * 1024)
+CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91545e6 + 3.71218e6) * 1024)
 
 
 def main():
