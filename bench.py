@@ -1,6 +1,3 @@
-OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
-                        "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "
-                        "the grid written once + the incidences; the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
 #!/usr/bin/env python3
 """bench.py -- throughput of ComA's dense hot path on MI355X (contract: see the round brief).
 
@@ -381,9 +378,9 @@ def bench_occupancy(args, dev, world, rank):
 #                                        groupmax 0.06 GB
 UNET_GEMM_PMC_TRAFFIC_BYTES = int(162.64e6)
 OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.96e9)   # fused 11.02 + 0.25, rowprep 0.42 + 0.23, groupmax 0.04 GB
-OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.50 GB) + occupancy_fused (11.11 GB written, "
-                        "0.42 GB fetched) + occupancy_groupmax (0.06 GB) at H=1310, R=128, S=2000: the grid written once + the bucketed incidences; "
-                        "the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
+OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
+                        "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "
+                        "the grid written once + the incidences; the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
 CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91545e6 + 3.71218e6) * 1024)
 
 
