@@ -248,3 +248,24 @@ def copy_d2d(dst, src):
     assert dst.numel() * dst.element_size() == n and dst.is_contiguous() and src.is_contiguous()
     _p(dst, "dst", dst.dtype), _p(src, "src", src.dtype)
     _lib.check(_lib.lib().sd_copy_d2d(dst.data_ptr(), src.data_ptr(), n, _stream(dst)), "sd_copy_d2d")
+
+
+def winograd_input(x0, v, *, batch, h, w, c0, x1=None, c1=0):
+    """v fp16 [16][batch*h/2*w/2][c0+c1] = B^T d B of every 4x4 patch (F(2x2,3x3), zero pad 1)."""
+    _lib.check(_lib.lib().sd_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, h, w, _p(v, "v"), _stream(v)),
+               "sd_winograd_input_f16")
+    return v
+
+
+def winograd_weight(w, u, *, n, c):
+    """u fp16 [16][n][c] = G g G^T of w fp16 [n][9][c]."""
+    _lib.check(_lib.lib().sd_winograd_weight_f16(_p(w, "w"), n, c, _p(u, "u"), _stream(u)), "sd_winograd_weight_f16")
+    return u
+
+
+def winograd_output(m, out, *, batch, h, w, n, ldm=0, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, silu=False):
+    """out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] (+ bias, per-sample bias, SiLU, residual)."""
+    rc = _lib.lib().sd_winograd_output_f16(_p(m, "m"), ldm or n, batch, h, w, n, _p(bias, "bias"), _p(bias_bn, "bias_bn"), ldbb,
+                                           _p(res, "res"), ldr, _p(out, "out"), ldo, 1 if silu else 0, _stream(out))
+    _lib.check(rc, "sd_winograd_output_f16")
+    return out
