@@ -410,7 +410,10 @@ class AdaptiveMaskInpaintPipeline:
                     else:
                         raise NotImplementedError
                     segs = []
+                    select = getattr(self.adaptive_mask_model, "select", None)      # predictors.PerItemState: per-image plug-in state
                     for b in range(B):
+                        if select is not None:
+                            select(b)
                         seg = self.adaptive_mask_model(pred_orig_images[b])["mask"]
                         if isinstance(seg, torch.Tensor):
                             seg = seg.to(device=dev, dtype=torch.uint8)

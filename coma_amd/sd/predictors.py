@@ -202,3 +202,43 @@ def build_adaptive_mask_model(adaptive_mask_model_type, pointrend_threshold, use
     else:
         backends.pop("sam_backend", None)
     return cls(**kw, **backends)
+
+
+class PerItemState:
+    """One predictor instance serving the B images of a batched pipeline call (an addition: the reference runs one image per call,
+    so its predictors keep the state of "the current item" in plain attributes -- `presumed_asset_mask` / `presumed_asset_bbox`
+    (:1336-1339), `initial_human_bbox` (:1283-1296, :1380-1386; the `s_ab_ae` type accumulates its boxes there)).  `select(b)`
+    parks the attributes of the slot that was current and brings in those of slot b; the networks (the only large members) are
+    shared.  The pipeline calls `select(b)` before it hands image b to the plug-in; the harness calls it before priming item b."""
+    STATE_ATTRS = ("initial_human_bbox", "presumed_asset_mask", "presumed_asset_bbox", "_empty")
+    _MISSING = object()
+
+    def __init__(self, model, batch):
+        self.__dict__["model"] = model
+        self.__dict__["slot"] = 0
+        self.__dict__["states"] = [None] * batch
+        first = {k: getattr(model, k, self._MISSING) for k in self.STATE_ATTRS}
+        for b in range(batch):
+            self.states[b] = dict(first)            # every slot starts from the state the model was constructed with
+
+    def select(self, b):
+        if b == self.slot:
+            return
+        m = self.model
+        self.states[self.slot] = {k: getattr(m, k, self._MISSING) for k in self.STATE_ATTRS}
+        for k, v in self.states[b].items():
+            if v is self._MISSING:
+                if hasattr(m, k):
+                    delattr(m, k)
+            else:
+                setattr(m, k, v)
+        self.__dict__["slot"] = b
+
+    def __call__(self, image, *a, **kw):
+        return self.model(image, *a, **kw)
+
+    def __getattr__(self, name):                    # everything else (use_visualizer, accepts_device_tensor, set_* hooks) is the model's
+        return getattr(self.model, name)
+
+    def __setattr__(self, name, value):
+        setattr(self.model, name, value)

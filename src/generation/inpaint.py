@@ -5,7 +5,10 @@ CLI surface and host behaviour of the reference's ``src/generation/inpaint.py``:
   * work list = render x valid mask x prompt x viewpoint augmentation x inpaint_id (:187-269), per-category /
     per-view override chain for ddim_steps / cfg_scale / strength / enforce_full_mask_ratio / human_detection_thres
     (:253-267), sorted by result path, per-process slice ``sub = len // n + 1`` (:271-278);
-  * per item: device generator seeded with ``inpaint_id`` (:308-309), skip-if-exists (:294-297), PNG output (:352).
+  * per item: device generator seeded with ``inpaint_id`` (:308-309), skip-if-exists (:294-297), PNG output (:352);
+  * the rank's slice is walked in groups of ``--batch_size`` (default 8) consecutive items with equal per-call settings; one
+    pipeline call per group, one generator / prompt / mask / plug-in state per image (the reference's loop runs one item per
+    call, :280-352; batching it is output-preserving because every item carries its own seed).
 The pipeline is :class:`coma_amd.sd.pipeline.AdaptiveMaskInpaintPipeline` (HIP kernels).  Model weights, the CLIP text
 encoder and PointRend are third-party assets that cannot be provisioned offline: ``--weights_dir`` points at a
 diffusers-format checkpoint directory when one exists (its tokenizer/ + text_encoder/ then embed the prompts); otherwise
@@ -46,6 +49,7 @@ DEFAULT_ENFORCE_FULL_MASK_RATIO = 0.0
 DEFAULT_HUMAN_DETECTION_THRES = 0.015
 NEGATIVE_PROMPT = "worst quality, normal quality, low quality, bad anatomy, artifacts, blurry, cropped, watermark, greyscale, nsfw"
 SKIP_DONE = True
+DEFAULT_BATCH_SIZE = 8          # addition: images per pipeline call (the reference runs 1; per-item seeding makes batching output-preserving)
 
 
 def prepare_asset_render_pths(asset_render_dir, supercategories, categories):
@@ -128,7 +132,8 @@ class HashTextEncoder:
 
 
 def set_pipeline(ldm_model_key, adaptive_mask_model_type, default_ddim_steps, weights_dir=None, mask_model="auto", device="cuda",
-                 default_pointrend_threshold=DEFAULT_POINTREND_THRESHOLD, use_visualizer=False, enable_sam_multitask_output=False):
+                 default_pointrend_threshold=DEFAULT_POINTREND_THRESHOLD, use_visualizer=False, enable_sam_multitask_output=False,
+                 batch_size=1):
     """src/generation/inpaint.py:45-134 of the reference: pipeline + the mask plug-in picked by `adaptive_mask_model_type`
     (PointRend / SAM family, coma_amd.sd.predictors) + the dilate / provoke schedules.  `mask_model="synthetic"` swaps in the
     dependency-free stand-in; "auto" needs detectron2 (and segment-anything for the SAM types) and says so if they are missing."""
@@ -136,12 +141,12 @@ def set_pipeline(ldm_model_key, adaptive_mask_model_type, default_ddim_steps, we
     from coma_amd.sd.predictors import build_adaptive_mask_model
     assert ldm_model_key in HF_MODEL_KEYS
     if weights_dir:
-        pipeline = AdaptiveMaskInpaintPipeline.from_pretrained(weights_dir, batch_size=1, device=device)
+        pipeline = AdaptiveMaskInpaintPipeline.from_pretrained(weights_dir, batch_size=batch_size, device=device)
         if pipeline.text_encoder is None:
             raise FileNotFoundError(f"{weights_dir} has no text_encoder/ + tokenizer/: with a real checkpoint the prompts must go "
                                     "through its CLIP text tower (the hash encoder is only for the random-weight path)")
     else:
-        pipeline = AdaptiveMaskInpaintPipeline.from_random(batch_size=1, device=device)
+        pipeline = AdaptiveMaskInpaintPipeline.from_random(batch_size=batch_size, device=device)
     pipeline.scheduler.set_timesteps(default_ddim_steps)
     if mask_model == "synthetic":
         pipeline.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
@@ -173,42 +178,89 @@ def prime_mask_model(model, adaptive_mask_model_type, asset_seg, default_mask):
             model.set_initial_human_bbox(default_mask)
 
 
+SETTING_KEYS = ("ddim_steps", "cfg_scale", "strength", "enforce_full_mask_ratio", "human_detection_thres")
+
+
+def group_for_batches(items, batch_size):
+    """Walk the (sorted, sliced) work list in order and cut it into groups of at most `batch_size` CONSECUTIVE items that share
+    every per-call setting of the override chain (ddim_steps / cfg_scale / strength / enforce_full_mask_ratio /
+    human_detection_thres: one pipeline call has one value of each).  The reference runs one item per call
+    (src/generation/inpaint.py:280-352); every item keeps its own generator seeded with its `inpaint_id` (:308-309), its own
+    prompt, mask and plug-in state, so the images do not depend on how the list is cut."""
+    groups, cur = [], []
+    for it in items:
+        if cur and (len(cur) == batch_size or any(it[k] != cur[0][k] for k in SETTING_KEYS)):
+            groups.append(cur)
+            cur = []
+        cur.append(it)
+    if cur:
+        groups.append(cur)
+    return groups
+
+
 def inpaint_human(args):
     import numpy as np
     import torch
     from PIL import Image
+    from coma_amd.sd.predictors import PerItemState
     renders = prepare_asset_render_pths(args.asset_render_dir, args.supercategories, args.categories)
     defaults = dict(ddim_steps=args.default_ddim_steps, cfg_scale=args.default_cfg_scale, strength=args.default_strength,
                     enforce_full_mask_ratio=args.default_enforce_full_mask_ratio, human_detection_thres=args.default_human_detection_thres)
     items = build_work_list(renders, args.asset_mask_dir, args.asset_seg_dir, args.prompts_dir, args.save_dir, args.num_img_per_combination,
                             args.negative_prompt, defaults, use_visualizer=args.use_visualizer)
     items = slice_for_process(items, args.parallel_idx, args.parallel_num)
-    pipeline = set_pipeline(args.ldm_model_key, args.adaptive_mask_model_type, args.default_ddim_steps, args.weights_dir, args.mask_model,
-                            default_pointrend_threshold=args.default_pointrend_threshold, use_visualizer=args.use_visualizer,
-                            enable_sam_multitask_output=args.enable_sam_multitask_output)
-    # a real checkpoint brings its CLIP text tower (prompts are tokenised and encoded as in the reference); only the
-    # random-weight path embeds prompts with the deterministic hash encoder
-    encode = None if pipeline.text_encoder is not None else HashTextEncoder()
-    for it in items:
+    todo = []
+    for it in items:                       # skip-if-exists first (:294-297), so that finished items do not occupy batch slots
         os.makedirs(it["result_save_dir"], exist_ok=True)
         if os.path.exists(it["result_save_pth"]) and args.skip_done:
             if args.verbose:
                 print(f"Continueing {it['result_save_pth']} Since Already Done!")
             continue
-        init_image = Image.open(it["asset_render_pth"]).convert("RGB")
-        default_mask = Image.open(it["asset_mask_pth"]).convert("L")
-        if os.path.exists(it["asset_seg_pth"]):
-            prime_mask_model(pipeline.adaptive_mask_model, args.adaptive_mask_model_type, np.array(Image.open(it["asset_seg_pth"]).convert("L")) > 0,
-                             np.asarray(default_mask) > 0)
-        generator = torch.Generator(device="cuda")
-        generator.manual_seed(it["inpaint_id"])
-        text = dict(prompt=it["input_prompt"], negative_prompt=it["input_negprompt"]) if encode is None else \
-            dict(prompt_embeds=encode(it["input_prompt"]), negative_prompt_embeds=encode(it["input_negprompt"]))
-        result = pipeline(image=init_image, default_mask_image=default_mask, guidance_scale=it["cfg_scale"], strength=it["strength"],
-                          use_adaptive_mask=args.adaptive_mask_model_type != "baseline", generator=generator,
-                          num_inference_steps=it["ddim_steps"], enforce_full_mask_ratio=it["enforce_full_mask_ratio"],
-                          visualization_save_dir=it["visualization_save_dir"], human_detection_thres=it["human_detection_thres"], **text).images[0]
-        result.save(it["result_save_pth"])
+        todo.append(it)
+    if not todo:
+        return
+    B = max(1, int(getattr(args, "batch_size", 1)))
+    pipeline = set_pipeline(args.ldm_model_key, args.adaptive_mask_model_type, args.default_ddim_steps, args.weights_dir, args.mask_model,
+                            default_pointrend_threshold=args.default_pointrend_threshold, use_visualizer=args.use_visualizer,
+                            enable_sam_multitask_output=args.enable_sam_multitask_output, batch_size=B)
+    # a real checkpoint brings its CLIP text tower (prompts are tokenised and encoded as in the reference); only the
+    # random-weight path embeds prompts with the deterministic hash encoder
+    encode = None if pipeline.text_encoder is not None else HashTextEncoder()
+    adaptive = args.adaptive_mask_model_type != "baseline"
+    if adaptive and B > 1:
+        # one plug-in instance serves B images of a batch: its small per-item state (presumed asset mask, person boxes) is swapped
+        # in and out around every call, the networks are shared
+        pipeline.register_adaptive_mask_model(PerItemState(pipeline.adaptive_mask_model, B))
+    for group in group_for_batches(todo, B):
+        n = len(group)
+        slots = group + [group[-1]] * (B - n)          # ragged tail: the last item fills the spare slots, its copies are dropped
+        images = [Image.open(it["asset_render_pth"]).convert("RGB") for it in slots]
+        masks = [Image.open(it["asset_mask_pth"]).convert("L") for it in slots]
+        for b, it in enumerate(slots):
+            if os.path.exists(it["asset_seg_pth"]):
+                model = pipeline.adaptive_mask_model
+                if isinstance(model, PerItemState):
+                    model.select(b)
+                prime_mask_model(model, args.adaptive_mask_model_type, np.array(Image.open(it["asset_seg_pth"]).convert("L")) > 0,
+                                 np.asarray(masks[b]) > 0)
+        generators = []
+        for it in slots:                                # one generator per image, seeded with its inpaint_id (:308-309)
+            g = torch.Generator(device="cuda")
+            g.manual_seed(it["inpaint_id"])
+            generators.append(g)
+        if encode is None:
+            text = dict(prompt=[it["input_prompt"] for it in slots], negative_prompt=[it["input_negprompt"] for it in slots])
+        else:
+            text = dict(prompt_embeds=torch.cat([encode(it["input_prompt"]) for it in slots]),
+                        negative_prompt_embeds=torch.cat([encode(it["input_negprompt"]) for it in slots]))
+        it0 = group[0]
+        results = pipeline(image=images if B > 1 else images[0], default_mask_image=masks if B > 1 else masks[0],
+                           guidance_scale=it0["cfg_scale"], strength=it0["strength"], use_adaptive_mask=adaptive,
+                           generator=generators if B > 1 else generators[0], num_inference_steps=it0["ddim_steps"],
+                           enforce_full_mask_ratio=it0["enforce_full_mask_ratio"], visualization_save_dir=it0["visualization_save_dir"],
+                           human_detection_thres=it0["human_detection_thres"], **text).images
+        for it, img in zip(group, results[:n]):
+            img.save(it["result_save_pth"])
 
 
 def build_parser():
@@ -241,6 +293,9 @@ def build_parser():
     p.add_argument("--parallel_idx", type=int, default=0)
     # additions (not in the reference): offline asset provisioning
     p.add_argument("--weights_dir", type=str, default=None, help="diffusers-format checkpoint dir; default: seeded random weights")
+    p.add_argument("--batch_size", type=int, default=DEFAULT_BATCH_SIZE,
+                   help="images per pipeline call (the UNet runs 2 x batch_size rows per step); the work list is walked in groups, every "
+                        "image keeps its own generator / prompt / mask, so the outputs do not depend on it")
     p.add_argument("--mask_model", type=str, default="auto", choices=["auto", "synthetic"],
                    help="auto: the PointRend / SAM plug-in selected by --adaptive_mask_model_type (needs detectron2 / segment-anything); "
                         "synthetic: dependency-free stand-in")

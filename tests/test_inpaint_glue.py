@@ -155,3 +155,63 @@ def test_checkpoint_layout_check():
     del t2i["mid_block.resnets.0.conv1.bias"]
     with pytest.raises(ValueError, match="1 missing.*conv1.bias.*1 with other shapes.*conv_in.weight"):
         weights.check_state(t2i, shapes, "UNet")
+
+
+def test_group_for_batches_keeps_order_and_settings():
+    """src/generation/inpaint.py: the rank's slice is cut into groups of <= batch_size CONSECUTIVE items with equal per-call settings."""
+    from src.generation import inpaint as gi
+    base = dict(ddim_steps=50, cfg_scale=11.0, strength=0.98, enforce_full_mask_ratio=0.0, human_detection_thres=0.015)
+    items = [dict(base, result_save_pth=f"a/{i:06}.png", inpaint_id=i) for i in range(11)]
+    items += [dict(base, strength=0.9, result_save_pth=f"b/{i:06}.png", inpaint_id=i) for i in range(3)]
+    items += [dict(base, result_save_pth=f"c/{i:06}.png", inpaint_id=i) for i in range(2)]
+    groups = gi.group_for_batches(items, 8)
+    assert [len(g) for g in groups] == [8, 3, 3, 2]
+    assert [it["result_save_pth"] for g in groups for it in g] == [it["result_save_pth"] for it in items]       # order kept
+    for g in groups:
+        assert all(all(it[k] == g[0][k] for k in gi.SETTING_KEYS) for it in g)
+    assert [len(g) for g in gi.group_for_batches(items, 1)] == [1] * 16
+    assert gi.group_for_batches([], 8) == []
+    assert gi.build_parser().parse_args([]).batch_size == gi.DEFAULT_BATCH_SIZE == 8
+
+
+def test_per_item_state_swaps_only_the_small_state():
+    """coma_amd/sd/predictors.PerItemState: one predictor serves B batch slots, every slot with its own box / asset-mask state."""
+    from coma_amd.sd.predictors import PerItemState
+
+    class Net:           # stands for the shared segmentation network
+        pass
+
+    class Pred:
+        use_visualizer = False
+
+        def __init__(self):
+            self.net, self.initial_human_bbox, self.calls = Net(), None, 0
+
+        def set_presumed_asset_mask(self, m):
+            self.presumed_asset_mask, self.presumed_asset_bbox = m, ("bbox", int(m.sum()))
+
+        def __call__(self, image):
+            self.calls += 1
+            box = np.array([image, image, image + 1, image + 1])
+            self.initial_human_bbox = box if self.initial_human_bbox is None else np.minimum(self.initial_human_bbox, box)
+            return {"mask": self.initial_human_bbox.copy(), "asset": getattr(self, "presumed_asset_bbox", None)}
+
+    p = Pred()
+    w = PerItemState(p, 3)
+    for b in range(3):
+        w.select(b)
+        if b != 1:
+            w.set_presumed_asset_mask(np.ones((b + 2, b + 2)))
+    outs = []
+    for step in range(2):
+        for b in range(3):
+            w.select(b)
+            outs.append(w(10 * (b + 1) - step))
+    assert p.calls == 6 and w.net is p.net and w.use_visualizer is False
+    # slot b saw images 10(b+1) and 10(b+1) - 1: its running box is its own, not the other slots'
+    assert [int(o["mask"][0]) for o in outs] == [10, 20, 30, 9, 19, 29]
+    assert [o["asset"] for o in outs[:3]] == [("bbox", 4), None, ("bbox", 16)]
+    w.select(1)
+    assert not hasattr(p, "presumed_asset_mask")
+    w.select(2)
+    assert p.presumed_asset_mask.shape == (4, 4)
