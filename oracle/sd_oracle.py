@@ -90,10 +90,29 @@ def ddim_timesteps(num_inference_steps=50, num_train=1000, steps_offset=1):
     return [int(i * ratio) + steps_offset for i in range(num_inference_steps)][::-1]
 
 
-def ddim_step_ref(eps, t, x, alphas, num_inference_steps=50, num_train=1000):
+def r16(x):
+    """Round to fp16 and come back: one fp16 tensor op of the reference's half-precision pipeline (torch computes an fp16 elementwise
+    op in fp32 and rounds the result once, python / 0-dim fp32 scalars stay fp32)."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+def ddim_step_ref(eps, t, x, alphas, num_inference_steps=50, num_train=1000, dtype_flow="fp32"):
+    """DDIMScheduler.step with eta = 0 (:1015-1017).  dtype_flow "fp32": the closed form in f64.  dtype_flow "fp16": op by op the way
+    diffusers 0.20.2 evaluates it on the fp16 tensors of the reference's pipeline (src/generation/inpaint.py:64-70 loads it with
+    torch_dtype=float16): `pred_original_sample = (sample - beta_prod_t ** 0.5 * model_output) / alpha_prod_t ** 0.5`,
+    `pred_sample_direction = (1 - alpha_prod_t_prev) ** 0.5 * model_output`,
+    `prev_sample = alpha_prod_t_prev ** 0.5 * pred_original_sample + pred_sample_direction` -- the alphas are fp32 scalars, every
+    tensor result is rounded to fp16."""
     prev_t = t - num_train // num_inference_steps
     a_t = alphas[t]
     a_p = alphas[prev_t] if prev_t >= 0 else alphas[0]           # set_alpha_to_one=False
+    if dtype_flow == "fp16":
+        a_t32, a_p32 = a_t.float(), a_p.float()                  # alphas_cumprod is an fp32 tensor in the scheduler
+        e, xs = r16(eps.float()), r16(x.float())
+        x0 = r16(r16(xs - r16((1 - a_t32) ** 0.5 * e)) / a_t32 ** 0.5)
+        direction = r16((1 - a_p32) ** 0.5 * e)
+        prev = r16(r16(a_p32 ** 0.5 * x0) + direction)
+        return prev, x0
     x0 = (x.double() - (1 - a_t).sqrt() * eps.double()) / a_t.sqrt()
     prev = a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps.double()
     return prev, x0
@@ -266,7 +285,13 @@ def adapt_mask_ref(seg, default_mask_np, dilate_num, use_default_mask, human_det
 class AdaptiveLoopRef:
     def __init__(self, ustate, vstate, ucfg, vcfg, *, image, default_mask, ctx_uncond, ctx_cond, lat0, plugin, settings,
                  num_inference_steps=50, strength=1.0, guidance=7.5, enforce_full_mask_ratio=0.5, human_detection_thres=0.008,
-                 use_adaptive_mask=True, device="cpu"):
+                 use_adaptive_mask=True, device="cpu", dtype_flow="fp32"):
+        """dtype_flow "fp32": everything outside the networks in fp32 / f64 (what the product does: fp32 latents).  "fp16": the
+        tensors the reference's fp16 pipeline holds in half precision are rounded where it rounds them -- latents, the UNet's
+        output, the CFG combination op by op (:1010-1012), the scheduler step (ddim_step_ref), the VAE moments / posterior sample
+        and the decoder input.  The networks themselves stay fp32 restatements in both flows."""
+        assert dtype_flow in ("fp32", "fp16")
+        self.flow = dtype_flow
         dev = torch.device(device)
         self.dev = dev
         self.us = {k: v.to(dev, torch.float32) for k, v in ustate.items()}
@@ -284,6 +309,8 @@ class AdaptiveLoopRef:
         init = min(int(num_inference_steps * strength), num_inference_steps)
         self.timesteps = ts[max(num_inference_steps - init, 0):]               # get_timesteps (:622-628)
         self.lat = lat0.double().to(dev)                                       # caller-provided `latents` (:662-664), sigma = 1
+        if self.flow == "fp16":
+            self.lat = r16(self.lat.float())
         self.mask_np = self.default_np.copy()
         self.mask_lat = self.masked_lat = None
 
@@ -295,18 +322,27 @@ class AdaptiveLoopRef:
         self.mask_np = mask_np
         self.mask_lat = F.interpolate(m, size=(m.shape[-2] // 8, m.shape[-1] // 8))
         mom = vae_encode_ref(self.vs, masked, self.vcfg)
-        self.masked_lat = vae_sample_ref(mom, noise.to(self.dev), self.vcfg["scaling_factor"])
+        if self.flow == "fp16":          # moments, std, std * noise, mean + ., . * scaling_factor: five fp16 tensor results (:675-684)
+            mean, logvar = r16(mom.float()).chunk(2, dim=1)
+            std = r16(torch.exp(r16(0.5 * logvar.clamp(-30.0, 20.0))))
+            self.masked_lat = r16(r16(mean + r16(std * r16(noise.to(self.dev).float()))) * self.vcfg["scaling_factor"])
+        else:
+            self.masked_lat = vae_sample_ref(mom, noise.to(self.dev), self.vcfg["scaling_factor"])
         return self.masked_lat
 
     def unet_eps(self, t):
         B = self.B
         inp = torch.cat([self.lat.float(), self.mask_lat, self.masked_lat], dim=1)
         eps = unet_ref(self.us, torch.cat([inp, inp]), torch.full((2 * B,), float(t), device=self.dev), self.ctx, self.ucfg)
+        if self.flow == "fp16":          # noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond) on fp16 tensors
+            eps = r16(eps)
+            return r16(eps[:B] + r16(self.guidance * r16(eps[B:] - eps[:B])))
         return eps[:B] + self.guidance * (eps[B:] - eps[:B])
 
     def segment(self, x0):
         """decode x0 and run the plug-in per image (its NumPy contract) -> images u8 [B,H,W,3], segs u8 [B,H,W]."""
-        imgs = decode_to_npuint8_ref(self.vs, self.vcfg, x0)
+        imgs = decode_to_npuint8_ref(self.vs, self.vcfg, r16(r16(x0.float()) / self.vcfg["scaling_factor"]) * self.vcfg["scaling_factor"]
+                                     if self.flow == "fp16" else x0)
         segs = np.stack([np.asarray(self.plugin(imgs[b])["mask"]).astype(np.uint8) for b in range(self.B)])
         return imgs, segs
 
@@ -326,7 +362,7 @@ class AdaptiveLoopRef:
         self.set_mask(self.default_np, next(it))
         for i, t in enumerate(self.timesteps):
             e = self.unet_eps(t)
-            self.lat, x0 = ddim_step_ref(e, t, self.lat, self.alphas.to(self.dev), num_inference_steps=self.N)
+            self.lat, x0 = ddim_step_ref(e, t, self.lat, self.alphas.to(self.dev), num_inference_steps=self.N, dtype_flow=self.flow)
             if self.adaptive and self.settings.provoke_scheduler(i):
                 imgs, segs = self.segment(x0)
                 mask = self.adapt(i, t, segs)

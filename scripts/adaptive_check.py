@@ -45,5 +45,20 @@ for h, r in zip(hip["trace"], ref["trace"]):
     print(f" i={h['i']:2d} t={h['t']:3d} k={k:2d} dflt={int(h['use_default'])} mask IoU min {min(ious):.4f} seg IoU min {min(seg_ious):.4f} "
           f"glue-exact {exact} x0 rel {x0e:.3e} masked_lat rel {mle:.3e} u8 maxdiff {du8.max()} mean {du8.mean():.3f} "
           f"area {h['area'].tolist()[:4]}")
-fe = [float((hip["latents"][b].double() - ref["latents"][b].double()).norm() / ref["latents"][b].double().norm()) for b in range(B)]
-print("final latents rel-L2 per image:", ["%.3e" % e for e in fe])
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+fe = [rel(hip["latents"][b], ref["latents"][b]) for b in range(B)]
+print("final latents rel-L2 per image (product vs fp32 flow):", ["%.3e" % e for e in fe])
+if os.environ.get("FLOW16", "1") != "0":
+    # the reference's own dtype flow (fp16 latents / CFG / scheduler step / VAE sample; networks fp32 in both restatements)
+    r16 = run_ref(inp, hip["noises"], make_plugin(kind), strength=strength, device=DEV, dtype_flow="fp16")
+    print("final latents rel-L2 per image (product vs fp16 flow):", ["%.3e" % rel(hip["latents"][b], r16["latents"][b]) for b in range(B)])
+    print("final latents rel-L2 per image (fp16 flow vs fp32 flow):", ["%.3e" % rel(r16["latents"][b], ref["latents"][b]) for b in range(B)])
+    x0p = [rel(h["x0"], r["x0"]) for h, r in zip(hip["trace"], r16["trace"])]
+    x0f = [rel(a["x0"], r["x0"]) for a, r in zip(r16["trace"], ref["trace"])]
+    mi = [min(iou(h["mask"][b], r["mask"][b]) for b in range(B)) for h, r in zip(hip["trace"], r16["trace"])]
+    mf = [min(iou(a["mask"][b], r["mask"][b]) for b in range(B)) for a, r in zip(r16["trace"], ref["trace"])]
+    print(f"x0 at the re-estimations: product vs fp16 flow {min(x0p):.2e} ... {max(x0p):.2e}; fp16 flow vs fp32 flow {min(x0f):.2e} ... {max(x0f):.2e}")
+    print(f"free-running mask IoU (min over steps / images): product vs fp16 flow {min(mi):.4f}; fp16 flow vs fp32 flow {min(mf):.4f}")

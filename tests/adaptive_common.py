@@ -96,14 +96,14 @@ def run_hip(pipe, inp, plugin, *, strength, seeds=None, dev="cuda:0", use_adapti
     return dict(latents=out.float().cpu(), trace=trace, noises=noises, last_mask=pipe.last_mask_image_np)
 
 
-def run_ref(inp, noises, plugin, *, strength, device="cpu", use_adaptive_mask=True, steps=50, seed=0):
+def run_ref(inp, noises, plugin, *, strength, device="cpu", use_adaptive_mask=True, steps=50, seed=0, dtype_flow="fp32"):
     plugin = type(plugin)()
     plugin.accepts_device_tensor = False
     ref = so.AdaptiveLoopRef(weights.random_state(weights.unet_shapes(), seed=seed), weights.random_state(weights.vae_shapes(), seed=seed + 1),
                              weights.UNET_CFG, weights.VAE_CFG, image=inp["image"], default_mask=inp["mask"], ctx_uncond=inp["ne"],
                              ctx_cond=inp["pe"], lat0=inp["lat0"], plugin=plugin, settings=inp["settings"], num_inference_steps=steps,
                              strength=strength, guidance=inp["guidance"], enforce_full_mask_ratio=inp["ratio"],
-                             human_detection_thres=inp["thres"], use_adaptive_mask=use_adaptive_mask, device=device)
+                             human_detection_thres=inp["thres"], use_adaptive_mask=use_adaptive_mask, device=device, dtype_flow=dtype_flow)
     trace = []
     with torch.no_grad():
         lat = ref.run(noises, on_adapt=lambda d: trace.append(dict(i=d["i"], t=d["t"], x0=d["x0"].float().cpu(), image_u8=d["image_u8"],

@@ -19,11 +19,12 @@ from tests.adaptive_common import iou, make_inputs, make_plugin, run_hip, run_re
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# tolerances (fp16 UNet / VAE against fp32, 49 steps).  Measured with scripts/adaptive_check.py (profiles/r03_notes.md): final latents
-# 2.0e-3 ... 3.5e-3 relative L2, x0 at the re-estimations <= 7e-3, free-running mask IoU >= 0.989 -- the plug-in decides per 16 x 16
-# block, and ONE block flipping on a +-1 uint8 difference of the decoded image moves the IoU of a ~30 000-pixel mask by 0.8 %, so
-# the per-step bar is 0.98 (two blocks) and the mean over all steps and images 0.995.
-MASK_IOU, MASK_IOU_MEAN, FINAL_REL, X0_REL = 0.98, 0.995, 1.5e-2, 2e-2
+# tolerances (fp16 UNet / VAE against fp32, 49 steps) = 2 x what scripts/adaptive_check.py measures (profiles/r03_notes.md 3,
+# profiles/r04_notes.md 3): final latents 2.0e-3 ... 3.5e-3 relative L2 -> 7e-3, x0 at the re-estimations <= 7e-3 -> 1.4e-2, so that a
+# kernel regression of 2-3 x shows; free-running mask IoU >= 0.989 -- the plug-in decides per 16 x 16 block, and ONE block flipping
+# on a +-1 uint8 difference of the decoded image moves the IoU of a ~30 000-pixel mask by 0.8 %, so the per-step bar is 0.98 (two
+# blocks) and the mean over all steps and images 0.995.
+MASK_IOU, MASK_IOU_MEAN, FINAL_REL, X0_REL = 0.98, 0.995, 7e-3, 1.4e-2
 
 
 def _pipe(B, HW=512):
@@ -94,7 +95,7 @@ def test_adaptive_loop_49_steps_matches_restatement(hip_lib, fp32_strict, B):
     if B == 8:
         # image b of the batch-8 run == its own batch-1 run (same generator seed, same inputs; other tile shapes -> fp16 rounding only)
         p1 = _pipe(1)
-        for b in (0, 5):
+        for b in (5,):
             one = run_hip(p1, take(inp, [b]), make_plugin("block"), strength=0.98, seeds=[100 + b])
             assert _rel(one["latents"][0], hip["latents"][b]) <= FINAL_REL
             for h1, h8 in zip(one["trace"], hip["trace"]):

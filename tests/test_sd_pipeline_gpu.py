@@ -147,3 +147,35 @@ def test_from_pretrained_reads_a_diffusers_layout_checkpoint(tmp_path, hip_lib):
         del pipe
         torch.cuda.empty_cache()
     assert outs[0].shape == (1, 512, 512, 3) and torch.equal(outs[0], outs[1])
+
+
+def test_ddim_fp16_flow_is_torch_half_arithmetic(hip_lib):
+    """oracle/sd_oracle.ddim_step_ref(dtype_flow="fp16") and the fp16 CFG combination of AdaptiveLoopRef, against the SAME expressions
+    evaluated by torch on fp16 tensors with fp32 0-dim alphas -- what diffusers' DDIMScheduler.step / the reference's loop
+    (utils/adaptive_mask_inpainting.py:1010-1017) execute in the fp16 pipeline ON THE DEVICE (the reference runs on cuda: a 0-dim CPU
+    fp32 alpha enters the elementwise kernel as an fp32 scalar; torch's CPU kernels round it to fp16 first for `mul`, which is why
+    this is a device test).  Bit-equal.  Nothing of libcoma_hip.so is involved: this pins the oracle's fp16 flow to torch."""
+    from oracle import sd_oracle as so
+    g = torch.Generator().manual_seed(3)
+    dev = "cuda:0"
+    alphas = so.ddim_alphas()
+    for t in (981, 501, 21, 1):
+        x = (torch.randn(2, 4, 8, 8, generator=g) * 1.3).to(dev)
+        eu, ec = torch.randn(2, 4, 8, 8, generator=g).to(dev), torch.randn(2, 4, 8, 8, generator=g).to(dev)
+        # CFG on fp16 tensors with a python-float guidance scale
+        eu16, ec16 = eu.half(), ec.half()
+        e16 = eu16 + 11.0 * (ec16 - eu16)
+        e_ref = so.r16(so.r16(eu) + so.r16(11.0 * so.r16(so.r16(ec) - so.r16(eu))))
+        assert e16.dtype == torch.float16 and torch.equal(e16.float(), e_ref)
+        # scheduler step: the alphas are 0-dim fp32 tensors (scheduler.alphas_cumprod[timestep])
+        a32 = alphas.float()                      # stays on the CPU, as scheduler.alphas_cumprod does
+        a_t, a_p = a32[t], a32[t - 20] if t - 20 >= 0 else a32[0]
+        x16 = x.half()
+        x0_16 = (x16 - (1 - a_t) ** 0.5 * e16) / a_t ** 0.5
+        prev16 = a_p ** 0.5 * x0_16 + (1 - a_p) ** 0.5 * e16
+        assert x0_16.dtype == prev16.dtype == torch.float16
+        prev, x0 = so.ddim_step_ref(e_ref, t, x, alphas.to(dev), dtype_flow="fp16")
+        assert torch.equal(x0, x0_16.float()) and torch.equal(prev, prev16.float()), t
+        # and the fp32 flow is the closed form
+        p64, x64 = so.ddim_step_ref(e_ref, t, x, alphas.to(dev))
+        assert float((prev.double() - p64).abs().max()) < 2e-2 and p64.dtype == torch.float64

@@ -31,6 +31,7 @@ def _metrics(out, ref):
     out, ref = out.float().cpu(), ref.float().cpu()
     rel = float((out - ref).norm() / ref.norm())
     cos = float(torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0))
+    print(f"METRIC rel-L2 {rel:.3e} cos {cos:.6f}")        # pytest -rP shows the measured distances the bars are set from
     return rel, cos
 
 

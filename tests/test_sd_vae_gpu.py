@@ -20,7 +20,9 @@ def vae_setup(hip_lib):
 
 def _metrics(out, ref):
     out, ref = out.float().cpu(), ref.float().cpu()
-    return float((out - ref).norm() / ref.norm()), float(torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0))
+    rel, cos = float((out - ref).norm() / ref.norm()), float(torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0))
+    print(f"METRIC rel-L2 {rel:.3e} cos {cos:.6f}")        # pytest -rP shows the measured distances the bars are set from
+    return rel, cos
 
 
 def test_decoder(vae_setup):
