@@ -7,6 +7,7 @@ libcoma_hip.so (coma_occupancy_splat / coma_occupancy_reduce), bit-exact counts.
 """
 from __future__ import annotations
 
+import os
 import pickle
 from copy import deepcopy
 
@@ -312,20 +313,96 @@ class ComA_Occupancy:
         reference) and return max over the selected human vertices, [R,R,R] f32 on the device."""
         return self._reduce(human_indices)
 
-    def export(self, save_pth=None):
+    @staticmethod
+    def shard_path(save_pth, rank):
+        """`.../key:total.pickle` -> `.../key:total_rank{rank}.pickle` (row-sliced export of a multi-GPU run)."""
+        stem, ext = os.path.splitext(save_pth)
+        return f"{stem}_rank{rank}{ext}"
+
+    def export(self, save_pth=None, shard=None):
+        """The reference's export (utils/coma_occupancy.py:315-330): every public attribute except the caches, tensors as NumPy.
+        shard = (rank, world, total_rows) (an addition, SURVEY.md 7 "Memory at config 5"): this object holds human rows
+        `shard_slice(total_rows, rank, world)` of a row-sharded run; the SAME keys are written to `shard_path(save_pth, rank)` with
+        `spatial_occupancy_grids` = this rank's rows, `human_res` = total_rows, plus one extra key `row_shard` = (rank, world, lo,
+        hi) -- no rank ever holds or pickles the full [H, R, R, R] grid (88 GB at config 5).  `load` accepts either form and
+        `assemble_shards` rebuilds the single-file dict bit for bit."""
         to_export = {k: v for k, v in vars(self).items() if k not in ("cache", "used") and not k.startswith("_")}
         self._materialize()
         to_export["spatial_occupancy_grids"] = self._grid
-        to_export = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else deepcopy(v)) for k, v in to_export.items()}
-        to_export = to_np_torch_recursive(to_export, use_torch=False, device="cpu")
+        to_export = {k: (v if isinstance(v, torch.Tensor) else deepcopy(v)) for k, v in to_export.items()}
+        to_export = to_np_torch_recursive(to_export, use_torch=False, device="cpu")      # .cpu().numpy(): already a copy of every tensor
+        if shard is not None:
+            from .dist import shard_slice
+            rank, world, total = (int(x) for x in shard)
+            lo, hi = shard_slice(total, rank, world)
+            assert hi - lo == self.human_res, f"row shard {rank}/{world} of {total} has {hi - lo} rows, this object {self.human_res}"
+            to_export["human_res"] = total
+            to_export["row_shard"] = (rank, world, lo, hi)
+            if save_pth is not None:
+                save_pth = self.shard_path(save_pth, rank)
         if save_pth is None:
             return to_export
         with open(save_pth, "wb") as handle:
             pickle.dump(to_export, handle, protocol=pickle.HIGHEST_PROTOCOL)
 
-    def load(self, load_pth):
-        with open(load_pth, "rb") as handle:
-            loadables = pickle.load(handle)
+    @classmethod
+    def shard_files(cls, load_pth):
+        """The row-shard files of `load_pth`, ordered by rank, or [] (none / incomplete set)."""
+        import glob
+        import re
+        stem, ext = os.path.splitext(load_pth)
+        found = {}
+        for f in glob.glob(f"{glob.escape(stem)}_rank*{ext}"):
+            m = re.fullmatch(re.escape(stem) + r"_rank(\d+)" + re.escape(ext), f)
+            if m:
+                found[int(m.group(1))] = f
+        return [found[r] for r in range(len(found))] if found and sorted(found) == list(range(len(found))) else []
+
+    @classmethod
+    def assemble_shards(cls, files):
+        """Row-shard pickles -> the dict a single-process export would have written (same keys, same bits)."""
+        parts = []
+        for f in files:
+            with open(f, "rb") as handle:
+                parts.append(pickle.load(handle))
+        world = len(parts)
+        for r, d in enumerate(parts):
+            rank, w, lo, hi = d["row_shard"]
+            assert (rank, w) == (r, world), f"{files[r]}: shard {rank}/{w}, expected {r}/{world}"
+        out = {k: v for k, v in parts[0].items() if k != "row_shard"}
+        out["spatial_occupancy_grids"] = np.concatenate([d["spatial_occupancy_grids"] for d in parts], axis=0)
+        assert out["spatial_occupancy_grids"].shape[0] == out["human_res"]
+        return out
+
+    def load(self, load_pth, shard=None):
+        """The reference's load (:333-343).  If `load_pth` does not exist but its row-shard files do (see export), they are
+        re-assembled; with shard = (rank, world) and a shard set written by the same world size only this rank's file is read and
+        the object becomes that row shard (human_res = its rows)."""
+        if os.path.exists(load_pth):
+            with open(load_pth, "rb") as handle:
+                loadables = pickle.load(handle)
+            if shard is not None:
+                from .dist import shard_slice
+                lo, hi = shard_slice(int(loadables["human_res"]), int(shard[0]), int(shard[1]))
+                loadables["spatial_occupancy_grids"] = loadables["spatial_occupancy_grids"][lo:hi]
+                loadables["human_res"] = hi - lo
+        else:
+            files = self.shard_files(load_pth)
+            if not files:
+                raise FileNotFoundError(f"{load_pth}: neither the file nor a complete set of row shards "
+                                        f"({self.shard_path(load_pth, 0)}, ...) exists")
+            if shard is not None and int(shard[1]) == len(files):
+                with open(files[int(shard[0])], "rb") as handle:
+                    loadables = pickle.load(handle)
+                rank, world, lo, hi = loadables.pop("row_shard")
+                loadables["human_res"] = hi - lo
+            else:
+                loadables = self.assemble_shards(files)
+                if shard is not None:
+                    from .dist import shard_slice
+                    lo, hi = shard_slice(int(loadables["human_res"]), int(shard[0]), int(shard[1]))
+                    loadables["spatial_occupancy_grids"] = loadables["spatial_occupancy_grids"][lo:hi]
+                    loadables["human_res"] = hi - lo
         loadables = to_np_torch_recursive(loadables, use_torch=True, device=self.device)
         for k, v in loadables.items():
             setattr(self, k, v)

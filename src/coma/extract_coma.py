@@ -31,6 +31,8 @@ from constants.coma.qual import QUAL_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT  # n
 from constants.coma.quant import QUANT_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT  # noqa: E402
 from constants.metadata import DEFAULT_SEED  # noqa: E402
 
+# occupancy grids larger than this leave a multi-GPU run as one pickle per rank (row slices) instead of being gathered onto rank 0
+SHARD_EXPORT_BYTES = int(os.environ.get("COMA_SHARD_EXPORT_BYTES", 8 << 30))
 KNOWN_SENTINELS = ["NOT ALLOWED VIEWPOINT PROMPTS", "ERRONEOUS SAMPLE DUE TO TOO SMALL HUMAN", "TOO LITTLE INLIERS",
                    "LARGELY PENETRATED HUMAN"]
 
@@ -161,11 +163,22 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
             coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **dict(common, human_res=row_hi - row_lo))
         else:
             coma = ComA(**common)
-        if skip_done and os.path.exists(save_pth):
-            if occ_rows:               # the exported pickle holds the complete grid: rank 0 reloads it whole, the others have nothing to do
-                del coma
-                coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **common) if rank == 0 else None
-            if coma is not None:
+        # config 5 (H = 10475, R = 128: an 88 GB grid) never gathers the rows: every rank pickles its own row slice
+        # (`..._rank{r}.pickle`, ComA_Occupancy.export(shard=...)); small grids (R = 30) keep the reference's single file
+        shard_export = occ_rows and 4 * H * hp["spatial_res"] ** 3 > SHARD_EXPORT_BYTES
+        # skip-or-compute is decided ONCE, on rank 0, and broadcast: the ranks of one scene must take the same branch (both contain
+        # collectives), whatever a slow or non-shared filesystem shows each of them
+        have = skip_done and (os.path.exists(save_pth) or (visualize_type == "occupancy" and bool(ComA_Occupancy.shard_files(save_pth))))
+        if world > 1:
+            flag = [bool(have)]
+            dist.broadcast_object_list(flag, src=0)
+            have = flag[0]
+        if have:
+            if occ_rows:               # every rank reloads ITS rows (its own shard file when the set was written by this world size)
+                coma.load(save_pth, shard=(rank, world))
+                from coma_amd.dist import occupancy_rows_reduce
+                _, field_dev = occupancy_rows_reduce(coma, H, gather=False)
+            else:
                 coma.load(save_pth)
         else:
             lo, hi = (0, len(inputs)) if occ_rows else shard_slice(len(inputs), rank, world)
@@ -185,14 +198,21 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
             coma.aggregate_all_samples()
             if occ_rows:
                 from coma_amd.dist import occupancy_rows_reduce
-                full, field_dev = occupancy_rows_reduce(coma, H)
-                if rank == 0:          # the exported object carries the complete raw per-vertex grid, as a single process would
-                    used, used_count = coma.used, coma.used_count
-                    coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **common)
-                    coma.spatial_occupancy_grids, coma.used, coma.used_count = full, used, used_count
+                if shard_export:
+                    # export first: it runs the one fused pass (raw counts left in place, the field of all rows kept aside), the
+                    # reduction below then only picks that field up and MAX-all-reduces it -- no row leaves its rank
+                    os.makedirs(save_dir, exist_ok=True)
+                    coma.export(save_pth=save_pth, shard=(rank, world, H))
+                    _, field_dev = occupancy_rows_reduce(coma, H, gather=False)
+                else:
+                    full, field_dev = occupancy_rows_reduce(coma, H)
+                    if rank == 0:      # the exported object carries the complete raw per-vertex grid, as a single process would
+                        used, used_count = coma.used, coma.used_count
+                        coma = ComA_Occupancy(scale_tolerance=scale_tolerance, **common)
+                        coma.spatial_occupancy_grids, coma.used, coma.used_count = full, used, used_count
             elif world > 1:
                 coma.all_reduce()
-            if rank == 0:
+            if rank == 0 and not shard_export:
                 os.makedirs(save_dir, exist_ok=True)
                 coma.export(save_pth=save_pth)
         # K4 reducers: with more than one rank every rank holds the all-reduced (or reloaded) state; each
@@ -228,6 +248,8 @@ def run_affordance_extraction(supercategories, categories, prompts, camera_dir, 
                 np.save(f"{out}/occupancy.npy", dict(prob_field=0.7 * field, spatial_grid_metadata=coma.spatial_grid_metadata))
             done.append((scam, save_pth, out))
         del coma
+        if world > 1:
+            dist.barrier()             # no rank runs ahead into the next scene's collectives (or its skip decision)
     return done
 
 

@@ -233,6 +233,97 @@ def test_row_sharded_occupancy_reduce_over_gloo(tmp_path):
         assert p.returncode == 0 and f"RANK_OK {r}" in out, out
 
 
+_OCC_SHARD_EXPORT_WORKER = r"""
+import os, pickle, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from coma_amd import dist as cdist
+from coma_amd.coma_occupancy import ComA_Occupancy
+from oracle import coma_oracle as orc
+out_dir = sys.argv[2]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+H, R = 11, 6                                   # 11 rows over 2 ranks: 6 + 5 (ragged shards)
+oracle = orc.OccupancyOracle(H, R, 3.0)
+rng = np.random.default_rng(3)
+for _ in range(5):
+    oracle.aggregate_sample(rng.uniform(-1.0, 1.0, size=(H, 3)), np.zeros((1, 3)))
+lo, hi = cdist.shard_slice(H, rank, world)
+kw = dict(scale_tolerance=3.0, obj_res=1, normal_res=0, spatial_res=R, device="cpu")      # host-side state only: no kernel runs
+save_pth = os.path.join(out_dir, "key:total.pickle")
+
+shard = ComA_Occupancy(human_res=hi - lo, **kw)
+shard.spatial_occupancy_grids = torch.from_numpy(oracle.occ[lo:hi].copy())
+shard.used_count = 5
+shard.export(save_pth=save_pth, shard=(rank, world, H))
+assert os.path.exists(os.path.join(out_dir, f"key:total_rank{rank}.pickle")) and not os.path.exists(save_pth)
+dist.barrier()
+
+files = ComA_Occupancy.shard_files(save_pth)
+assert [os.path.basename(f) for f in files] == ["key:total_rank0.pickle", "key:total_rank1.pickle"]
+single = ComA_Occupancy(human_res=H, **kw)
+single.spatial_occupancy_grids = torch.from_numpy(oracle.occ.copy())
+single.used_count = 5
+ref = single.export()                           # what a single process writes (utils/coma_occupancy.py:315-330)
+got = ComA_Occupancy.assemble_shards(files)
+assert list(got.keys()) == list(ref.keys()), (list(got.keys()), list(ref.keys()))
+for k in ref:
+    a, b = ref[k], got[k]
+    if isinstance(a, np.ndarray):
+        assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), k
+    elif isinstance(a, dict):
+        assert pickle.dumps(a) == pickle.dumps(b), k
+    else:
+        assert a == b, k
+with open(files[rank], "rb") as fh:
+    mine = pickle.load(fh)
+assert mine["row_shard"] == (rank, world, lo, hi) and mine["human_res"] == H and set(mine) == set(ref) | {"row_shard"}
+assert np.array_equal(mine["spatial_occupancy_grids"], oracle.occ[lo:hi])
+
+# loader: own shard only (same world), the whole grid from the shard set, and a row slice of a single file
+o = ComA_Occupancy(human_res=hi - lo, **kw)
+o.load(save_pth, shard=(rank, world))
+assert o.human_res == hi - lo and np.array_equal(o.spatial_occupancy_grids.numpy(), oracle.occ[lo:hi]) and not hasattr(o, "row_shard")
+o = ComA_Occupancy(human_res=H, **kw)
+o.load(save_pth)
+assert o.human_res == H and np.array_equal(o.spatial_occupancy_grids.numpy(), oracle.occ) and o.used_count == 5
+o3 = ComA_Occupancy(human_res=1, **kw)
+o3.load(save_pth, shard=(rank, 3))               # another world size: assembled, then sliced
+l3, h3 = cdist.shard_slice(H, rank, 3)
+assert np.array_equal(o3.spatial_occupancy_grids.numpy(), oracle.occ[l3:h3])
+dist.barrier()
+if rank == 0:
+    single.export(save_pth=save_pth)
+dist.barrier()
+o = ComA_Occupancy(human_res=hi - lo, **kw)
+o.load(save_pth, shard=(rank, world))            # the single file wins when it exists
+assert o.human_res == hi - lo and np.array_equal(o.spatial_occupancy_grids.numpy(), oracle.occ[lo:hi])
+try:
+    ComA_Occupancy(human_res=H, **kw).load(os.path.join(out_dir, "missing.pickle"))
+    raise SystemExit("expected FileNotFoundError")
+except FileNotFoundError:
+    pass
+dist.destroy_process_group()
+print("RANK_OK", rank)
+"""
+
+
+def test_row_sharded_occupancy_export_over_gloo(tmp_path):
+    """SURVEY.md 7 "Memory at config 5": every rank pickles its own row slice (`..._rank{r}.pickle`, same keys as the reference's
+    export, utils/coma_occupancy.py:315-330); the shards re-assemble to the single-process export bit for bit and the loader
+    takes either form."""
+    script = tmp_path / "wshard.py"
+    script.write_text(_OCC_SHARD_EXPORT_WORKER)
+    port = 33500 + os.getpid() % 2000
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0 and f"RANK_OK {r}" in out, out
+
+
 def test_presets_match_reference_tables():
     import json
     from constants.coma.qual import QUAL_AFFORDANCE_EXTRACTION_HYPERPARAMS_DICT as Q
