@@ -115,10 +115,7 @@ _switched = threading.local()       # device that was current before stream_ptr(
 def check(rc: int, what: str):
     """Raise on a non-zero return code.  Every wrapper calls this right after its launch, so it is also where the device that
     stream_ptr() made current for that launch is handed back to the caller (the process-wide current device is not ours to change)."""
-    prev = getattr(_switched, "dev", None)
-    if prev is not None:
-        _switched.dev = None
-        torch.cuda.set_device(prev)
+    _restore()
     if rc != 0:
         raise ComaHipError(f"{what} failed ({rc}): {lib().coma_last_error().decode()}")
 
@@ -140,13 +137,41 @@ def stream_ptr(device=None):
     """Current stream of `device`, and that device made current for the ONE launch that follows (the C ABI launches under HIP's
     current device, so a tensor on cuda:1 with cuda:0 current would otherwise meet a stream of another device); check() puts
     the caller's device back."""
+    _restore()              # a launch that raised between its stream_ptr() and its check() left the switch behind: undo it first
     if device is not None:
         dev = torch.device(device)
         if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
-            if getattr(_switched, "dev", None) is None:
-                _switched.dev = torch.cuda.current_device()          # restored by check() after the launch
+            _switched.dev = torch.cuda.current_device()          # restored by check() after the launch
             torch.cuda.set_device(dev)
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _restore():
+    prev = getattr(_switched, "dev", None)
+    if prev is not None:
+        _switched.dev = None
+        torch.cuda.set_device(prev)
+
+
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def on_device(device):
+    """`with _lib.on_device(t.device) as stream:` -- the stream pointer for ANY NUMBER of launches on `device`, that device current
+    inside the block and the caller's device back afterwards whatever happens (exceptions included).  The one-shot stream_ptr() /
+    check() pair is for wrappers with exactly one launch; a wrapper that launches twice uses this."""
+    _restore()
+    dev = torch.device(device) if device is not None else None
+    prev = None
+    if dev is not None and dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(dev)
+    try:
+        yield C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    finally:
+        if prev is not None:
+            torch.cuda.set_device(prev)
 
 
 def vec3(v):

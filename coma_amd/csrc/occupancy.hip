@@ -577,12 +577,8 @@ extern "C" int coma_occupancy_fused(const float* q, int S, int H, int R, const d
   float* partial = reinterpret_cast<float*>(wsb + occ_ws_items(S, H, window) + occ_ws_off(H, R));
   hipLaunchKernelGGL(occupancy_rowprep_kernel, dim3((unsigned)H), dim3(256), 0, st, q, S, H, R, window, centers, voxel, thres, thres_sq_cut,
                      items, plane_off, rowsum);
-  static size_t lds_set = 0;                                     // the attribute is per function, not per launch: set it when it grows
-  if (lds > lds_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(occupancy_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(COMA_E_LAUNCH, "coma_occupancy_fused: cannot reserve %zu bytes of LDS", lds);
-    lds_set = lds;
-  }
+  static coma::LdsOptIn lds_opt;                                 // the attribute is per function AND per device: set it when it grows
+  if (int rc = coma::opt_in_lds(lds_opt, reinterpret_cast<const void*>(occupancy_fused_kernel), lds, "coma_occupancy_fused")) return rc;
   hipLaunchKernelGGL(occupancy_fused_kernel, dim3((unsigned)slabs, (unsigned)groups), dim3(kFusedThreads), lds, st, items, plane_off, rowsum, select,
                      S, H, R, P, window, groups, write_raw, centers, voxel, thres, thres_sq_cut, counts, partial);
   const int64_t R3 = (int64_t)R * RR;

@@ -907,13 +907,8 @@ extern "C" int sd_attention_wide_f16(const void* q, const void* k, const void* v
   hipStream_t s = (hipStream_t)stream;
 #define SD_WIDE_LAUNCH(DT)                                                                                                    \
   do {                                                                                                                        \
-    static bool attr_set = false;                                                                                             \
-    if (!attr_set) {                                                                                                          \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_wide_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds) != hipSuccess)                                                                        \
-        return fail(COMA_E_LAUNCH, "sd_attention_wide_f16: cannot reserve %zu bytes of LDS", lds);                            \
-      attr_set = true;                                                                                                        \
-    }                                                                                                                         \
+    static coma::LdsOptIn lds_opt;                                                                                            \
+    if (int rc = coma::opt_in_lds(lds_opt, reinterpret_cast<const void*>(attention_wide_kernel<DT>), lds, "sd_attention_wide_f16")) return rc; \
     hipLaunchKernelGGL((attention_wide_kernel<DT>), grid, dim3(256), lds, s, a);                                              \
   } while (0)
   if (d == 512) SD_WIDE_LAUNCH(16);

@@ -169,18 +169,43 @@ extern "C" int sd_model_destroy(void* model) {
 extern "C" int sd_model_register_buffer(void* model, void* ptr, size_t bytes, int flags) {
   if (!model || !ptr || bytes == 0) return fail(COMA_E_INVALID, "sd_model_register_buffer: bad args");
   Model* m = as_model(model);
-  char* c = static_cast<char*>(ptr);
-  for (auto& b : m->bufs) {
-    if (c >= b.ptr && c + bytes <= b.ptr + b.bytes) return COMA_OK;                     // already covered
-    if (c < b.ptr + b.bytes && b.ptr < c + bytes)                                          // partial overlap: grow to the union
-    {
-      char* lo = c < b.ptr ? c : b.ptr;
-      char* hi = c + bytes > b.ptr + b.bytes ? c + bytes : b.ptr + b.bytes;
-      b.ptr = lo; b.bytes = (size_t)(hi - lo); b.flags |= flags;
-      return COMA_OK;
+  char* lo = static_cast<char*>(ptr);
+  char* hi = lo + bytes;
+  // Fold EVERY entry the range touches into one (a range bridging two entries must not leave overlapping entries behind) and OR
+  // the flags also when the range was already covered: a buffer first seen as scratch and later registered SD_BUF_PERSISTENT
+  // (constants Python filled outside a plan) must be saved with the model.  Anything filled outside a plan has to be registered
+  // PERSISTENT by its owner; a persistent sub-range makes the whole entry persistent (larger file, never a missing constant).
+  for (size_t k = 0; k < m->bufs.size();) {
+    Buffer& b = m->bufs[k];
+    if (lo < b.ptr + b.bytes && b.ptr < hi) {
+      if (b.owned) {                          // library-allocated (loaded model): never merged away, it already covers what it must
+        if (lo >= b.ptr && hi <= b.ptr + b.bytes) { b.flags |= flags; return COMA_OK; }
+        return fail(COMA_E_INVALID, "sd_model_register_buffer: range straddles a buffer the model owns");
+      }
+      if (b.ptr < lo) lo = b.ptr;
+      if (b.ptr + b.bytes > hi) hi = b.ptr + b.bytes;
+      flags |= b.flags;
+      m->bufs.erase(m->bufs.begin() + (long)k);
+      continue;                               // the union may now reach entries already passed: the sweep below catches them
+    }
+    ++k;
+  }
+  // one more sweep for entries that only the grown union reaches
+  for (bool again = true; again;) {
+    again = false;
+    for (size_t k = 0; k < m->bufs.size(); ++k) {
+      Buffer& b = m->bufs[k];
+      if (!b.owned && lo < b.ptr + b.bytes && b.ptr < hi) {
+        if (b.ptr < lo) lo = b.ptr;
+        if (b.ptr + b.bytes > hi) hi = b.ptr + b.bytes;
+        flags |= b.flags;
+        m->bufs.erase(m->bufs.begin() + (long)k);
+        again = true;
+        break;
+      }
     }
   }
-  m->bufs.push_back(Buffer{c, bytes, flags, false});
+  m->bufs.push_back(Buffer{lo, (size_t)(hi - lo), flags, false});
   return COMA_OK;
 }
 
@@ -260,26 +285,54 @@ extern "C" int sd_model_replay(void* model, const char* plan_name, void* stream)
   return COMA_OK;
 }
 
-// ---- file format (little endian, version 1):
-//   "SDMODEL1" | u32 nbuf | { u64 bytes, u32 flags } x nbuf | u32 nbind | { char name[32], u32 buf, u64 offset, u64 bytes } x nbind
+// ---- file format (little endian, version 2):
+//   "SDMODEL2" | u64 file_bytes | u64 checksum (FNV-1a over 64-bit words of everything after this 24-byte header)
+//   | u32 nbuf | { u64 bytes, u32 flags } x nbuf | u32 nbind | { char name[32], u32 buf, u64 offset, u64 bytes } x nbind
 //   | u32 nplans | { char name[32], u32 nrec, PlanRec x nrec with every non-null pointer rewritten as ((buf + 1) << 48) | offset }
 //   | the bytes of every SD_BUF_PERSISTENT buffer, in registry order
+// A launch record only carries the START of every operand; what a launch touches beyond it follows from its integer arguments.  A
+// file is therefore accepted only if its size and checksum say it is exactly what sd_model_save wrote (from a model whose plans had
+// run): a truncated or corrupted file is refused before any device memory is allocated, not discovered as an out-of-bounds access.
 namespace sd {
-static bool wr(FILE* f, const void* p, size_t n) { return fwrite(p, 1, n, f) == n; }
+struct Hasher {                      // FNV-1a on little-endian 64-bit words, tail zero-padded; streaming
+  uint64_t h = 0xcbf29ce484222325ULL, carry = 0, total = 0;
+  int ncarry = 0;
+  void word(uint64_t w) { h = (h ^ w) * 0x100000001b3ULL; }
+  void update(const void* p, size_t n) {
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    total += n;
+    while (n && ncarry) { carry |= (uint64_t)*c++ << (8 * ncarry); --n; if (++ncarry == 8) { word(carry); carry = 0; ncarry = 0; } }
+    for (; n >= 8; n -= 8, c += 8) { uint64_t w; memcpy(&w, c, 8); word(w); }
+    for (; n; --n) { carry |= (uint64_t)*c++ << (8 * ncarry); ++ncarry; }
+  }
+  uint64_t digest() const { uint64_t r = h; if (ncarry) r = (r ^ carry) * 0x100000001b3ULL; return r; }
+};
+struct Writer {
+  FILE* f;
+  Hasher hash;
+  bool ok = true;
+  bool put(const void* p, size_t n) { hash.update(p, n); ok = ok && fwrite(p, 1, n, f) == n; return ok; }
+};
 static bool rd(FILE* f, void* p, size_t n) { return fread(p, 1, n, f) == n; }
+constexpr uint64_t kMaxBufIndex = 0xfffe, kMaxOffset = (1ULL << 48) - 1;
 }  // namespace sd
 
 extern "C" int sd_model_save(const void* model, const char* path) {
   if (!model || !path) return fail(COMA_E_INVALID, "sd_model_save: bad args");
   const Model* m = static_cast<const Model*>(model);
+  if (m->bufs.size() > kMaxBufIndex) return fail(COMA_E_INVALID, "sd_model_save: %zu buffers do not fit the 16-bit buffer field", m->bufs.size());
+  for (const auto& b : m->bufs)
+    if (b.bytes > kMaxOffset) return fail(COMA_E_INVALID, "sd_model_save: a buffer of %zu bytes does not fit the 48-bit offset field", b.bytes);
   FILE* f = fopen(path, "wb");
   if (!f) return fail(COMA_E_INVALID, "sd_model_save: cannot open %s", path);
-  bool ok = wr(f, "SDMODEL1", 8);
+  const uint64_t zero2[2] = {0, 0};
+  bool ok = fwrite("SDMODEL2", 1, 8, f) == 8 && fwrite(zero2, 1, 16, f) == 16;      // size + checksum are patched in at the end
+  Writer w{f};
   const uint32_t nbuf = (uint32_t)m->bufs.size();
-  ok = ok && wr(f, &nbuf, 4);
-  for (const auto& b : m->bufs) { const uint64_t by = b.bytes; const uint32_t fl = (uint32_t)b.flags; ok = ok && wr(f, &by, 8) && wr(f, &fl, 4); }
+  w.put(&nbuf, 4);
+  for (const auto& b : m->bufs) { const uint64_t by = b.bytes; const uint32_t fl = (uint32_t)b.flags; w.put(&by, 8); w.put(&fl, 4); }
   const uint32_t nbind = (uint32_t)m->binds.size();
-  ok = ok && wr(f, &nbind, 4);
+  w.put(&nbind, 4);
   for (const auto& kv : m->binds) {
     char name[32] = {0};
     strncpy(name, kv.first.c_str(), 31);
@@ -287,15 +340,15 @@ extern "C" int sd_model_save(const void* model, const char* path) {
     if (k < 0) { fclose(f); return fail(COMA_E_INVALID, "sd_model_save: binding '%s' is not inside a registered buffer", name); }
     const uint32_t kb = (uint32_t)k;
     const uint64_t off = (uint64_t)(kv.second.ptr - m->bufs[k].ptr), by = kv.second.bytes;
-    ok = ok && wr(f, name, 32) && wr(f, &kb, 4) && wr(f, &off, 8) && wr(f, &by, 8);
+    w.put(name, 32); w.put(&kb, 4); w.put(&off, 8); w.put(&by, 8);
   }
   const uint32_t nplans = (uint32_t)m->plans.size();
-  ok = ok && wr(f, &nplans, 4);
+  w.put(&nplans, 4);
   for (const auto& pl : m->plans) {
     char name[32] = {0};
     strncpy(name, pl.name.c_str(), 31);
     const uint32_t nrec = (uint32_t)pl.recs.size();
-    ok = ok && wr(f, name, 32) && wr(f, &nrec, 4);
+    w.put(name, 32); w.put(&nrec, 4);
     for (PlanRec r : pl.recs) {
       for (auto& q : r.p) {
         if (!q) continue;
@@ -303,7 +356,7 @@ extern "C" int sd_model_save(const void* model, const char* path) {
         if (k < 0) { fclose(f); return fail(COMA_E_INVALID, "sd_model_save: plan '%s' uses a pointer outside every registered buffer", name); }
         q = reinterpret_cast<void*>(((uint64_t)(k + 1) << 48) | (uint64_t)(static_cast<char*>(q) - m->bufs[k].ptr));
       }
-      ok = ok && wr(f, &r, sizeof r);
+      w.put(&r, sizeof r);
     }
   }
   std::vector<char> host;
@@ -311,8 +364,10 @@ extern "C" int sd_model_save(const void* model, const char* path) {
     if (!(b.flags & SD_BUF_PERSISTENT)) continue;
     host.resize(b.bytes);
     if (hipMemcpy(host.data(), b.ptr, b.bytes, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return fail(COMA_E_LAUNCH, "sd_model_save: device read failed"); }
-    ok = ok && wr(f, host.data(), b.bytes);
+    w.put(host.data(), b.bytes);
   }
+  const uint64_t trailer[2] = {24 + w.hash.total, w.hash.digest()};
+  ok = ok && w.ok && fseek(f, 8, SEEK_SET) == 0 && fwrite(trailer, 1, 16, f) == 16;
   ok = (fclose(f) == 0) && ok;
   return ok ? COMA_OK : fail(COMA_E_INVALID, "sd_model_save: short write to %s", path);
 }
@@ -324,12 +379,22 @@ extern "C" int sd_model_load(const char* path, void** model) {
   Model* m = new Model();
   auto bail = [&](const char* what) { fclose(f); sd_model_destroy(m); return fail(COMA_E_INVALID, "sd_model_load: %s (%s)", what, path); };
   char magic[8];
-  if (!rd(f, magic, 8) || memcmp(magic, "SDMODEL1", 8)) return bail("not a model file");
+  uint64_t header[2];
+  if (!rd(f, magic, 8) || memcmp(magic, "SDMODEL2", 8) || !rd(f, header, 16)) return bail("not a model file (or one of format version 1)");
+  {
+    // first pass: the file must be exactly what sd_model_save wrote -- size and checksum -- before anything is allocated or trusted
+    Hasher hs;
+    std::vector<char> chunk(1 << 22);
+    for (size_t n; (n = fread(chunk.data(), 1, chunk.size(), f)) > 0;) hs.update(chunk.data(), n);
+    if (24 + hs.total != header[0]) return bail("truncated or over-long file");
+    if (hs.digest() != header[1]) return bail("checksum mismatch: the file is corrupt");
+    if (fseek(f, 24, SEEK_SET) != 0) return bail("seek failed");
+  }
   uint32_t nbuf = 0;
-  if (!rd(f, &nbuf, 4) || nbuf > 1000000) return bail("bad buffer count");
+  if (!rd(f, &nbuf, 4) || nbuf > kMaxBufIndex) return bail("bad buffer count");
   for (uint32_t k = 0; k < nbuf; ++k) {
     uint64_t by; uint32_t fl;
-    if (!rd(f, &by, 8) || !rd(f, &fl, 4) || by == 0) return bail("bad buffer table");
+    if (!rd(f, &by, 8) || !rd(f, &fl, 4) || by == 0 || by > kMaxOffset) return bail("bad buffer table");
     void* d = nullptr;
     if (hipMalloc(&d, by) != hipSuccess) return bail("out of device memory");
     m->bufs.push_back(Buffer{static_cast<char*>(d), (size_t)by, (int)fl, true});

@@ -611,12 +611,8 @@ extern "C" int sd_xattn_chain_f16(const void* attn1_out, const void* h, const vo
   g.M = (int)rows; g.rows_per_sample = rows_per_sample; g.lk = lk; g.ldv2 = ldv2; g.stage = debug_out ? debug_stage : 0;
   g.scale_log2 = 0.15811388300841897f * 1.4426950408889634f;      // 40^-0.5 * log2(e)
   g.eps = eps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xc::xchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, xc::LDS_BYTES) != hipSuccess)
-      return fail(COMA_E_LAUNCH, "sd_xattn_chain_f16: cannot reserve %d bytes of LDS", xc::LDS_BYTES);
-    attr_set = true;
-  }
+  static coma::LdsOptIn lds_opt;
+  if (int rc = coma::opt_in_lds(lds_opt, reinterpret_cast<const void*>(xc::xchain_kernel), xc::LDS_BYTES, "sd_xattn_chain_f16")) return rc;
   hipLaunchKernelGGL(xc::xchain_kernel, dim3((unsigned)(rows / xc::TM)), dim3(xc::NW * 64), xc::LDS_BYTES, (hipStream_t)stream, g);
   return check_launch("xchain_kernel");
 }
@@ -641,12 +637,8 @@ extern "C" int sd_xfront_f16(const void* x, const float* gn_affine, const void* 
   g.x = (const _Float16*)x; g.gn_affine = gn_affine; g.wpi = (const _Float16*)wpi; g.bpi = (const _Float16*)bpi; g.g1 = (const _Float16*)gamma1;
   g.b1 = (const _Float16*)beta1; g.wqk = (const _Float16*)wqk; g.wv = (const _Float16*)wv; g.h = (_Float16*)h; g.qk = (_Float16*)qk;
   g.vt = (_Float16*)vt; g.M = (int)rows; g.rows_per_sample = rows_per_sample; g.ldv = ldv; g.eps = eps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xc::xfront_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, xc::LDS_BYTES) != hipSuccess)
-      return fail(COMA_E_LAUNCH, "sd_xfront_f16: cannot reserve %d bytes of LDS", xc::LDS_BYTES);
-    attr_set = true;
-  }
+  static coma::LdsOptIn lds_opt;
+  if (int rc = coma::opt_in_lds(lds_opt, reinterpret_cast<const void*>(xc::xfront_kernel), xc::LDS_BYTES, "sd_xfront_f16")) return rc;
   hipLaunchKernelGGL(xc::xfront_kernel, dim3((unsigned)(rows / xc::TM)), dim3(xc::NW * 64), xc::LDS_BYTES, (hipStream_t)stream, g);
   return check_launch("xfront_kernel");
 }

@@ -365,12 +365,8 @@ extern "C" int sd_xtail_f16(const void* n3, const void* h2, const void* x, const
   g.n3 = (const _Float16*)n3; g.h2 = (const _Float16*)h2; g.x = (const _Float16*)x; g.w1 = (const _Float16*)w1; g.b1 = (const _Float16*)b1;
   g.w2 = (const _Float16*)w2; g.b2 = (const _Float16*)b2; g.wpo = (const _Float16*)wpo; g.bpo = (const _Float16*)bpo; g.out = (_Float16*)out;
   g.colstats = colstats; g.M = (int)rows;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(xt::xtail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, xt::LDS_BYTES) != hipSuccess)
-      return fail(COMA_E_LAUNCH, "sd_xtail_f16: cannot reserve %d bytes of LDS", xt::LDS_BYTES);
-    attr_set = true;
-  }
+  static coma::LdsOptIn lds_opt;
+  if (int rc = coma::opt_in_lds(lds_opt, reinterpret_cast<const void*>(xt::xtail_kernel), xt::LDS_BYTES, "sd_xtail_f16")) return rc;
   hipLaunchKernelGGL(xt::xtail_kernel, dim3((unsigned)(rows / xt::TM)), dim3(xt::NW * 64), xt::LDS_BYTES, (hipStream_t)stream, g);
   return check_launch("xtail_kernel");
 }

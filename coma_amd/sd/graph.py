@@ -197,8 +197,16 @@ class LaunchGraph:
         """Record the launch list into the library-owned plan (once), run it eagerly once (module loading and argument checks happen
         outside any capture); the library captures its hipGraph on the first replay."""
         if not self._recorded:
-            self.model.record(self.plan, self.run)
-            assert self.model.num_launches(self.plan) >= len(self.launches)
+            def record_checked():
+                # every closure must end up in the plan: one that calls no sd_* entry point (a stray torch op) would execute now,
+                # during recording, and be missing from every replay and from a saved model
+                for fn, (tag, _) in zip(self.launches, self.tags):
+                    n0 = self.model.num_launches(self.plan)
+                    fn()
+                    if self.model.num_launches(self.plan) <= n0:
+                        raise RuntimeError(f"launch '{tag}' of plan '{self.plan}' recorded nothing: only sd_* entry points may be added to a LaunchGraph")
+            assert len(self.tags) == len(self.launches)
+            self.model.record(self.plan, record_checked)
             self._recorded = True
             self.model.run(self.plan)
             torch.cuda.synchronize(self.device)
@@ -223,5 +231,6 @@ class LaunchGraph:
                     self.run()
             return self._tg.replay()
         if not self._recorded:
-            self.capture()
+            self.capture()            # recorded, then run eagerly once: that run IS this call's execution (no second pass over the step)
+            return
         self.model.replay(self.plan)

@@ -4,13 +4,25 @@ for replays.  A saved model (``save``) is everything a caller without Python nee
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
 from .. import _lib
 
 BUF_PERSISTENT, BUF_ZEROED = 1, 2
-_recording = None          # the SdModel this thread is recording into (ops._p registers every tensor it is handed)
+
+
+class _Recording(threading.local):
+    model = None           # the SdModel THIS THREAD is recording into (ops._p registers every tensor it is handed); thread-local like
+                           # the C side's t_plan, so that a second thread's launches are neither registered nor swallowed
+
+
+_rec = _Recording()
+
+
+def recording():
+    return _rec.model
 
 
 class SdModel:
@@ -62,13 +74,12 @@ class SdModel:
     # ---- plans
     def record(self, plan, fn):
         """Run `fn` (Python code that calls the sd_* wrappers of ops.py) with every launch recorded into `plan` instead of issued."""
-        global _recording
         _lib.check(_lib.lib().sd_model_record_begin(self.h, plan.encode()), "sd_model_record_begin")
-        _recording = self
+        _rec.model = self
         try:
             fn()
         finally:
-            _recording = None
+            _rec.model = None
             _lib.check(_lib.lib().sd_model_record_end(self.h), "sd_model_record_end")
 
     def num_launches(self, plan):

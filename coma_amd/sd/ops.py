@@ -28,8 +28,9 @@ def _p(t, name="tensor", dtype=F16):
     if t is None:
         return None
     from . import model
-    if model._recording is not None:            # a plan is being recorded: whatever it points into belongs to the model
-        model._recording.register(t)            # (buffers of LaunchGraph.buf were registered as scratch before: no-op for them)
+    rec = model.recording()
+    if rec is not None:                         # this thread is recording a plan: whatever it points into belongs to the model
+        rec.register(t)                         # (buffers of LaunchGraph.buf were registered as scratch before: no-op for them)
     return _lib.ptr(t, dtype, name).value
 
 

@@ -31,8 +31,8 @@ def test_single_gpu_line(hip_lib):
     assert "workload" in line["config"] and line["secondary"]["value"] > 0
     assert line["roofline"]["algorithmic_bytes"] > 0                       # so that traffic / algorithmic is on the line
     occ = line["occupancy"]
-    assert occ["value"] > 0 and occ["roofline"]["traffic"] > 0 and 0 < occ["roofline"]["hard_floor_frac"] < occ["roofline"]["frac"] < 1
-    assert line["adaptive_loop"]["value"] > 0
+    assert occ["value"] > 0 and occ["roofline"]["traffic"] > 0 and 0 < occ["roofline"]["frac"] < occ["roofline"]["structure_b_frac"] < 1
+    assert line["adaptive_loop"]["value"] > line["adaptive_loop_b1"]["value"] > 0        # the one-image-per-call shape is a stated number
 
 
 def test_two_ranks_control_flow(hip_lib):

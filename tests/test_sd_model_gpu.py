@@ -138,4 +138,62 @@ def test_model_python_roundtrip_and_errors(tmp_path, hip_lib):
     bad.run("p")                                                      # runs from the caller's buffers
     torch.cuda.synchronize()
     assert float(out.abs().max()) == 0.0                              # LayerNorm of zeros with beta = 0
-    assert mm._recording is None
+    assert mm.recording() is None
+
+
+def test_model_file_is_verified_before_it_is_trusted(tmp_path, hip_lib):
+    """Format version 2: a truncated file, a file with one flipped byte in the launch records and one with a flipped byte
+    in the weights are all refused by sd_model_load (size / checksum), nothing is launched; and a buffer first registered as scratch,
+    later registered SD_BUF_PERSISTENT (constants filled outside a plan), is saved with the model; a range bridging two registered
+    buffers leaves one entry."""
+    from coma_amd._lib import ComaHipError
+    from coma_amd.sd import ops
+    from coma_amd.sd.model import BUF_PERSISTENT, SdModel
+    m = SdModel(DEV)
+    big = torch.zeros(3, 64, 320, dtype=torch.float16, device=DEV)              # one allocation, three row blocks
+    x, gamma_beta, out = big[0], big[1], big[2]
+    import ctypes
+    from coma_amd import _lib
+
+    def reg(t, flags):                                                           # the C entry point on exactly the bytes of `t`
+        _lib.check(_lib.lib().sd_model_register_buffer(m.h, ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size(), flags),
+                   "sd_model_register_buffer")
+    m._keep.append(big)
+    reg(x, 0)                                                                    # scratch ...
+    reg(out, 0)
+    reg(big[0:2, 32:], 0)                                                        # ... a range bridging x and gamma_beta, then all three:
+    reg(big, 0)                                                                  # one entry is left (a save would refuse overlapping ones)
+    gamma_beta[0].fill_(2.0)                                                     # constants filled OUTSIDE a plan
+    gamma_beta[1].fill_(0.5)
+    reg(gamma_beta, BUF_PERSISTENT)                                              # covered already: the flag must still be OR-ed in
+    x.copy_(torch.randn(64, 320, device=DEV).half())
+    m.bind("x", x)
+    m.bind("out", out)
+    m.record("p", lambda: ops.layernorm(x, gamma_beta[0], gamma_beta[1], out, rows=64, c=320))
+    m.run("p")
+    torch.cuda.synchronize()
+    want = out.clone()
+    xin = x.clone()
+    path = tmp_path / "m.sdm"
+    m.save(path)
+    blob = path.read_bytes()
+    assert blob[:8] == b"SDMODEL2" and int.from_bytes(blob[8:16], "little") == len(blob)
+    # the round trip keeps the constants (gamma = 2, beta = 0.5 live in the persistent range)
+    m2 = SdModel.load(path, DEV)
+    p, n = m2.binding("x")
+    po, no = m2.binding("out")
+    assert n == xin.numel() * 2 and no == n
+    _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(p), ctypes.c_void_p(xin.data_ptr()), n, _lib.stream_ptr(xin.device)), "copy")
+    m2.run("p")
+    got = torch.empty_like(want)
+    _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(got.data_ptr()), ctypes.c_void_p(po), no, _lib.stream_ptr(got.device)), "copy")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and float(want.float().mean()) != 0.0
+    for name, data in (("trunc", blob[:-100]), ("long", blob + b"\0" * 8),
+                       ("rec", blob[:200] + bytes([blob[200] ^ 0x40]) + blob[201:]),
+                       ("weights", blob[:-5] + bytes([blob[-5] ^ 1]) + blob[-4:]),
+                       ("v1", b"SDMODEL1" + blob[8:])):
+        bad = tmp_path / f"{name}.sdm"
+        bad.write_bytes(data)
+        with pytest.raises(ComaHipError, match="truncated|checksum|not a model file"):
+            SdModel.load(bad, DEV)
