@@ -1,0 +1,136 @@
+// sd_smallconv.hip -- 3x3 convolutions with a handful of channels on one side (gfx950): the two ends of the VAE.
+//
+// sd_conv3x3_small_n_f16: GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with n <= 4 OUTPUT channels --
+//   the decoder's conv_norm_out -> SiLU -> conv_out (128 -> 3 at 512 x 512; self.vae.decode, utils/adaptive_mask_inpainting.py:1086,
+//   :1112).  Through the implicit GEMM this layer computed a 64-column tile for 3 channels (0.45 ms per 8 images) behind a separate
+//   GroupNorm pass that read and wrote the 0.5 GB tensor once more.  Here a workgroup owns a 16 x 16 pixel tile: the (18 x 18) x 64
+//   channel halo patch is normalised, activated and rounded to fp16 on its way into LDS (what the GroupNorm kernel would have
+//   stored), the weights of the chunk live in registers as 18 MFMA operands (n padded to 16 rows, 9 taps x 64 channels), and every
+//   `v_mfma_f32_16x16x32_f16` takes its pixel operand with one conflict-free 16-byte LDS read.  Bound: HBM -- the input read once.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "sd_plan.h"
+#include "../../include/sd_hip.h"
+
+namespace sd {
+namespace sc {
+
+using coma::check_launch;
+using coma::fail;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int kTile = 16, kHalo = 18, kChunk = 64;       // pixels per tile edge, with halo, channels staged per pass
+
+// slot of 16-byte channel octet v (0..7) of halo pixel p: 16 consecutive pixels x one octet hit 16 distinct bank groups
+__device__ __forceinline__ int slot(int p, int v) { return p * 8 + (v ^ ((p >> 1) & 7)); }
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void conv3x3_small_n_kernel(const _Float16* __restrict__ x, const float* __restrict__ affine, int silu,
+                                                              const _Float16* __restrict__ w, const _Float16* __restrict__ bias, int n_out,
+                                                              int H, int W, _Float16* __restrict__ out, int ldo) {
+  static_assert(C % kChunk == 0, "channels in chunks of 64");
+  __shared__ half8 tile[kHalo * kHalo * 8];               // 41 472 bytes
+  __shared__ float2 aff[C];
+  const int b = blockIdx.z, ty0 = blockIdx.y * kTile, tx0 = blockIdx.x * kTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lp = lane & 15, lo = lane >> 4;
+
+  if (affine)
+    for (int i = tid; i < C; i += 256) aff[i] = reinterpret_cast<const float2*>(affine)[(size_t)b * C + i];
+
+  float4v acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int chunk = 0; chunk < C / kChunk; ++chunk) {
+    // this chunk's weights -> registers (18 MFMA operands): operand row = output channel (zero rows above n_out), K octet = lane >> 4
+    half8 wf[9][kChunk / 32];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kh = 0; kh < kChunk / 32; ++kh) {
+        half8 q = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (lp < n_out) q = *reinterpret_cast<const half8*>(w + ((size_t)lp * 9 + tap) * C + chunk * kChunk + kh * 32 + lo * 8);
+        wf[tap][kh] = q;
+      }
+    __syncthreads();                                       // the previous chunk's operand reads are done; `aff` is visible
+    for (int idx = tid; idx < kHalo * kHalo * 8; idx += 256) {
+      const int p = idx >> 3, v = idx & 7;
+      const int r = p / kHalo, c = p - r * kHalo;
+      const int y = ty0 + r - 1, xx = tx0 + c - 1;
+      half8 q = {0, 0, 0, 0, 0, 0, 0, 0};                  // zero padding applies to the ACTIVATED tensor
+      if (y >= 0 && y < H && xx >= 0 && xx < W) {
+        q = *reinterpret_cast<const half8*>(x + (((size_t)b * H + y) * W + xx) * C + chunk * kChunk + v * 8);
+        if (affine) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float2 a = aff[chunk * kChunk + v * 8 + e];
+            float f = fmaf((float)q[e], a.x, a.y);
+            if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
+            q[e] = (_Float16)f;
+          }
+        }
+      }
+      tile[slot(p, v)] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+      for (int kh = 0; kh < kChunk / 32; ++kh) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int p = (4 * wave + t + dy) * kHalo + lp + dx;
+          const half8 px = tile[slot(p, kh * 4 + lo)];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tap][kh], px, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[n][pixel]: lane = pixel + 16 * (n / 4), register = n % 4 -> lanes 0..15 hold the n_out <= 4 real channels of their pixel
+  if (lane < 16) {
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = (bias && j < n_out) ? (float)bias[j] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int y = ty0 + 4 * wave + t, xx = tx0 + lp;
+      if (y < H && xx < W) {
+        half8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < n_out) o[j] = (_Float16)(acc[t][j] + bv[j]);
+        *reinterpret_cast<half8*>(out + (((size_t)b * H + y) * W + xx) * ldo) = o;
+      }
+    }
+  }
+}
+
+}  // namespace sc
+}  // namespace sd
+
+extern "C" int sd_conv3x3_small_n_f16(const void* x, const float* gn_affine, int silu, const void* w, const void* bias, int batch, int h,
+                                      int w_, int c, int n, void* out, int ldo, void* stream) {
+  using namespace sd::sc;
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_CONV_SMALL_N;
+    r.p[0] = (void*)x; r.p[1] = (void*)gn_affine; r.p[2] = (void*)w; r.p[3] = (void*)bias; r.p[4] = out;
+    r.i[0] = silu; r.i[1] = batch; r.i[2] = h; r.i[3] = w_; r.i[4] = c; r.i[5] = n; r.i[6] = ldo;
+    return sd::plan_record(r);
+  }
+  if (!x || !w || !out) return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: null pointer");
+  if (c != 128) return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: c = %d (built for 128 input channels)", c);
+  if (n < 1 || n > 4 || batch <= 0 || h <= 0 || w_ <= 0 || ldo < 8 || ldo % 8)
+    return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: bad shape n=%d batch=%d h=%d w=%d ldo=%d", n, batch, h, w_, ldo);
+  if ((size_t)batch * h * w_ * c >= (1ull << 40)) return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: tensor too large");
+  const dim3 grid((unsigned)((w_ + kTile - 1) / kTile), (unsigned)((h + kTile - 1) / kTile), (unsigned)batch);
+  hipLaunchKernelGGL(conv3x3_small_n_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, gn_affine, silu,
+                     (const _Float16*)w, (const _Float16*)bias, n, h, w_, (_Float16*)out, ldo);
+  return check_launch("conv3x3_small_n_kernel");
+}

@@ -166,6 +166,19 @@ class LaunchGraph:
                  flops=2 * rows * c * (8 * c + 4 * c + c), tag=f"xtail rows={rows} C={c}", nbytes=2 * (4 * rows * c + 13 * c * c))
         return out
 
+    def gn_silu_conv3x3_small_n(self, x, gamma, beta, w, bias, out, *, batch, h, w_, c, n, eps, silu=True):
+        """GroupNorm (+ SiLU) -> 3x3 convolution with n <= 4 output channels in one pass over x: only the per-(sample, channel) affine
+        table is computed (statistics from the producer's column sums when it left them), the normalised tensor is never written."""
+        hw = h * w_
+        stats = self.gn_scratch(batch, hw)
+        cs0 = self._colstats.get(x.data_ptr()) if hw % 32 == 0 else None
+        self.add(lambda: ops.groupnorm_table(x, gamma, beta, stats, batch=batch, hw=hw, c0=c, eps=eps, colstats0=cs0),
+                 tag=f"groupnorm(table) B={batch} hw={hw} C={c}")
+        self.add(lambda: ops.conv3x3_small_n(x, w, out, batch=batch, h=h, w_=w_, c=c, n=n, bias=bias, gn_affine=stats, silu=silu,
+                                             ldo=out.shape[-1]),
+                 flops=2 * batch * hw * n * 9 * c, tag=f"conv3x3(small n) B={batch} {h}x{w_} C={c} n={n}", nbytes=2 * batch * hw * (c + 8))
+        return out
+
     def attention_wide(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
         self.add(lambda: ops.attention_wide(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
                                             scale=d ** -0.5),

@@ -270,3 +270,11 @@ def winograd_output(m, out, *, batch, h, w, n, ldm=0, bias=None, bias_bn=None, l
                                            _p(res, "res"), ldr, _p(out, "out"), ldo, 1 if silu else 0, _stream(out))
     _lib.check(rc, "sd_winograd_output_f16")
     return out
+
+
+def conv3x3_small_n(x, w, out, *, batch, h, w_, c, n, bias=None, gn_affine=None, silu=False, ldo=64):
+    """out[:, 0:n] = conv3x3(act(x * scale + shift)) + bias for n <= 4 output channels (VAE decoder conv_norm_out + SiLU + conv_out)."""
+    rc = _lib.lib().sd_conv3x3_small_n_f16(_p(x, "x"), _p(gn_affine, "gn_affine", torch.float32), 1 if silu else 0, _p(w, "w"), _p(bias, "bias"),
+                                           batch, h, w_, c, n, _p(out, "out"), ldo, _stream(out))
+    _lib.check(rc, "sd_conv3x3_small_n_f16")
+    return out

@@ -20,6 +20,7 @@ class _Cfg(dict):
 
 
 class _VaeBase:
+    fused_conv_out = True        # class-level switch (tests / A-B): False = GroupNorm kernel + 64-column implicit-GEMM tile for conv_out
     fused_attention = True       # class-level switch (tests / A-B): False = QK^T GEMM -> softmax -> PV GEMM through memory
 
     def __init__(self, state, batch, device, cfg, use_graph=True, plan="decode"):
@@ -119,12 +120,20 @@ class HipVaeDecoder(_VaeBase):
                 g.conv(x, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout, n=cout,
                        taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
                 x, H, W = o, 2 * H, 2 * W
-        gn = g.buf(B * H * W, cin)
-        g.groupnorm(x, s["decoder.conv_norm_out.weight"], s["decoder.conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin,
-                    eps=1e-6, silu=True)
         self.image = g.buf(B * H * W, 64, zero=True)          # 3 valid channels
-        g.conv(gn, conv_weight(s["decoder.conv_out.weight"], cout_pad=64), self.image, batch=B, in_h=H, in_w=W, c0=cin, n=64,
-               taps=9, bias=pad_vec(s["decoder.conv_out.bias"], 64))
+        nout = s["decoder.conv_out.weight"].shape[0]
+        if self.fused_conv_out and cin == 128 and nout <= 4:
+            # conv_norm_out -> SiLU -> conv_out as ONE pass over the last feature map (sd_conv3x3_small_n_f16): no normalised copy of
+            # the 0.5 GB tensor, no 64-column GEMM tile for 3 channels
+            g.gn_silu_conv3x3_small_n(x, s["decoder.conv_norm_out.weight"], s["decoder.conv_norm_out.bias"],
+                                      conv_weight(s["decoder.conv_out.weight"]), s["decoder.conv_out.bias"].contiguous(), self.image,
+                                      batch=B, h=H, w_=W, c=cin, n=nout, eps=1e-6, silu=True)
+        else:
+            gn = g.buf(B * H * W, cin)
+            g.groupnorm(x, s["decoder.conv_norm_out.weight"], s["decoder.conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin,
+                        eps=1e-6, silu=True)
+            g.conv(gn, conv_weight(s["decoder.conv_out.weight"], cout_pad=64), self.image, batch=B, in_h=H, in_w=W, c0=cin, n=64,
+                   taps=9, bias=pad_vec(s["decoder.conv_out.bias"], 64))
         self.out_h, self.out_w = H, W
         g.model.bind("z", self.z)
         g.model.bind("image", self.image)

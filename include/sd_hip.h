@@ -192,12 +192,23 @@ int sd_xattn_chain_f16(const void* attn1_out, const void* h, const void* wo1, co
  *   sd_winograd_input_f16   v fp16 [16][T][c0+c1] = B^T d B of every 4x4 input patch (two concatenated NHWC sources, zero pad)
  *   sd_winograd_weight_f16  u fp16 [16][n][c] = G g G^T of w fp16 [n][9][c] (computed in fp32, rounded once; at prep time)
  *   sd_winograd_output_f16  out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] + bias + per-sample bias, SiLU, + residual
- * h, w even; channel counts multiples of 8.
+ * h, w even; channel counts multiples of 8.  Measurement probe (profiles/r04_notes.md 1): not part of any network plan, not recordable.
  * replaces: diffusers Conv2d(3x3) inside self.unet(...) / self.vae.decode, utils/adaptive_mask_inpainting.py:1001-1007, :1086, :1112. */
 int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, void* v, void* stream);
 int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream);
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
                            const void* res, int ldr, void* out, int ldo, int silu, void* stream);
+
+/* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with FEW (n <= 4) output channels:
+ *   out[m, 0:n] = conv3x3(act(x * scale + shift))[m, 0:n] + bias,   act = SiLU if silu else identity
+ * x fp16 NHWC [batch, h, w, c] (c = 128); gn_affine fp32 [batch][c][2] = (scale, shift) per sample and channel (the table of
+ * sd_groupnorm_table_f16) or NULL for a plain convolution; w fp16 [n][9][c]; bias fp16 [n] or NULL; out fp16 [batch*h*w, ldo]
+ * (ldo >= 8, multiple of 8): channels 0..7 of every pixel are written (n results + zeros), channels >= 8 are left alone.
+ * The normalised tensor is never written: the halo patch of a 16 x 16 pixel tile is activated on its way into LDS and rounded to
+ * fp16 there, i.e. the result equals GroupNorm kernel -> convolution up to fp32 summation order.  Recordable.
+ * replaces: decoder.conv_norm_out + SiLU + decoder.conv_out of AutoencoderKL (self.vae.decode, utils/adaptive_mask_inpainting.py:1086, :1112). */
+int sd_conv3x3_small_n_f16(const void* x, const float* gn_affine, int silu, const void* w, const void* bias, int batch, int h, int w_,
+                           int c, int n, void* out, int ldo, void* stream);
 
 /* Row softmax in place over fp16 [rows, n] with scale (VAE mid-block attention, un-fused). */
 int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream);

@@ -8,13 +8,15 @@ from coma_amd.sd import vae as vae_mod
 from coma_amd.sd.vae import HipAutoencoderKL
 if "--unfused" in sys.argv:
     vae_mod._VaeBase.fused_attention = False          # A/B: QK^T GEMM -> softmax -> PV GEMM through memory
+if "--gemm-conv-out" in sys.argv:
+    vae_mod._VaeBase.fused_conv_out = False           # A/B: GroupNorm kernel + 64-column implicit-GEMM tile for the decoder's conv_out
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = "cuda:0"
 vae = HipAutoencoderKL(weights.random_state(weights.vae_shapes(), seed=1), batch=B, device=dev)
 vae.dec.z.copy_(torch.randn(vae.dec.z.shape, device=dev).half()); vae.dec.z[:, :, 4:] = 0
 vae.enc.x.copy_(torch.randn(vae.enc.x.shape, device=dev).half()); vae.enc.x[:, :, 3:] = 0
 for name, m, run in (("decoder", vae.dec, vae.dec.decode_static), ("encoder", vae.enc, vae.enc.encode_static)):
-    run(); torch.cuda.synchronize()
+    run(); run(); torch.cuda.synchronize()       # record + eager run, then the graph capture
     t0 = time.perf_counter()
     for _ in range(3): run()
     torch.cuda.synchronize()

@@ -60,7 +60,7 @@ def test_batched_cli_writes_the_same_files_and_images(tmp_path, hip_lib):
     a = np.asarray(Image.open(tmp_path / "out_b1" / f1[0])).astype(np.int32)
     b = np.asarray(Image.open(tmp_path / "out_b1" / f1[1])).astype(np.int32)
     assert np.abs(a - b).mean() > 10 * max(worst_mean, 0.05)
-    assert worst_mean <= 1.0 and worst_frac <= 2e-2
+    assert worst_mean <= 0.4 and worst_frac <= 1e-3           # measured 0.19 grey levels / no pixel off by more than 8
     # skip_done: a second run finds every file and writes nothing
     mt = {f: os.path.getmtime(tmp_path / "out_b4" / f) for f in f4}
     _run(tmp_path, tmp_path / "out_b4", 4)

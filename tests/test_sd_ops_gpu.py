@@ -665,3 +665,58 @@ def test_layernorm_folded_into_the_v_transposed_projection(ops, L, C):
     real = ((j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)) < L
     close(out[:, :, real], ref[:, :, real], tol=4e-3)
     assert bool(torch.isfinite(out.float()).all())
+
+
+@pytest.mark.parametrize("B,H,W,n,norm,silu", [(2, 32, 48, 3, True, True), (1, 24, 40, 3, True, True), (2, 16, 16, 4, True, False),
+                                               (1, 50, 21, 1, False, False), (1, 64, 64, 3, False, False)])
+def test_conv3x3_small_n_with_folded_groupnorm(ops, B, H, W, n, norm, silu):
+    """sd_conv3x3_small_n_f16 (VAE decoder conv_norm_out + SiLU + conv_out in one pass) against GroupNorm -> SiLU -> conv2d in fp32:
+    tiles ragged against the 16 x 16 workgroup tile, n = 1 / 3 / 4, with and without the folded GroupNorm; channels n..7 of every output
+    pixel are zero and channels >= 8 untouched."""
+    C, hw = 128, H * W
+    x = rnd(B * hw, C, seed=1) * 1.5 + 0.3
+    w = rnd(n, 9, C, seed=2, scale=(9 * C) ** -0.5)
+    b = rnd(n, seed=3)
+    ga, be = rnd(C, seed=4) * 0.2 + 1, rnd(C, seed=5) * 0.2
+    out = torch.full((B * hw, 64), 7.0, dtype=F16, device=DEV)
+    table = None
+    if norm:
+        table = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+        ops.groupnorm_table(x.to(DEV), ga.to(DEV), be.to(DEV), table, batch=B, hw=hw, c0=C, eps=1e-6)
+    ops.conv3x3_small_n(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=n, bias=b.to(DEV), gn_affine=table, silu=silu)
+    y = so.groupnorm_ref(x, ga, be, batch=B, hw=hw, eps=1e-6, silu=silu) if norm else x.float()
+    ref = so.conv_ref(y.half().float(), w, batch=B, h=H, w_=W, taps=9, bias=b)          # the activation is rounded to fp16, as stored
+    o = out.float().cpu()
+    close(o[:, :n], ref)
+    assert float(o[:, n:8].abs().max()) == 0.0 and bool((o[:, 8:] == 7.0).all())
+    with pytest.raises(Exception, match="128 input channels"):
+        ops.conv3x3_small_n(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=64, n=n)
+    with pytest.raises(Exception, match="bad shape"):
+        ops.conv3x3_small_n(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=5)
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,n", [(2, 16, 16, 64, 0, 128), (1, 8, 12, 64, 64, 64), (3, 32, 32, 320, 0, 320)])
+def test_winograd_f2x2_3x3_chain_equals_the_direct_convolution(ops, B, H, W, c0, c1, n):
+    """The measured Winograd probe (profiles/r04_notes.md 1; not part of the UNet / VAE plans): input transform -> 16 plane products
+    through sd_conv_gemm_f16(nbatch_z = 16) -> output transform (+ bias, per-sample bias, SiLU, residual) against conv2d in fp32.  Two
+    fp16 roundings more than the direct path (transformed activations, plane products): bar 4e-3 instead of 3e-3."""
+    C, M, T = c0 + c1, B * H * W, B * H * W // 4
+    x0 = rnd(M, c0, seed=1)
+    x1 = rnd(M, c1, seed=2) if c1 else None
+    w = rnd(n, 9, C, seed=3, scale=(9 * C) ** -0.5)
+    b, bb, r = rnd(n, seed=4), rnd(B, n, seed=5), rnd(M, n, seed=6)
+    V = torch.empty(16, T, C, dtype=F16, device=DEV)
+    U = torch.empty(16, n, C, dtype=F16, device=DEV)
+    P = torch.empty(16, T, n, dtype=F16, device=DEV)
+    out = torch.empty(M, n, dtype=F16, device=DEV)
+    ops.winograd_weight(w.reshape(n, -1).to(DEV), U, n=n, c=C)
+    ops.winograd_input(x0.to(DEV), V, batch=B, h=H, w=W, c0=c0, x1=x1.to(DEV) if c1 else None, c1=c1)
+    ops.conv_gemm(V, U, P, batch=T, in_h=1, in_w=1, c0=C, n=n, nbatch_z=16, stride_a=T * C, stride_w=n * C, stride_out=T * n)
+    ops.winograd_output(P, out, batch=B, h=H, w=W, n=n, bias=b.to(DEV), bias_bn=bb.to(DEV), res=r.to(DEV), silu=True)
+    xc = torch.cat([x0, x1], -1) if c1 else x0
+    close(out, so.conv_ref(xc, w, batch=B, h=H, w_=W, taps=9, bias=b, bias_bn=bb, res=r, silu=True), tol=4e-3)
+    # the weight transform itself: G g G^T in fp32, rounded once
+    g = w.float().reshape(n, 3, 3, C)
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float32)
+    u_ref = torch.einsum("ia,nabc,jb->ijnc", G, g, G).reshape(16, n, C)
+    assert float((U.float().cpu() - u_ref).abs().max()) <= 1e-3 * float(u_ref.abs().max())

@@ -77,6 +77,7 @@ def test_fixed_mask_loop_matches_fp32_restatement(hip_lib, B, IH, IW, steps):
         e = eps[:B] + guidance * (eps[B:] - eps[:B])
         x, _ = so.ddim_step_ref(e, t, x, alphas, num_inference_steps=steps)
     rel = float((out.cpu().double() - x).norm() / x.norm())
+    print(f"METRIC fixed-mask loop {steps} steps rel-L2 {rel:.3e}")
     assert rel <= 5e-2, rel
 
 
@@ -178,4 +179,4 @@ def test_ddim_fp16_flow_is_torch_half_arithmetic(hip_lib):
         assert torch.equal(x0, x0_16.float()) and torch.equal(prev, prev16.float()), t
         # and the fp32 flow is the closed form
         p64, x64 = so.ddim_step_ref(e_ref, t, x, alphas.to(dev))
-        assert float((prev.double() - p64).abs().max()) < 2e-2 and p64.dtype == torch.float64
+        assert float((prev.double() - p64).abs().max()) < 1e-2 * float(p64.abs().max()) and p64.dtype == torch.float64

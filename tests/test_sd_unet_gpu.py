@@ -2,14 +2,17 @@
 random weights (oracle/sd_oracle.py: unet_ref).  Full SD-1.5-inpainting widths (320/640/1280/1280, 8 heads, 77x768
 context); the latent is 16x16 so that the fp32 reference finishes in seconds on the host (every layer is
 resolution-agnostic; the 64x64 case is covered by properties in test_sd_pipeline_gpu.py).
-Tolerance: the graph stores every activation in fp16 through ~60 layers -> relative L2 error <= 2e-2 and
-cosine similarity >= 0.999 against the fp32 reference (an fp16 torch run of the same graph lands at ~5e-3)."""
+Tolerance: the graph stores every activation in fp16 through ~60 layers; measured (`pytest -rP` prints every METRIC line,
+profiles/r04_notes.md 3): relative L2 1.43e-3 ... 1.83e-3, cosine >= 0.999995 over every case of this file -- the bars are 2 x
+that (REL_L2 = 4e-3, 1 - COS = 2e-5), so that a kernel regression of 2-3 x fails (an fp16 torch run of the same graph lands at
+~5e-3, i.e. would fail: the fp32 accumulation everywhere is part of what is tested)."""
 import pytest
 import torch
 
 from oracle import sd_oracle as so
 
 pytestmark = pytest.mark.gpu
+REL_L2, COS = 4e-3, 0.99998
 DEV = "cuda:0"
 
 
@@ -42,7 +45,7 @@ def test_unet_matches_fp32_reference(setup, use_graph):
     out = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
     assert tuple(out.shape) == (2, 4, 16, 16)
     rel, cos = _metrics(out, ref)
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)
     out2 = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
     assert torch.equal(out, out2), "graph replay must be bitwise reproducible"
 
@@ -56,7 +59,7 @@ def test_unet_responds_to_timestep_and_context(setup):
     assert not torch.equal(a, b) and not torch.equal(a, c)
     ref_b = so.unet_ref(state, sample, torch.tensor([1.0, 1.0]), ctx, __import__("coma_amd.sd.weights", fromlist=["x"]).UNET_CFG)
     rel, cos = _metrics(b, ref_b)
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)
 
 
 @pytest.mark.parametrize("hw,batch", [(16, 4), (64, 16)])
@@ -90,7 +93,7 @@ def test_shared_cfg_prefix_is_bit_identical(setup, hw, batch):
     if hw == 16:
         from coma_amd.sd import weights
         rel, cos = _metrics(outs[2], so.unet_ref(state, sample, t, ctx, weights.UNET_CFG))
-        assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+        assert rel <= REL_L2 and cos >= COS, (rel, cos)
 
 
 def test_unet_benchmark_shape_matches_fp32_reference(setup):
@@ -115,13 +118,13 @@ def test_unet_benchmark_shape_matches_fp32_reference(setup):
     torch.cuda.empty_cache()
     ref = torch.cat([so.unet_ref(state, sample[i:i + 4], t[i:i + 4], ctx[i:i + 4], weights.UNET_CFG) for i in range(0, B, 4)])
     rel, cos = _metrics(out, ref)
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)
     rel, cos = _metrics(out_f, ref)
-    assert rel <= 2e-2 and cos >= 0.999, ("folded", rel, cos)
+    assert rel <= REL_L2 and cos >= COS, ("folded", rel, cos)
     # per-sample: no sample may hide behind the batch average (a wrong tile shows up as one bad image)
     for i in range(B):
         r, c = _metrics(out[i], ref[i])
-        assert r <= 3e-2 and c >= 0.999, (i, r, c)
+        assert r <= REL_L2 and c >= COS, (i, r, c)
 
 
 def test_layernorm_fold_equals_the_unfused_graph(setup):
@@ -139,7 +142,7 @@ def test_layernorm_fold_equals_the_unfused_graph(setup):
         assert any("ln_stats" in tag for tag, _ in unet.g.tags) == fold and any("layernorm" in tag for tag, _ in unet.g.tags) != fold
         outs.append(unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0].clone())
         rel, cos = _metrics(outs[-1], ref)
-        assert rel <= 2e-2 and cos >= 0.999, (fold, rel, cos)
+        assert rel <= REL_L2 and cos >= COS, (fold, rel, cos)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-2 * float(outs[0].abs().max())
 
 
@@ -168,7 +171,7 @@ def test_row_tile_fusions_agree_with_the_unfused_graph(setup):
     ref = so.unet_ref(state, sample, t, ctx, weights.UNET_CFG)
     for o in outs:
         rel, cos = _metrics(o, ref)
-        assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+        assert rel <= REL_L2 and cos >= COS, (rel, cos)
 
 
 def test_unet_ragged_resolution_matches_fp32_reference(setup):
@@ -187,4 +190,4 @@ def test_unet_ragged_resolution_matches_fp32_reference(setup):
     assert tuple(out.shape) == (B, 4, h, w)
     ref = so.unet_ref(state, sample, t, ctx, weights.UNET_CFG)
     rel, cos = _metrics(out, ref)
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)

@@ -1,12 +1,13 @@
 """GPU: VAE decoder / encoder launch graphs against the torch fp32 reference of the same architecture and weights
 (oracle/sd_oracle.py), full SD-1.5 widths (128/256/512/512) at a 64x64 image (8x8 latent) so the host reference is
-quick.  Tolerance: relative L2 <= 2e-2, cosine >= 0.999 (fp16 activations through ~30 layers)."""
+quick.  Tolerance: relative L2 <= 3e-3, cosine >= 0.99998 = 2 x the measured 1.22e-3 ... 1.50e-3 (fp16 activations through ~30 layers)."""
 import pytest
 import torch
 
 from oracle import sd_oracle as so
 
 pytestmark = pytest.mark.gpu
+REL_L2, COS = 3e-3, 0.99998
 DEV = "cuda:0"
 
 
@@ -31,7 +32,7 @@ def test_decoder(vae_setup):
     out = vae.decode(z.to(DEV), return_dict=False)[0]
     assert tuple(out.shape) == (2, 3, 64, 64)
     rel, cos = _metrics(out, so.vae_decode_ref(state, z, cfg))
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)
 
 
 def test_encoder_moments_and_sampling(vae_setup):
@@ -42,7 +43,7 @@ def test_encoder_moments_and_sampling(vae_setup):
     ref = so.vae_encode_ref(state, img, cfg)                       # [2, 8, 8, 8]
     mode = dist.mode()
     rel, cos = _metrics(mode, ref[:, :4])
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)
     # sampling formula on the kernel's own moments: (mean + exp(0.5*clamp(logvar)) * noise) * scale
     mom = vae.enc.moments.float().reshape(2, 64, 64)[:, :, :8]
     noise = torch.randn(2, 64, 4, generator=torch.Generator().manual_seed(2))
@@ -68,7 +69,7 @@ def test_decoder_512_matches_fp32_reference(vae512):
     out = vae.decode(z.to(DEV), return_dict=False)[0]
     assert tuple(out.shape) == (1, 3, 512, 512)
     rel, cos = _metrics(out, so.vae_decode_ref(state, z, cfg))
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)
 
 
 def test_encoder_512_matches_fp32_reference(vae512):
@@ -77,4 +78,4 @@ def test_encoder_512_matches_fp32_reference(vae512):
     mode = vae.encode(img.to(DEV)).latent_dist.mode()
     ref = so.vae_encode_ref(state, img, cfg)
     rel, cos = _metrics(mode, ref[:, :4])
-    assert rel <= 2e-2 and cos >= 0.999, (rel, cos)
+    assert rel <= REL_L2 and cos >= COS, (rel, cos)
