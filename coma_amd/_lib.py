@@ -77,6 +77,7 @@ SIGNATURES = {
     "sd_model_num_launches": (_i, [_vp, C.c_char_p]),
     "sd_model_run": (_i, [_vp, C.c_char_p, _vp]),
     "sd_model_replay": (_i, [_vp, C.c_char_p, _vp]),
+    "sd_model_prepare": (_i, [_vp, C.c_char_p]),
     "sd_model_save": (_i, [_vp, C.c_char_p]),
     "sd_model_load": (_i, [C.c_char_p, C.POINTER(_vp)]),
     "sd_copy_d2d": (_i, [_vp, _vp, C.c_size_t, _vp]),

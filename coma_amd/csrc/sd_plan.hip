@@ -118,6 +118,11 @@ static int launch(const PlanRec& r, void* st) {
     case PK_CONV_SMALL_N:
       return sd_conv3x3_small_n_f16(p[0], (const float*)p[1], (int)i[0], p[2], p[3], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], p[4],
                                     (int)i[6], st);
+    case PK_WINO_IN:
+      return sd_winograd_input_f16(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], p[2], st);
+    case PK_WINO_OUT:
+      return sd_winograd_output_f16(p[0], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], p[1], p[2], (int)i[5], p[3], (int)i[6], p[4],
+                                    (int)i[7], (int)i[8], st);
     case PK_COPY:
       return sd_copy_d2d(p[0], p[1], (size_t)i[0], st);
     default:
@@ -261,29 +266,43 @@ extern "C" int sd_model_run(void* model, const char* plan_name, void* stream) {
   return run_plan(*p, stream);
 }
 
+namespace sd {
+// capture the eager replay of a plan on a private stream (nothing executes) and instantiate it, once
+static int ensure_exec(Model* m, Plan* p, const char* who) {
+  if (p->exec) return COMA_OK;
+  if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
+    return fail(COMA_E_LAUNCH, "%s: cannot create the capture stream", who);
+  if (hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    return fail(COMA_E_LAUNCH, "%s: hipStreamBeginCapture failed", who);
+  const int rc = run_plan(*p, m->cap_stream);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+  if (rc != COMA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess || !g) return fail(COMA_E_LAUNCH, "%s: capture of plan '%s' failed: %s", who, p->name.c_str(), hipGetErrorString(e));
+  if (hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    p->exec = nullptr;
+    return fail(COMA_E_LAUNCH, "%s: hipGraphInstantiate failed for plan '%s'", who, p->name.c_str());
+  }
+  p->graph = g;
+  return COMA_OK;
+}
+}  // namespace sd
+
+extern "C" int sd_model_prepare(void* model, const char* plan_name) {
+  if (!model || !plan_name) return fail(COMA_E_INVALID, "sd_model_prepare: bad args");
+  Model* m = as_model(model);
+  Plan* p = m->find(plan_name);
+  if (!p) return fail(COMA_E_INVALID, "sd_model_prepare: no plan named '%s'", plan_name);
+  return sd::ensure_exec(m, p, "sd_model_prepare");
+}
+
 extern "C" int sd_model_replay(void* model, const char* plan_name, void* stream) {
   if (!model || !plan_name) return fail(COMA_E_INVALID, "sd_model_replay: bad args");
   Model* m = as_model(model);
   Plan* p = m->find(plan_name);
   if (!p) return fail(COMA_E_INVALID, "sd_model_replay: no plan named '%s'", plan_name);
-  if (!p->exec) {
-    // capture the eager replay on a private stream (nothing executes), instantiate once
-    if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess)
-      return fail(COMA_E_LAUNCH, "sd_model_replay: cannot create the capture stream");
-    if (hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
-      return fail(COMA_E_LAUNCH, "sd_model_replay: hipStreamBeginCapture failed");
-    const int rc = run_plan(*p, m->cap_stream);
-    hipGraph_t g = nullptr;
-    const hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
-    if (rc != COMA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (e != hipSuccess || !g) return fail(COMA_E_LAUNCH, "sd_model_replay: capture of plan '%s' failed: %s", plan_name, hipGetErrorString(e));
-    if (hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0) != hipSuccess) {
-      (void)hipGraphDestroy(g);
-      p->exec = nullptr;
-      return fail(COMA_E_LAUNCH, "sd_model_replay: hipGraphInstantiate failed for plan '%s'", plan_name);
-    }
-    p->graph = g;
-  }
+  if (int rc = sd::ensure_exec(m, p, "sd_model_replay")) return rc;
   if (hipGraphLaunch(p->exec, (hipStream_t)stream) != hipSuccess) return fail(COMA_E_LAUNCH, "sd_model_replay: hipGraphLaunch failed");
   return COMA_OK;
 }

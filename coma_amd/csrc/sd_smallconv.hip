@@ -45,38 +45,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_n_kernel(const _Float16*
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
 
+  // Staging is split in two so that no thread ever waits on one load at a time: `fetch` issues ALL of a chunk's global loads of this
+  // thread into registers (11 independent 16-byte loads), `commit` activates them and writes LDS.  The second chunk is fetched before
+  // the first chunk's MFMAs, so its HBM latency runs under them.
+  constexpr int kVec = kHalo * kHalo * 8, kPer = (kVec + 255) / 256;      // 2592 vectors, 11 per thread
+  half8 q[kPer];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int idx = tid + it * 256;
+      const int p = idx >> 3, v = idx & 7;
+      const int r = p / kHalo, c = p - r * kHalo;
+      const int y = ty0 + r - 1, xx = tx0 + c - 1;
+      half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (idx < kVec && y >= 0 && y < H && xx >= 0 && xx < W)
+        z = *reinterpret_cast<const half8*>(x + (((size_t)b * H + y) * W + xx) * C + chunk * kChunk + v * 8);
+      q[it] = z;
+    }
+  };
+  auto commit = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int idx = tid + it * 256;
+      if (idx >= kVec) break;
+      const int p = idx >> 3, v = idx & 7;
+      const int r = p / kHalo, c = p - r * kHalo;
+      const int y = ty0 + r - 1, xx = tx0 + c - 1;
+      half8 z = q[it];
+      if (affine && y >= 0 && y < H && xx >= 0 && xx < W) {       // zero padding applies to the ACTIVATED tensor: pad pixels stay 0
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float2 a = aff[chunk * kChunk + v * 8 + e];
+          float f = fmaf((float)z[e], a.x, a.y);
+          if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
+          z[e] = (_Float16)f;
+        }
+      }
+      tile[slot(p, v)] = z;
+    }
+  };
+
+  fetch(0);
+  __syncthreads();                                         // `aff` is visible
 #pragma unroll
   for (int chunk = 0; chunk < C / kChunk; ++chunk) {
+    commit(chunk);
     // this chunk's weights -> registers (18 MFMA operands): operand row = output channel (zero rows above n_out), K octet = lane >> 4
     half8 wf[9][kChunk / 32];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int kh = 0; kh < kChunk / 32; ++kh) {
-        half8 q = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (lp < n_out) q = *reinterpret_cast<const half8*>(w + ((size_t)lp * 9 + tap) * C + chunk * kChunk + kh * 32 + lo * 8);
-        wf[tap][kh] = q;
+        half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (lp < n_out) z = *reinterpret_cast<const half8*>(w + ((size_t)lp * 9 + tap) * C + chunk * kChunk + kh * 32 + lo * 8);
+        wf[tap][kh] = z;
       }
-    __syncthreads();                                       // the previous chunk's operand reads are done; `aff` is visible
-    for (int idx = tid; idx < kHalo * kHalo * 8; idx += 256) {
-      const int p = idx >> 3, v = idx & 7;
-      const int r = p / kHalo, c = p - r * kHalo;
-      const int y = ty0 + r - 1, xx = tx0 + c - 1;
-      half8 q = {0, 0, 0, 0, 0, 0, 0, 0};                  // zero padding applies to the ACTIVATED tensor
-      if (y >= 0 && y < H && xx >= 0 && xx < W) {
-        q = *reinterpret_cast<const half8*>(x + (((size_t)b * H + y) * W + xx) * C + chunk * kChunk + v * 8);
-        if (affine) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float2 a = aff[chunk * kChunk + v * 8 + e];
-            float f = fmaf((float)q[e], a.x, a.y);
-            if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
-            q[e] = (_Float16)f;
-          }
-        }
-      }
-      tile[slot(p, v)] = q;
-    }
+    if (chunk + 1 < C / kChunk) fetch(chunk + 1);          // in flight under this chunk's MFMAs
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -91,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_n_kernel(const _Float16*
         }
       }
     }
+    __syncthreads();                                       // every wave is done reading the tile before the next commit overwrites it
   }
   // D[n][pixel]: lane = pixel + 16 * (n / 4), register = n % 4 -> lanes 0..15 hold the n_out <= 4 real channels of their pixel
   if (lane < 16) {

@@ -168,6 +168,12 @@ extern "C" {
 
 int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, void* v, void* stream) {
   using namespace sd;
+  if (plan_recording()) {
+    PlanRec r{};
+    r.kind = PK_WINO_IN;
+    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = v; r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = h; r.i[4] = w;
+    return plan_record(r);
+  }
   if (!x0 || !v) return fail(COMA_E_INVALID, "sd_winograd_input_f16: null pointer");
   if (c0 <= 0 || c0 % 8 || c1 < 0 || c1 % 8 || (c1 > 0 && !x1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: channel counts must be multiples of 8");
   if (batch <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: even h, w required");
@@ -189,6 +195,13 @@ int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream) {
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
                            const void* res, int ldr, void* out, int ldo, int silu, void* stream) {
   using namespace sd;
+  if (plan_recording()) {
+    PlanRec r{};
+    r.kind = PK_WINO_OUT;
+    r.p[0] = (void*)m; r.p[1] = (void*)bias; r.p[2] = (void*)bias_bn; r.p[3] = (void*)res; r.p[4] = out;
+    r.i[0] = ldm; r.i[1] = batch; r.i[2] = h; r.i[3] = w; r.i[4] = n; r.i[5] = ldbb; r.i[6] = ldr; r.i[7] = ldo; r.i[8] = silu;
+    return plan_record(r);
+  }
   if (!m || !out) return fail(COMA_E_INVALID, "sd_winograd_output_f16: null pointer");
   if (n <= 0 || n % 8 || ldm % 8 || batch <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_winograd_output_f16: bad shape");
   if (ldo == 0) ldo = n;

@@ -80,6 +80,22 @@ class LaunchGraph:
                  tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}")
         return out
 
+    def conv3x3_winograd(self, a0, w9, out, *, batch, in_h, in_w, c0, n, a1=None, c1=0, bias=None, bias_bn=None, ldbb=0, res=None):
+        """A 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3): input transform -> 16 plane products (the 1x1 GEMM path,
+        nbatch_z = 16) -> output transform with the epilogue (bias, per-sample bias, residual).  2.25 x fewer MFMA flops; only worth it
+        where the 4 x larger transformed tensors stay in the Infinity Cache and K = C_in is long -- the 16 x 16 / 8 x 8 levels of the UNet
+        (profiles/r04_notes.md 1).  w9: fp16 [n][9 * (c0 + c1)] (the direct kernel's layout); its transform is computed once, here."""
+        C, T = c0 + c1, batch * (in_h // 2) * (in_w // 2)
+        U = torch.empty(16, n, C, dtype=torch.float16, device=self.device)        # constants: registered PERSISTENT when first recorded
+        ops.winograd_weight(w9, U, n=n, c=C)
+        V, P = self.buf(16, T, C), self.buf(16, T, n)
+        self.add(lambda: ops.winograd_input(a0, V, batch=batch, h=in_h, w=in_w, c0=c0, x1=a1, c1=c1),
+                 tag=f"winograd input B={batch} {in_h}x{in_w} C={C}", nbytes=2 * 5 * batch * in_h * in_w * C)
+        self.conv(V, U, P, batch=T, in_h=1, in_w=1, c0=C, n=n, nbatch_z=16, stride_a=T * C, stride_w=n * C, stride_out=T * n)
+        self.add(lambda: ops.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res),
+                 tag=f"winograd output B={batch} {in_h}x{in_w} N={n}", nbytes=2 * (5 + (1 if res is not None else 0)) * batch * in_h * in_w * n)
+        return out
+
     def dup(self, src, dst):
         """dst = [src | src] along the batch axis (two identical CFG halves); the GroupNorm column sums of src follow."""
         assert dst.numel() == 2 * src.numel()
@@ -245,5 +261,6 @@ class LaunchGraph:
             return self._tg.replay()
         if not self._recorded:
             self.capture()            # recorded, then run eagerly once: that run IS this call's execution (no second pass over the step)
+            self.model.prepare(self.plan)      # the hipGraph is captured and instantiated now (nothing executes), so the next call only launches
             return
         self.model.replay(self.plan)

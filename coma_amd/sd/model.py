@@ -88,6 +88,11 @@ class SdModel:
     def run(self, plan):
         _lib.check(_lib.lib().sd_model_run(self.h, plan.encode(), _lib.stream_ptr(self.device)), "sd_model_run")
 
+    def prepare(self, plan):
+        """Capture + instantiate the plan's hipGraph now (nothing executes)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().sd_model_prepare(self.h, plan.encode()), "sd_model_prepare")
+
     def replay(self, plan):
         _lib.check(_lib.lib().sd_model_replay(self.h, plan.encode(), _lib.stream_ptr(self.device)), "sd_model_replay")
 

@@ -19,6 +19,8 @@ concatenation -> GroupNorm/SiLU -> conv_out.  Fusions done here, none of which c
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -28,6 +30,9 @@ from .weights import UNET_CFG, conv_weight, geglu_interleave, ln_fold, pad_vec
 
 class _Cfg(dict):
     __getattr__ = dict.__getitem__
+
+
+WINOGRAD_MAX_H = 0          # default rule, set from the A/B inside the captured forward (profiles/r04_notes.md)
 
 
 class HipUNet2DConditionModel:
@@ -50,6 +55,8 @@ class HipUNet2DConditionModel:
         self.fuse_qkv = fuse_qkv            # C = 640 / 1280 blocks: to_q | to_k | to_v one GEMM, V^T written transposed by its epilogue (sd_conv_gemm_desc.out_t)
         self.fuse_xtail = fuse_xtail        # C = 320 blocks: ff (GEGLU, Linear) + residual, proj_out + residual in one launch (sd_xtail_f16)
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
+        # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
+        self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
         self.dtype = F16
@@ -147,8 +154,13 @@ class HipUNet2DConditionModel:
                     silu=True)
         h = g.buf(M, cout)
         off = self._tb_off[p]
-        g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
-               bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
+        wino = self.winograd_max_h and H <= self.winograd_max_h and H % 2 == 0 and W % 2 == 0
+        if wino:       # deep levels only: 2.25 x fewer MFMA flops where the transformed tensors stay in cache (profiles/r04_notes.md 1)
+            g.conv3x3_winograd(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout,
+                               bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld)
+        else:
+            g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
+                   bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
         n2 = g.buf(M, cout)
         g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
         if p + ".conv_shortcut.weight" in s:
@@ -159,8 +171,12 @@ class HipUNet2DConditionModel:
             assert x1 is None and c0 == cout
             sc = x0
         out = g.buf(M, cout)
-        g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
-               bias=s[p + ".conv2.bias"], res=sc, stats=True)
+        if wino:
+            g.conv3x3_winograd(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout,
+                               bias=s[p + ".conv2.bias"], res=sc)
+        else:
+            g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
+                   bias=s[p + ".conv2.bias"], res=sc, stats=True)
         return out
 
     def _transformer(self, p, x, C, H, W):

@@ -192,7 +192,7 @@ int sd_xattn_chain_f16(const void* attn1_out, const void* h, const void* wo1, co
  *   sd_winograd_input_f16   v fp16 [16][T][c0+c1] = B^T d B of every 4x4 input patch (two concatenated NHWC sources, zero pad)
  *   sd_winograd_weight_f16  u fp16 [16][n][c] = G g G^T of w fp16 [n][9][c] (computed in fp32, rounded once; at prep time)
  *   sd_winograd_output_f16  out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] + bias + per-sample bias, SiLU, + residual
- * h, w even; channel counts multiples of 8.  Measurement probe (profiles/r04_notes.md 1): not part of any network plan, not recordable.
+ * h, w even; channel counts multiples of 8.  sd_winograd_input_f16 / _output_f16 are recordable (sd_winograd_weight_f16 runs at prep time).
  * replaces: diffusers Conv2d(3x3) inside self.unet(...) / self.vae.decode, utils/adaptive_mask_inpainting.py:1001-1007, :1086, :1112. */
 int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, void* v, void* stream);
 int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream);
@@ -290,6 +290,7 @@ int sd_model_record_end(void* model);
 int sd_model_num_launches(const void* model, const char* plan_name);                  /* -1: no such plan */
 int sd_model_run(void* model, const char* plan_name, void* stream);
 int sd_model_replay(void* model, const char* plan_name, void* stream);
+int sd_model_prepare(void* model, const char* plan_name);   /* capture + instantiate the plan's hipGraph now (nothing executes); sd_model_replay does it on first use otherwise */
 int sd_model_save(const void* model, const char* path);
 int sd_model_load(const char* path, void** model);
 /* dst[0:bytes) = src[0:bytes), device to device, on `stream` (recordable: the duplicated CFG halves of the UNet). */
