@@ -1024,7 +1024,13 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   // inside the captured graph)
   const bool deep = g.K >= 1024 && k64;
   // 256 x 320 tile: N a multiple of 320 (every layer of the SD UNet), enough rows to fill the chip with 1 block / CU
-  const bool big = !geglu && nz == 1 && k64 && g.N % 320 == 0 && (long long)((g.M + 255) / 256) * (g.N / 320) >= 192 && !(d->epi & ((1 << 20) | (1 << 21)));
+  // ... or z-batched plain products whose tiles fill it together (the 16 plane products of a Winograd convolution at the 16 x 16 level:
+  // 4 x 4 tiles x 16 planes = one block per CU, where the generic 128 x 128 tile needs 2.5 rounds; SD_GEMM_ZBIG=0 switches it off for A/B)
+  static const bool zbig_on = !getenv("SD_GEMM_ZBIG") || atoi(getenv("SD_GEMM_ZBIG")) != 0;
+  const bool zplain = nz > 1 && zbig_on && d->taps == 1 && !d->colstats && !d->rowstats && !d->ln_stats && !d->out_t &&
+                      !(d->epi & ~SD_EPI_TUNING_MASK);
+  const bool big = !geglu && (nz == 1 || zplain) && k64 && g.N % 320 == 0 && (long long)((g.M + 255) / 256) * (g.N / 320) * nz >= 192 &&
+                   !(d->epi & ((1 << 20) | (1 << 21)));
   // GEGLU (needs an even number of MFMA column tiles per wave): 256 x 256, 8 waves, wave tile 64 x 128
   const bool big_geglu = geglu && nz == 1 && k64 && g.N % 256 == 0 && g.M >= 256 * 16 && !(d->epi & (1 << 20));
   // VAE widths (128 / 256 / 512 channels at up to 512 x 512 pixels): 256 x 256 and 256 x 128 tiles, 8 waves

@@ -32,7 +32,8 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-WINOGRAD_MAX_H = 0          # default rule, set from the A/B inside the captured forward (profiles/r04_notes.md)
+WINOGRAD_MAX_H = 16         # ResNet 3x3 convolutions of feature maps up to 16 x 16 with >= 640 channels run as Winograd F(2x2,3x3): -0.6 ms per
+                            # batch-16 forward measured inside the captured graph (A B A B, profiles/r04_notes.md 4); the 32 x 32 level adds nothing
 
 
 class HipUNet2DConditionModel:
@@ -154,7 +155,7 @@ class HipUNet2DConditionModel:
                     silu=True)
         h = g.buf(M, cout)
         off = self._tb_off[p]
-        wino = self.winograd_max_h and H <= self.winograd_max_h and H % 2 == 0 and W % 2 == 0
+        wino = self.winograd_max_h and max(H, W) <= self.winograd_max_h and H % 2 == 0 and W % 2 == 0 and min(cin, cout) >= 640
         if wino:       # deep levels only: 2.25 x fewer MFMA flops where the transformed tensors stay in cache (profiles/r04_notes.md 1)
             g.conv3x3_winograd(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout,
                                bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld)
