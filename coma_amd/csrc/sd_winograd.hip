@@ -162,6 +162,159 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const _Float16* __
     }
 }
 
+
+// ---- GroupNorm (+ SiLU) of a SMALL feature map fused with the Winograd input transform: one block per (sample, group), the group's
+// hw x (C / groups) slice held in LDS.  The slice comes either from NHWC tensors (mode 0: norm1 of a ResNet block, two concatenated
+// sources) or straight from the 16 plane products of the PREVIOUS Winograd convolution (mode 1: conv1 -> norm2 -> conv2 of a ResNet
+// block; h = A^T m A + bias + per-sample bias is formed here, rounded to fp16 as the stored tensor would be, and never written).
+// Three launches of the unfused chain (output transform, GroupNorm, input transform) become one; the arithmetic of every stage is the
+// unfused kernels' (same statistics formula, same affine + SiLU expression, transforms in fp32 rounded once).
+constexpr int kGnWinoMaxSlice = 20480;          // halfs: 16 x 16 pixels x 80 channels (C = 2560, 32 groups)
+typedef _Float16 half4w __attribute__((ext_vector_type(4)));
+
+struct GnWinoArgs {
+  const _Float16 *x0, *x1;
+  int c0, c1;
+  const _Float16* m;          // != nullptr: mode 1, fp16 [16][batch * T][ldm]
+  int ldm;
+  const _Float16 *bias, *bias_bn;
+  int ldbb;
+  int h, w, groups;
+  float eps;
+  const _Float16 *gamma, *beta;
+  int silu;
+  _Float16* v;                // fp16 [16][batch * T][C]
+};
+
+__device__ __forceinline__ float wave_sum64(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+__global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
+  __shared__ _Float16 slice[kGnWinoMaxSlice];
+  __shared__ float rs[4], rq[4];
+  const int C = a.c0 + a.c1, cg = C / a.groups, q4 = cg >> 2;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int hw = a.h * a.w, th = a.h >> 1, tw = a.w >> 1, T = th * tw;
+  const long long ntile = (long long)gridDim.y * T;
+  float s = 0.0f, q = 0.0f;
+  if (!a.m) {
+    for (int it = tid; it < hw * q4; it += 256) {
+      const int p = it / q4, cc = (it - p * q4) * 4, c = g * cg + cc;
+      const long long pix = (long long)b * hw + p;
+      const half4w v4 = *reinterpret_cast<const half4w*>(c < a.c0 ? a.x0 + pix * a.c0 + c : a.x1 + pix * a.c1 + (c - a.c0));
+      *reinterpret_cast<half4w*>(slice + p * cg + cc) = v4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float f = (float)v4[j]; s += f; q += f * f; }
+    }
+  } else {
+    for (int it = tid; it < T * q4; it += 256) {
+      const int t = it / q4, cc = (it - t * q4) * 4, c = g * cg + cc;
+      const int ty = t / tw, tx = t - ty * tw;
+      const long long tg = (long long)b * T + t;
+      float sm[2][4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float mm[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const half4w v4 = *reinterpret_cast<const half4w*>(a.m + ((long long)(4 * i + j) * ntile + tg) * a.ldm + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mm[i][e] = (float)v4[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sm[0][j][e] = mm[0][e] + mm[1][e] + mm[2][e];
+          sm[1][j][e] = mm[1][e] - mm[2][e] - mm[3][e];
+        }
+      }
+      float add[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) { const half4w v4 = *reinterpret_cast<const half4w*>(a.bias + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) add[e] += (float)v4[e]; }
+      if (a.bias_bn) { const half4w v4 = *reinterpret_cast<const half4w*>(a.bias_bn + (long long)b * a.ldbb + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) add[e] += (float)v4[e]; }
+#pragma unroll
+      for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+        for (int xb = 0; xb < 2; ++xb) {
+          half4w o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = (xb == 0 ? sm[ya][0][e] + sm[ya][1][e] + sm[ya][2][e] : sm[ya][1][e] - sm[ya][2][e] - sm[ya][3][e]) + add[e];
+            o[e] = (_Float16)y;
+            const float f = (float)o[e];            // the statistics see the fp16 tensor the unfused chain would have stored
+            s += f; q += f * f;
+          }
+          *reinterpret_cast<half4w*>(slice + ((2 * ty + ya) * a.w + 2 * tx + xb) * cg + cc) = o;
+        }
+    }
+  }
+  s = wave_sum64(s);
+  q = wave_sum64(q);
+  if ((tid & 63) == 0) { rs[tid >> 6] = s; rq[tid >> 6] = q; }
+  __syncthreads();
+  s = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+  q = (rq[0] + rq[1]) + (rq[2] + rq[3]);
+  const float count = (float)hw * (float)cg;
+  const float mean = s / count;
+  const float var = fmaxf(q / count - mean * mean, 0.0f);
+  const float rstd = rsqrtf(var + a.eps);
+  for (int it = tid; it < hw * q4; it += 256) {
+    const int p = it / q4, cc = (it - p * q4) * 4, c = g * cg + cc;
+    const half4w ga = *reinterpret_cast<const half4w*>(a.gamma + c), be = *reinterpret_cast<const half4w*>(a.beta + c);
+    half4w v4 = *reinterpret_cast<half4w*>(slice + p * cg + cc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sc = rstd * (float)ga[j];
+      float y = fmaf((float)v4[j], sc, (float)be[j] - mean * sc);
+      if (a.silu) y = y / (1.0f + __expf(-y));
+      v4[j] = (_Float16)y;
+    }
+    *reinterpret_cast<half4w*>(slice + p * cg + cc) = v4;
+  }
+  __syncthreads();
+  for (int it = tid; it < T * q4; it += 256) {
+    const int t = it / q4, cc = (it - t * q4) * 4, c = g * cg + cc;
+    const int ty = t / tw, tx = t - ty * tw;
+    float d[4][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = 2 * ty - 1 + i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = 2 * tx - 1 + j;
+        half4w v4 = {0, 0, 0, 0};
+        if (y >= 0 && y < a.h && x >= 0 && x < a.w) v4 = *reinterpret_cast<const half4w*>(slice + (y * a.w + x) * cg + cc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[i][j][e] = (float)v4[e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = d[0][j][e], d1 = d[1][j][e], d2 = d[2][j][e], d3 = d[3][j][e];
+        d[0][j][e] = d0 - d2; d[1][j][e] = d1 + d2; d[2][j][e] = d2 - d1; d[3][j][e] = d1 - d3;
+      }
+    const long long tg = (long long)b * T + t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      half4w o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t0 = d[i][0][e], t1 = d[i][1][e], t2 = d[i][2][e], t3 = d[i][3][e];
+        o[0][e] = (_Float16)(t0 - t2); o[1][e] = (_Float16)(t1 + t2); o[2][e] = (_Float16)(t2 - t1); o[3][e] = (_Float16)(t1 - t3);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<half4w*>(a.v + ((long long)(4 * i + j) * ntile + tg) * C + c) = o[j];
+    }
+  }
+}
+
 }  // namespace sd
 
 extern "C" {
@@ -212,6 +365,35 @@ int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int 
                      (const _Float16*)m, ldm, batch, h, w, n, (const _Float16*)bias, (const _Float16*)bias_bn, ldbb, (const _Float16*)res,
                      ldr, (_Float16*)out, ldo, silu);
   return check_launch("sd_winograd_output_f16");
+}
+
+int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, const void* m, int ldm, const void* bias, const void* bias_bn,
+                             int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, void* v,
+                             void* stream) {
+  using namespace sd;
+  if (plan_recording()) {
+    PlanRec r{};
+    r.kind = PK_GN_WINO_IN;
+    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = (void*)m; r.p[3] = (void*)bias; r.p[4] = (void*)bias_bn; r.p[5] = (void*)gamma;
+    r.p[6] = (void*)beta; r.p[7] = v;
+    r.i[0] = c0; r.i[1] = c1; r.i[2] = ldm; r.i[3] = ldbb; r.i[4] = batch; r.i[5] = h; r.i[6] = w; r.i[7] = groups; r.i[8] = silu; r.f[0] = eps;
+    return plan_record(r);
+  }
+  if ((!x0 && !m) || !gamma || !beta || !v) return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: null pointer");
+  if (m && (x0 || x1 || c1)) return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: either NHWC sources or plane products, not both");
+  const int C = c0 + c1;
+  if (c0 <= 0 || c0 % 4 || c1 < 0 || c1 % 4 || (c1 > 0 && !x1) || groups <= 0 || C % groups || (C / groups) % 4)
+    return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: channels per group must be a multiple of 4 (c0=%d c1=%d groups=%d)", c0, c1, groups);
+  if (batch <= 0 || batch > 65535 || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: even h, w required");
+  if ((long long)h * w * (C / groups) > kGnWinoMaxSlice)
+    return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: a group's slice (%d x %d pixels x %d channels) exceeds %d elements", h, w, C / groups, kGnWinoMaxSlice);
+  if (m && (ldm % 4 || ldm < C)) return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: ldm = %d", ldm);
+  GnWinoArgs a;
+  a.x0 = (const _Float16*)x0; a.x1 = (const _Float16*)x1; a.c0 = c0; a.c1 = c1; a.m = (const _Float16*)m; a.ldm = ldm;
+  a.bias = (const _Float16*)bias; a.bias_bn = (const _Float16*)bias_bn; a.ldbb = ldbb > 0 ? ldbb : C; a.h = h; a.w = w; a.groups = groups;
+  a.eps = eps; a.gamma = (const _Float16*)gamma; a.beta = (const _Float16*)beta; a.silu = silu; a.v = (_Float16*)v;
+  hipLaunchKernelGGL(gn_winograd_input_kernel, dim3((unsigned)groups, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("sd_gn_winograd_input_f16");
 }
 
 }  // extern "C"

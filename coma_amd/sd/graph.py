@@ -80,21 +80,53 @@ class LaunchGraph:
                  tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}")
         return out
 
-    def conv3x3_winograd(self, a0, w9, out, *, batch, in_h, in_w, c0, n, a1=None, c1=0, bias=None, bias_bn=None, ldbb=0, res=None):
-        """A 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3): input transform -> 16 plane products (the 1x1 GEMM path,
-        nbatch_z = 16) -> output transform with the epilogue (bias, per-sample bias, residual).  2.25 x fewer MFMA flops; only worth it
-        where the 4 x larger transformed tensors stay in the Infinity Cache and K = C_in is long -- the 16 x 16 / 8 x 8 levels of the UNet
-        (profiles/r04_notes.md 1).  w9: fp16 [n][9 * (c0 + c1)] (the direct kernel's layout); its transform is computed once, here."""
-        C, T = c0 + c1, batch * (in_h // 2) * (in_w // 2)
-        U = torch.empty(16, n, C, dtype=torch.float16, device=self.device)        # constants: registered PERSISTENT when first recorded
-        ops.winograd_weight(w9, U, n=n, c=C)
-        V, P = self.buf(16, T, C), self.buf(16, T, n)
-        self.add(lambda: ops.winograd_input(a0, V, batch=batch, h=in_h, w=in_w, c0=c0, x1=a1, c1=c1),
-                 tag=f"winograd input B={batch} {in_h}x{in_w} C={C}", nbytes=2 * 5 * batch * in_h * in_w * C)
-        self.conv(V, U, P, batch=T, in_h=1, in_w=1, c0=C, n=n, nbatch_z=16, stride_a=T * C, stride_w=n * C, stride_out=T * n)
-        self.add(lambda: ops.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res),
-                 tag=f"winograd output B={batch} {in_h}x{in_w} N={n}", nbytes=2 * (5 + (1 if res is not None else 0)) * batch * in_h * in_w * n)
+    # ---- Winograd F(2x2,3x3) for the deep ResNet levels (profiles/r04_notes.md 1, 4): input transform -> 16 plane products (the 1x1 GEMM
+    # path, nbatch_z = 16) -> output transform with the epilogue.  2.25 x fewer MFMA flops; only worth it where the 4 x larger transformed
+    # tensors stay in the Infinity Cache and K = C_in is long -- the 16 x 16 / 8 x 8 levels of the UNet.
+    def winograd_weight(self, w9, *, n, c):
+        """w9 fp16 [n][9 * c] (the direct kernel's layout) -> U fp16 [16][n][c] = G g G^T, computed once, here."""
+        U = torch.empty(16, n, c, dtype=torch.float16, device=self.device)        # constants: registered PERSISTENT when first recorded
+        ops.winograd_weight(w9, U, n=n, c=c)
+        return U
+
+    def winograd_planes(self, V, U, *, tiles, c, n):
+        P = self.buf(16, tiles, n)
+        self.conv(V, U, P, batch=tiles, in_h=1, in_w=1, c0=c, n=n, nbatch_z=16, stride_a=tiles * c, stride_w=n * c, stride_out=tiles * n)
+        return P
+
+    def winograd_input(self, a0, *, batch, h, w, c0, a1=None, c1=0):
+        C, T = c0 + c1, batch * (h // 2) * (w // 2)
+        V = self.buf(16, T, C)
+        self.add(lambda: ops.winograd_input(a0, V, batch=batch, h=h, w=w, c0=c0, x1=a1, c1=c1),
+                 tag=f"winograd input B={batch} {h}x{w} C={C}", nbytes=2 * 5 * batch * h * w * C)
+        return V
+
+    GN_WINO_MAX_SLICE = 20480
+
+    def gn_winograd_input(self, gamma, beta, *, batch, h, w, c0, x0=None, x1=None, c1=0, m=None, bias=None, bias_bn=None, ldbb=0, eps, silu=True,
+                          groups=32):
+        """GroupNorm (+ SiLU) -> Winograd input transform in ONE launch (sd_gn_winograd_input_f16); the source is [x0 | x1] or the plane
+        products `m` of the previous Winograd convolution (its output transform, bias and per-sample bias happen here)."""
+        C, T = c0 + c1, batch * (h // 2) * (w // 2)
+        assert h * w * (C // groups) <= self.GN_WINO_MAX_SLICE
+        V = self.buf(16, T, C)
+        self.add(lambda: ops.gn_winograd_input(V, gamma, beta, batch=batch, h=h, w=w, c0=c0, x0=x0, x1=x1, c1=c1, m=m, ldm=c0, bias=bias,
+                                               bias_bn=bias_bn, ldbb=ldbb, groups=groups, eps=eps, silu=silu),
+                 tag=f"groupnorm + winograd input{' (from planes)' if m is not None else ''} B={batch} {h}x{w} C={C}",
+                 nbytes=2 * (5 + (16 if m is not None else 1)) * batch * h * w * C // (4 if m is not None else 1))
+        return V
+
+    def winograd_output(self, P, out, *, batch, h, w, n, bias=None, bias_bn=None, ldbb=0, res=None):
+        self.add(lambda: ops.winograd_output(P, out, batch=batch, h=h, w=w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res),
+                 tag=f"winograd output B={batch} {h}x{w} N={n}", nbytes=2 * (5 + (1 if res is not None else 0)) * batch * h * w * n)
         return out
+
+    def conv3x3_winograd(self, a0, w9, out, *, batch, in_h, in_w, c0, n, a1=None, c1=0, bias=None, bias_bn=None, ldbb=0, res=None):
+        """The unfused chain: input transform -> plane products -> output transform (+ bias, per-sample bias, residual)."""
+        C, T = c0 + c1, batch * (in_h // 2) * (in_w // 2)
+        V = self.winograd_input(a0, batch=batch, h=in_h, w=in_w, c0=c0, a1=a1, c1=c1)
+        P = self.winograd_planes(V, self.winograd_weight(w9, n=n, c=C), tiles=T, c=C, n=n)
+        return self.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res)
 
     def dup(self, src, dst):
         """dst = [src | src] along the batch axis (two identical CFG halves); the GroupNorm column sums of src follow."""

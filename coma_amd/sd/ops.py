@@ -278,3 +278,12 @@ def conv3x3_small_n(x, w, out, *, batch, h, w_, c, n, bias=None, gn_affine=None,
                                            batch, h, w_, c, n, _p(out, "out"), ldo, _stream(out))
     _lib.check(rc, "sd_conv3x3_small_n_f16")
     return out
+
+
+def gn_winograd_input(v, gamma, beta, *, batch, h, w, c0, x0=None, x1=None, c1=0, m=None, ldm=0, bias=None, bias_bn=None, ldbb=0, groups=32,
+                      eps=1e-5, silu=True):
+    """v = B^T act(GroupNorm(source)) B, source = [x0 | x1] or the output transform of the plane products m (+ bias, per-sample bias)."""
+    rc = _lib.lib().sd_gn_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, _p(m, "m"), ldm or c0, _p(bias, "bias"), _p(bias_bn, "bias_bn"),
+                                             ldbb, batch, h, w, groups, eps, _p(gamma), _p(beta), 1 if silu else 0, _p(v, "v"), _stream(v))
+    _lib.check(rc, "sd_gn_winograd_input_f16")
+    return v

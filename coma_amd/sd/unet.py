@@ -58,6 +58,7 @@ class HipUNet2DConditionModel:
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
+        self.fuse_gn_winograd = os.environ.get("SD_GN_WINOGRAD", "1") != "0"     # GroupNorms folded into the Winograd transforms (A/B: 0)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
         self.dtype = F16
@@ -150,20 +151,31 @@ class HipUNet2DConditionModel:
     def _resnet(self, p, x0, c0, x1, c1, cout, H, W):
         g, s, B = self.g, self.s, self._B
         M, cin = B * H * W, c0 + c1
-        n1 = g.buf(M, cin)
-        g.groupnorm(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=c0, x1=x1, c1=c1, eps=1e-5,
-                    silu=True)
-        h = g.buf(M, cout)
         off = self._tb_off[p]
         wino = self.winograd_max_h and max(H, W) <= self.winograd_max_h and H % 2 == 0 and W % 2 == 0 and min(cin, cout) >= 640
-        if wino:       # deep levels only: 2.25 x fewer MFMA flops where the transformed tensors stay in cache (profiles/r04_notes.md 1)
-            g.conv3x3_winograd(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout,
-                               bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld)
+        # deep levels: Winograd F(2x2,3x3), 2.25 x fewer MFMA flops where the transformed tensors stay in cache (profiles/r04_notes.md 1, 4);
+        # with the GroupNorms folded into the transforms a block is five launches: [norm1 + B^T d B] -> planes -> [A^T m A + bias + temb,
+        # norm2, B^T d B] -> planes -> [A^T m A + bias + shortcut]
+        fused_gn = wino and self.fuse_gn_winograd and H * W * (max(cin, cout) // 32) <= g.GN_WINO_MAX_SLICE and cin % 128 == 0 and cout % 128 == 0
+        T = B * (H // 2) * (W // 2)
+        if fused_gn:
+            V1 = g.gn_winograd_input(s[p + ".norm1.weight"], s[p + ".norm1.bias"], batch=B, h=H, w=W, c0=c0, x0=x0, x1=x1, c1=c1, eps=1e-5)
+            P1 = g.winograd_planes(V1, g.winograd_weight(conv_weight(s[p + ".conv1.weight"]), n=cout, c=cin), tiles=T, c=cin, n=cout)
+            V2 = g.gn_winograd_input(s[p + ".norm2.weight"], s[p + ".norm2.bias"], batch=B, h=H, w=W, c0=cout, m=P1, bias=s[p + ".conv1.bias"],
+                                     bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, eps=1e-5)
         else:
-            g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
-                   bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
-        n2 = g.buf(M, cout)
-        g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
+            n1 = g.buf(M, cin)
+            g.groupnorm(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=c0, x1=x1, c1=c1, eps=1e-5,
+                        silu=True)
+            h = g.buf(M, cout)
+            if wino:
+                g.conv3x3_winograd(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout,
+                                   bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld)
+            else:
+                g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
+                       bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
+            n2 = g.buf(M, cout)
+            g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
         if p + ".conv_shortcut.weight" in s:
             sc = g.buf(M, cout)
             g.conv(x0, conv_weight(s[p + ".conv_shortcut.weight"]), sc, batch=B, in_h=H, in_w=W, c0=c0, n=cout, a1=x1, c1=c1,
@@ -172,7 +184,10 @@ class HipUNet2DConditionModel:
             assert x1 is None and c0 == cout
             sc = x0
         out = g.buf(M, cout)
-        if wino:
+        if fused_gn:
+            P2 = g.winograd_planes(V2, g.winograd_weight(conv_weight(s[p + ".conv2.weight"]), n=cout, c=cout), tiles=T, c=cout, n=cout)
+            g.winograd_output(P2, out, batch=B, h=H, w=W, n=cout, bias=s[p + ".conv2.bias"], res=sc)
+        elif wino:
             g.conv3x3_winograd(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout,
                                bias=s[p + ".conv2.bias"], res=sc)
         else:

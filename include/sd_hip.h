@@ -198,6 +198,17 @@ int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int ba
 int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream);
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
                            const void* res, int ldr, void* out, int ldo, int silu, void* stream);
+/* GroupNorm (+ SiLU) of a SMALL feature map fused with the Winograd input transform, one workgroup per (sample, group), the group's
+ * slice in LDS (h * w * C / groups <= 20480 elements: the 16 x 16 / 8 x 8 levels of the UNet):
+ *   source = the channel concatenation [x0 | x1] (NHWC fp16; m == NULL), or
+ *   source = A^T m A + bias + per-sample bias of the 16 plane products m fp16 [16][batch*h/2*w/2][ldm] of the PREVIOUS Winograd
+ *            convolution (x0 == x1 == NULL, c0 = its output channels, c1 = 0), rounded to fp16 and never written;
+ *   v fp16 [16][batch*h/2*w/2][c0+c1] = B^T act(GroupNorm(source)) B.
+ * Replaces sd_winograd_output_f16 -> sd_groupnorm_f16 -> sd_winograd_input_f16 (conv1 -> norm2 -> SiLU -> conv2 of a ResnetBlock2D)
+ * or sd_groupnorm_f16 -> sd_winograd_input_f16 (norm1 -> SiLU -> conv1) with one launch.  Recordable. */
+int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, const void* m, int ldm, const void* bias, const void* bias_bn,
+                             int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, void* v,
+                             void* stream);
 
 /* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with FEW (n <= 4) output channels:
  *   out[m, 0:n] = conv3x3(act(x * scale + shift))[m, 0:n] + bias,   act = SiLU if silu else identity

@@ -720,3 +720,72 @@ def test_winograd_f2x2_3x3_chain_equals_the_direct_convolution(ops, B, H, W, c0,
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float32)
     u_ref = torch.einsum("ia,nabc,jb->ijnc", G, g, G).reshape(16, n, C)
     assert float((U.float().cpu() - u_ref).abs().max()) <= 1e-3 * float(u_ref.abs().max())
+
+
+def _wino_input_ref(x_nhwc):
+    """[B,H,W,C] fp32 -> [16, B*H/2*W/2, C]: B^T d B of every 4x4 patch (stride 2, zero pad 1)."""
+    B, H, W, C = x_nhwc.shape
+    xp = torch.nn.functional.pad(x_nhwc, (0, 0, 1, 1, 1, 1))
+    d = xp.unfold(1, 4, 2).unfold(2, 4, 2)                       # [B, H/2, W/2, C, 4, 4]
+    Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+    v = torch.einsum("ia,btucab,jb->ijbtuc", Bt, d, Bt)
+    return v.reshape(16, B * (H // 2) * (W // 2), C)
+
+
+def _wino_output_ref(m, B, H, W):
+    """[16, T, N] fp32 -> [B*H*W, N]: A^T m A."""
+    N = m.shape[-1]
+    At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+    y = torch.einsum("ai,ijbtun,cj->btaucn", At, m.reshape(4, 4, B, H // 2, W // 2, N), At)
+    return y.reshape(B * H * W, N)
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,silu", [(2, 16, 16, 1280, 0, True), (2, 8, 8, 1280, 1280, True), (1, 16, 16, 1280, 640, True),
+                                              (3, 12, 20, 640, 0, False), (2, 4, 4, 2560, 0, True)])
+def test_groupnorm_fused_with_winograd_input_transform(ops, B, H, W, c0, c1, silu):
+    """sd_gn_winograd_input_f16, NHWC sources (norm1 of a deep ResNet block): GroupNorm(+SiLU) in fp32, rounded to fp16 as the unfused
+    GroupNorm kernel stores it, then B^T d B -- against the torch restatement, and BIT-EQUAL to the unfused chain of the library."""
+    C, hw, T = c0 + c1, H * W, B * (H // 2) * (W // 2)
+    x0, x1 = rnd(B * hw, c0, seed=1) + 0.5, (rnd(B * hw, c1, seed=2, scale=2.0) if c1 else None)
+    ga, be = rnd(C, seed=3) * 0.2 + 1, rnd(C, seed=4) * 0.2
+    V = torch.empty(16, T, C, dtype=F16, device=DEV)
+    ops.gn_winograd_input(V, ga.to(DEV), be.to(DEV), batch=B, h=H, w=W, c0=c0, x0=x0.to(DEV), x1=x1.to(DEV) if c1 else None, c1=c1, eps=1e-5,
+                          silu=silu)
+    xc = torch.cat([x0, x1], -1) if c1 else x0
+    n = so.groupnorm_ref(xc, ga, be, batch=B, hw=hw, eps=1e-5, silu=silu).half().float()
+    close(V, _wino_input_ref(n.reshape(B, H, W, C)))
+    # the unfused chain of the same library: GroupNorm kernel -> input transform
+    nb = torch.empty(B * hw, C, dtype=F16, device=DEV)
+    stats = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+    ops.groupnorm(x0.to(DEV), ga.to(DEV), be.to(DEV), nb, stats, batch=B, hw=hw, c0=c0, x1=x1.to(DEV) if c1 else None, c1=c1, eps=1e-5, silu=silu)
+    V2 = torch.empty_like(V)
+    ops.winograd_input(nb, V2, batch=B, h=H, w=W, c0=C)
+    assert torch.equal(V, V2)
+
+
+@pytest.mark.parametrize("B,H,W,n", [(2, 16, 16, 1280), (2, 8, 8, 1280), (1, 12, 20, 640)])
+def test_groupnorm_winograd_input_from_plane_products(ops, B, H, W, n):
+    """sd_gn_winograd_input_f16 fed the 16 plane products of the previous Winograd convolution (conv1 -> norm2 -> SiLU -> conv2):
+    A^T m A + bias + per-sample bias rounded to fp16, GroupNorm + SiLU, B^T d B -- against torch fp32 and against the unfused chain
+    (output transform -> GroupNorm kernel -> input transform; the statistics are summed in another order: fp16-rounding tolerance)."""
+    hw, T = H * W, B * (H // 2) * (W // 2)
+    m = rnd(16, T, n, seed=1)
+    b, bb = rnd(n, seed=2), rnd(B, n, seed=3)
+    ga, be = rnd(n, seed=4) * 0.2 + 1, rnd(n, seed=5) * 0.2
+    V = torch.empty(16, T, n, dtype=F16, device=DEV)
+    ops.gn_winograd_input(V, ga.to(DEV), be.to(DEV), batch=B, h=H, w=W, c0=n, m=m.to(DEV), bias=b.to(DEV), bias_bn=bb.to(DEV), eps=1e-5)
+    h = (_wino_output_ref(m.float(), B, H, W) + b.float()[None] + bb.float().repeat_interleave(hw, 0)).half()
+    nrm = so.groupnorm_ref(h, ga, be, batch=B, hw=hw, eps=1e-5, silu=True).half().float()
+    close(V, _wino_input_ref(nrm.reshape(B, H, W, n)))
+    hb = torch.empty(B * hw, n, dtype=F16, device=DEV)
+    ops.winograd_output(m.to(DEV), hb, batch=B, h=H, w=W, n=n, bias=b.to(DEV), bias_bn=bb.to(DEV))
+    assert torch.equal(hb.cpu(), h)                                             # the intermediate tensor the fused kernel never writes
+    nb = torch.empty(B * hw, n, dtype=F16, device=DEV)
+    stats = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+    ops.groupnorm(hb, ga.to(DEV), be.to(DEV), nb, stats, batch=B, hw=hw, c0=n, eps=1e-5, silu=True)
+    V2 = torch.empty_like(V)
+    ops.winograd_input(nb, V2, batch=B, h=H, w=W, c0=n)
+    close(V, V2.float(), tol=2e-3)
+    with pytest.raises(Exception, match="exceeds"):
+        ops.gn_winograd_input(torch.empty(16, 1024, 2560, dtype=F16, device=DEV), rnd(2560).to(DEV), rnd(2560).to(DEV), batch=1, h=64, w=64,
+                              c0=2560, x0=torch.empty(4096, 2560, dtype=F16, device=DEV))
