@@ -192,10 +192,15 @@ __device__ __forceinline__ float wave_sum64(float x) {
   return x;
 }
 
+// VEC = channels per lane in the plane-product load, the normalisation and the transform (8 when the group width allows 16-byte
+// accesses, else 4).  The NHWC load keeps 4-channel chunks in sd_groupnorm_f16's own thread order, so that the statistics -- and with
+// them every output bit -- equal the unfused GroupNorm kernel -> input transform chain.
+template <int VEC>
 __global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
-  __shared__ _Float16 slice[kGnWinoMaxSlice];
+  typedef _Float16 hv __attribute__((ext_vector_type(VEC)));
+  __shared__ __attribute__((aligned(16))) _Float16 slice[kGnWinoMaxSlice];
   __shared__ float rs[4], rq[4];
-  const int C = a.c0 + a.c1, cg = C / a.groups, q4 = cg >> 2;
+  const int C = a.c0 + a.c1, cg = C / a.groups, q4 = cg >> 2, qv = cg / VEC;
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int hw = a.h * a.w, th = a.h >> 1, tw = a.w >> 1, T = th * tw;
   const long long ntile = (long long)gridDim.y * T;
@@ -210,46 +215,48 @@ __global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
       for (int j = 0; j < 4; ++j) { const float f = (float)v4[j]; s += f; q += f * f; }
     }
   } else {
-    for (int it = tid; it < T * q4; it += 256) {
-      const int t = it / q4, cc = (it - t * q4) * 4, c = g * cg + cc;
+    for (int it = tid; it < T * qv; it += 256) {
+      const int t = it / qv, cc = (it - t * qv) * VEC, c = g * cg + cc;
       const int ty = t / tw, tx = t - ty * tw;
       const long long tg = (long long)b * T + t;
-      float sm[2][4][4];
+      float sm[2][4][VEC];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float mm[4][4];
+        float mm[4][VEC];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const half4w v4 = *reinterpret_cast<const half4w*>(a.m + ((long long)(4 * i + j) * ntile + tg) * a.ldm + c);
+          const hv v4 = *reinterpret_cast<const hv*>(a.m + ((long long)(4 * i + j) * ntile + tg) * a.ldm + c);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) mm[i][e] = (float)v4[e];
+          for (int e = 0; e < VEC; ++e) mm[i][e] = (float)v4[e];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < VEC; ++e) {
           sm[0][j][e] = mm[0][e] + mm[1][e] + mm[2][e];
           sm[1][j][e] = mm[1][e] - mm[2][e] - mm[3][e];
         }
       }
-      float add[4] = {0.f, 0.f, 0.f, 0.f};
-      if (a.bias) { const half4w v4 = *reinterpret_cast<const half4w*>(a.bias + c);
+      float add[VEC];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) add[e] += (float)v4[e]; }
-      if (a.bias_bn) { const half4w v4 = *reinterpret_cast<const half4w*>(a.bias_bn + (long long)b * a.ldbb + c);
+      for (int e = 0; e < VEC; ++e) add[e] = 0.0f;
+      if (a.bias) { const hv v4 = *reinterpret_cast<const hv*>(a.bias + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) add[e] += (float)v4[e]; }
+        for (int e = 0; e < VEC; ++e) add[e] += (float)v4[e]; }
+      if (a.bias_bn) { const hv v4 = *reinterpret_cast<const hv*>(a.bias_bn + (long long)b * a.ldbb + c);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) add[e] += (float)v4[e]; }
 #pragma unroll
       for (int ya = 0; ya < 2; ++ya)
 #pragma unroll
         for (int xb = 0; xb < 2; ++xb) {
-          half4w o;
+          hv o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < VEC; ++e) {
             const float y = (xb == 0 ? sm[ya][0][e] + sm[ya][1][e] + sm[ya][2][e] : sm[ya][1][e] - sm[ya][2][e] - sm[ya][3][e]) + add[e];
             o[e] = (_Float16)y;
             const float f = (float)o[e];            // the statistics see the fp16 tensor the unfused chain would have stored
             s += f; q += f * f;
           }
-          *reinterpret_cast<half4w*>(slice + ((2 * ty + ya) * a.w + 2 * tx + xb) * cg + cc) = o;
+          *reinterpret_cast<hv*>(slice + ((2 * ty + ya) * a.w + 2 * tx + xb) * cg + cc) = o;
         }
     }
   }
@@ -263,54 +270,56 @@ __global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
   const float mean = s / count;
   const float var = fmaxf(q / count - mean * mean, 0.0f);
   const float rstd = rsqrtf(var + a.eps);
-  for (int it = tid; it < hw * q4; it += 256) {
-    const int p = it / q4, cc = (it - p * q4) * 4, c = g * cg + cc;
-    const half4w ga = *reinterpret_cast<const half4w*>(a.gamma + c), be = *reinterpret_cast<const half4w*>(a.beta + c);
-    half4w v4 = *reinterpret_cast<half4w*>(slice + p * cg + cc);
+  for (int it = tid; it < hw * qv; it += 256) {
+    const int p = it / qv, cc = (it - p * qv) * VEC, c = g * cg + cc;
+    const hv ga = *reinterpret_cast<const hv*>(a.gamma + c), be = *reinterpret_cast<const hv*>(a.beta + c);
+    hv v4 = *reinterpret_cast<hv*>(slice + p * cg + cc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VEC; ++j) {
       const float sc = rstd * (float)ga[j];
       float y = fmaf((float)v4[j], sc, (float)be[j] - mean * sc);
       if (a.silu) y = y / (1.0f + __expf(-y));
       v4[j] = (_Float16)y;
     }
-    *reinterpret_cast<half4w*>(slice + p * cg + cc) = v4;
+    *reinterpret_cast<hv*>(slice + p * cg + cc) = v4;
   }
   __syncthreads();
-  for (int it = tid; it < T * q4; it += 256) {
-    const int t = it / q4, cc = (it - t * q4) * 4, c = g * cg + cc;
+  for (int it = tid; it < T * qv; it += 256) {
+    const int t = it / qv, cc = (it - t * qv) * VEC, c = g * cg + cc;
     const int ty = t / tw, tx = t - ty * tw;
-    float d[4][4][4];
+    float d[4][4][VEC];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int y = 2 * ty - 1 + i;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int x = 2 * tx - 1 + j;
-        half4w v4 = {0, 0, 0, 0};
-        if (y >= 0 && y < a.h && x >= 0 && x < a.w) v4 = *reinterpret_cast<const half4w*>(slice + (y * a.w + x) * cg + cc);
+        hv v4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[i][j][e] = (float)v4[e];
+        for (int e = 0; e < VEC; ++e) v4[e] = (_Float16)0.0f;
+        if (y >= 0 && y < a.h && x >= 0 && x < a.w) v4 = *reinterpret_cast<const hv*>(slice + (y * a.w + x) * cg + cc);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) d[i][j][e] = (float)v4[e];
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < VEC; ++e) {
         const float d0 = d[0][j][e], d1 = d[1][j][e], d2 = d[2][j][e], d3 = d[3][j][e];
         d[0][j][e] = d0 - d2; d[1][j][e] = d1 + d2; d[2][j][e] = d2 - d1; d[3][j][e] = d1 - d3;
       }
     const long long tg = (long long)b * T + t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      half4w o[4];
+      hv o[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < VEC; ++e) {
         const float t0 = d[i][0][e], t1 = d[i][1][e], t2 = d[i][2][e], t3 = d[i][3][e];
         o[0][e] = (_Float16)(t0 - t2); o[1][e] = (_Float16)(t1 + t2); o[2][e] = (_Float16)(t2 - t1); o[3][e] = (_Float16)(t1 - t3);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<half4w*>(a.v + ((long long)(4 * i + j) * ntile + tg) * C + c) = o[j];
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<hv*>(a.v + ((long long)(4 * i + j) * ntile + tg) * C + c) = o[j];
     }
   }
 }
@@ -392,7 +401,11 @@ int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, con
   a.x0 = (const _Float16*)x0; a.x1 = (const _Float16*)x1; a.c0 = c0; a.c1 = c1; a.m = (const _Float16*)m; a.ldm = ldm;
   a.bias = (const _Float16*)bias; a.bias_bn = (const _Float16*)bias_bn; a.ldbb = ldbb > 0 ? ldbb : C; a.h = h; a.w = w; a.groups = groups;
   a.eps = eps; a.gamma = (const _Float16*)gamma; a.beta = (const _Float16*)beta; a.silu = silu; a.v = (_Float16*)v;
-  hipLaunchKernelGGL(gn_winograd_input_kernel, dim3((unsigned)groups, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if ((C / groups) % 8 == 0 && (!m || ldm % 8 == 0) && a.ldbb % 8 == 0 && al16(m) && al16(bias) && al16(bias_bn) && al16(gamma) && al16(beta) && al16(v))
+    hipLaunchKernelGGL(gn_winograd_input_kernel<8>, dim3((unsigned)groups, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(gn_winograd_input_kernel<4>, dim3((unsigned)groups, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("sd_gn_winograd_input_f16");
 }
 

@@ -25,7 +25,10 @@ class LaunchGraph:
         self.launches = []          # zero-argument closures
         self.tags = []              # (description, flops) per launch, for profiling
         self.alg_bytes = []         # algorithmic HBM bytes per launch (inputs read once + output written once)
-        self.flops = 0              # algorithmic MFMA flops per run (2*M*N*K of every GEMM-shaped launch)
+        self.flops = 0              # ALGORITHMIC flops per run: 2*M*N*K of every GEMM-shaped operator (a Winograd convolution counts as the
+                                    # 3x3 convolution it computes, 2 * 9 * M * N * C_in)
+        self.exec_flops = 0         # MFMA flops actually issued (a Winograd convolution: 16 plane products = 4/9 of the above)
+        self.exec_tags = []         # executed flops per launch, parallel to `tags`
         self._gn_stats = None
         self._ws = None             # split-K workspace shared by every GEMM of the graph (launches are serial)
         self._colstats = {}         # data_ptr of a GEMM output -> its [M/32][2][N] column-sum buffer (GroupNorm statistics)
@@ -46,11 +49,14 @@ class LaunchGraph:
         return self._gn_stats
 
     # ---- recording
-    def add(self, fn, flops=0, tag="", nbytes=0):
+    def add(self, fn, flops=0, tag="", nbytes=0, alg_flops=None):
+        alg = flops if alg_flops is None else alg_flops
         self.launches.append(fn)
-        self.tags.append((tag, flops))
+        self.tags.append((tag, alg))
+        self.exec_tags.append(flops)
         self.alg_bytes.append(nbytes)
-        self.flops += flops
+        self.flops += alg
+        self.exec_flops += flops
 
     def conv(self, a0, w, out, *, batch, in_h, in_w, c0, n, out_h=None, out_w=None, a1=None, c1=0, taps=1, **kw):
         oh = out_h if out_h is not None else in_h
@@ -61,6 +67,7 @@ class LaunchGraph:
         kw.setdefault("workspace", self._ws)
         # GroupNorm statistics of the consumer come for free from the epilogue of large, never-split GEMMs
         M = batch * oh * ow
+        alg_flops = kw.pop("alg_flops", None)
         if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= 16384 and M % 32 == 0:
             cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
             kw["colstats"] = cs
@@ -72,12 +79,12 @@ class LaunchGraph:
             self._rowstats[out.data_ptr()] = rs
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
                                        c1=c1, taps=taps, **kw),
-                 flops=2 * batch * oh * ow * n * taps * (c0 + c1) * z,
+                 flops=2 * batch * oh * ow * n * taps * (c0 + c1) * z, alg_flops=alg_flops,
                  # unique bytes: the input activation(s), the weights (shared over z unless strided), bias / residual, the output
                  nbytes=2 * (z * batch * in_h * in_w * (c0 + c1) + (z if kw.get("stride_w") else 1) * n * taps * (c0 + c1)
                              + z * M * (n // 2 if kw.get("epi", 0) & ops.EPI_GEGLU else n) * (2 if kw.get("res") is not None else 1)
                              + (n if kw.get("bias") is not None else 0) + (batch * n if kw.get("bias_bn") is not None else 0)),
-                 tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}")
+                 tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}" + (" (winograd planes)" if alg_flops else ""))
         return out
 
     # ---- Winograd F(2x2,3x3) for the deep ResNet levels (profiles/r04_notes.md 1, 4): input transform -> 16 plane products (the 1x1 GEMM
@@ -91,7 +98,8 @@ class LaunchGraph:
 
     def winograd_planes(self, V, U, *, tiles, c, n):
         P = self.buf(16, tiles, n)
-        self.conv(V, U, P, batch=tiles, in_h=1, in_w=1, c0=c, n=n, nbatch_z=16, stride_a=tiles * c, stride_w=n * c, stride_out=tiles * n)
+        self.conv(V, U, P, batch=tiles, in_h=1, in_w=1, c0=c, n=n, nbatch_z=16, stride_a=tiles * c, stride_w=n * c, stride_out=tiles * n,
+                  alg_flops=2 * 9 * (4 * tiles) * n * c)            # the 3x3 convolution these 16 products compute
         return P
 
     def winograd_input(self, a0, *, batch, h, w, c0, a1=None, c1=0):

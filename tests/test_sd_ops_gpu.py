@@ -728,7 +728,7 @@ def _wino_input_ref(x_nhwc):
     xp = torch.nn.functional.pad(x_nhwc, (0, 0, 1, 1, 1, 1))
     d = xp.unfold(1, 4, 2).unfold(2, 4, 2)                       # [B, H/2, W/2, C, 4, 4]
     Bt = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
-    v = torch.einsum("ia,btucab,jb->ijbtuc", Bt, d, Bt)
+    v = torch.einsum("ia,ntucab,jb->ijntuc", Bt, d, Bt)
     return v.reshape(16, B * (H // 2) * (W // 2), C)
 
 
@@ -736,7 +736,7 @@ def _wino_output_ref(m, B, H, W):
     """[16, T, N] fp32 -> [B*H*W, N]: A^T m A."""
     N = m.shape[-1]
     At = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
-    y = torch.einsum("ai,ijbtun,cj->btaucn", At, m.reshape(4, 4, B, H // 2, W // 2, N), At)
+    y = torch.einsum("ai,ijstun,cj->staucn", At, m.reshape(4, 4, B, H // 2, W // 2, N), At)
     return y.reshape(B * H * W, N)
 
 
