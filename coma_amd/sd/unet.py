@@ -32,8 +32,9 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-WINOGRAD_MAX_H = 16         # ResNet 3x3 convolutions of feature maps up to 16 x 16 with >= 640 channels run as Winograd F(2x2,3x3): -0.6 ms per
-                            # batch-16 forward measured inside the captured graph (A B A B, profiles/r04_notes.md 4); the 32 x 32 level adds nothing
+WINOGRAD_MAX_H = 32         # ResNet 3x3 convolutions of feature maps up to 32 x 32 with >= 640 channels run as Winograd F(2x2,3x3).  Measured inside
+                            # the captured batch-16 forward (A B A B on one box, profiles/r04_notes.md 4): 19.02 ms direct, 18.18 ms with the
+                            # 16 x 16 / 8 x 8 levels, 18.01 ms with the 32 x 32 level as well; the 64 x 64 level (C = 320) loses.
 
 
 class HipUNet2DConditionModel:
