@@ -119,7 +119,7 @@ static int launch(const PlanRec& r, void* st) {
       return sd_conv3x3_small_n_f16(p[0], (const float*)p[1], (int)i[0], p[2], p[3], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], p[4],
                                     (int)i[6], st);
     case PK_WINO_IN:
-      return sd_winograd_input_f16(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], p[2], st);
+      return sd_winograd_input_f16(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], p[2], st);
     case PK_WINO_OUT:
       return sd_winograd_output_f16(p[0], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], p[1], p[2], (int)i[5], p[3], (int)i[6], p[4],
                                     (int)i[7], (int)i[8], st);

@@ -23,7 +23,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // thread = (tile, chunk of 8 channels); V[p][t][c], p = 4 i + j
 __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1, int c0,
-                                                            int c1, int batch, int h, int w, _Float16* __restrict__ v) {
+                                                            int c1, int batch, int h, int w, int up, _Float16* __restrict__ v) {
   const int c = c0 + c1, cch = c >> 3;
   const int th = h >> 1, tw = w >> 1;
   const long long ntile = (long long)batch * th * tw;
@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __r
     for (int j = 0; j < 4; ++j) {
       const int x = 2 * tx - 1 + j;
       half8 q = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (y >= 0 && y < h && x >= 0 && x < w) q = *reinterpret_cast<const half8*>(src + (((long long)b * h + y) * w + x) * ld + cc);
+      // up = 1: the 3x3 window slides over the nearest-x2 upsampling of the [h/2, w/2] source (diffusers Upsample2D)
+      if (y >= 0 && y < h && x >= 0 && x < w)
+        q = *reinterpret_cast<const half8*>(src + (((long long)b * (h >> up) + (y >> up)) * (w >> up) + (x >> up)) * ld + cc);
 #pragma unroll
       for (int e = 0; e < 8; ++e) d[i][j][e] = (float)q[e];
     }
@@ -328,20 +330,22 @@ __global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
 
 extern "C" {
 
-int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, void* v, void* stream) {
+int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, void* v, void* stream) {
   using namespace sd;
   if (plan_recording()) {
     PlanRec r{};
     r.kind = PK_WINO_IN;
-    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = v; r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = h; r.i[4] = w;
+    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = v; r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = h; r.i[4] = w; r.i[5] = upsample;
     return plan_record(r);
   }
+  if (upsample != 0 && upsample != 1) return fail(COMA_E_INVALID, "sd_winograd_input_f16: upsample must be 0 or 1");
+  if (upsample && ((h & 3) || (w & 3))) return fail(COMA_E_INVALID, "sd_winograd_input_f16: upsample needs h, w multiples of 4 (an even source)");
   if (!x0 || !v) return fail(COMA_E_INVALID, "sd_winograd_input_f16: null pointer");
   if (c0 <= 0 || c0 % 8 || c1 < 0 || c1 % 8 || (c1 > 0 && !x1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: channel counts must be multiples of 8");
   if (batch <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: even h, w required");
   const long long total = (long long)batch * (h / 2) * (w / 2) * ((c0 + c1) / 8);
   hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const _Float16*)x0, (const _Float16*)x1, c0, c1, batch, h, w, (_Float16*)v);
+                     (const _Float16*)x0, (const _Float16*)x1, c0, c1, batch, h, w, upsample, (_Float16*)v);
   return check_launch("sd_winograd_input_f16");
 }
 

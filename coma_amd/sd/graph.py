@@ -102,11 +102,11 @@ class LaunchGraph:
                   alg_flops=2 * 9 * (4 * tiles) * n * c)            # the 3x3 convolution these 16 products compute
         return P
 
-    def winograd_input(self, a0, *, batch, h, w, c0, a1=None, c1=0):
+    def winograd_input(self, a0, *, batch, h, w, c0, a1=None, c1=0, upsample=False):
         C, T = c0 + c1, batch * (h // 2) * (w // 2)
         V = self.buf(16, T, C)
-        self.add(lambda: ops.winograd_input(a0, V, batch=batch, h=h, w=w, c0=c0, x1=a1, c1=c1),
-                 tag=f"winograd input B={batch} {h}x{w} C={C}", nbytes=2 * 5 * batch * h * w * C)
+        self.add(lambda: ops.winograd_input(a0, V, batch=batch, h=h, w=w, c0=c0, x1=a1, c1=c1, upsample=upsample),
+                 tag=f"winograd input{' (upsampled)' if upsample else ''} B={batch} {h}x{w} C={C}", nbytes=2 * 5 * batch * h * w * C)
         return V
 
     GN_WINO_MAX_SLICE = 20480
@@ -129,10 +129,11 @@ class LaunchGraph:
                  tag=f"winograd output B={batch} {h}x{w} N={n}", nbytes=2 * (5 + (1 if res is not None else 0)) * batch * h * w * n)
         return out
 
-    def conv3x3_winograd(self, a0, w9, out, *, batch, in_h, in_w, c0, n, a1=None, c1=0, bias=None, bias_bn=None, ldbb=0, res=None):
-        """The unfused chain: input transform -> plane products -> output transform (+ bias, per-sample bias, residual)."""
+    def conv3x3_winograd(self, a0, w9, out, *, batch, in_h, in_w, c0, n, a1=None, c1=0, bias=None, bias_bn=None, ldbb=0, res=None, upsample=False):
+        """The unfused chain: input transform -> plane products -> output transform (+ bias, per-sample bias, residual).  in_h, in_w are
+        the convolution's own (= output) resolution; with upsample the sources are [in_h / 2, in_w / 2]."""
         C, T = c0 + c1, batch * (in_h // 2) * (in_w // 2)
-        V = self.winograd_input(a0, batch=batch, h=in_h, w=in_w, c0=c0, a1=a1, c1=c1)
+        V = self.winograd_input(a0, batch=batch, h=in_h, w=in_w, c0=c0, a1=a1, c1=c1, upsample=upsample)
         P = self.winograd_planes(V, self.winograd_weight(w9, n=n, c=C), tiles=T, c=C, n=n)
         return self.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res)
 

@@ -251,9 +251,10 @@ def copy_d2d(dst, src):
     _lib.check(_lib.lib().sd_copy_d2d(dst.data_ptr(), src.data_ptr(), n, _stream(dst)), "sd_copy_d2d")
 
 
-def winograd_input(x0, v, *, batch, h, w, c0, x1=None, c1=0):
-    """v fp16 [16][batch*h/2*w/2][c0+c1] = B^T d B of every 4x4 patch (F(2x2,3x3), zero pad 1)."""
-    _lib.check(_lib.lib().sd_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, h, w, _p(v, "v"), _stream(v)),
+def winograd_input(x0, v, *, batch, h, w, c0, x1=None, c1=0, upsample=False):
+    """v fp16 [16][batch*h/2*w/2][c0+c1] = B^T d B of every 4x4 patch (F(2x2,3x3), zero pad 1); upsample: [h, w] is the nearest-x2
+    upsampling of the [h/2, w/2] sources."""
+    _lib.check(_lib.lib().sd_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, h, w, 1 if upsample else 0, _p(v, "v"), _stream(v)),
                "sd_winograd_input_f16")
     return v
 

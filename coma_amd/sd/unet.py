@@ -59,6 +59,7 @@ class HipUNet2DConditionModel:
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
+        self.winograd_upsamplers = os.environ.get("SD_WINOGRAD_UP", "1") != "0"   # ... and the Upsample2D convolutions of those levels (A/B: 0)
         self.fuse_gn_winograd = os.environ.get("SD_GN_WINOGRAD", "1") != "0"     # GroupNorms folded into the Winograd transforms (A/B: 0)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
@@ -140,8 +141,13 @@ class HipUNet2DConditionModel:
             if i < len(ch) - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 o = g.buf(B * 4 * H * W, cout)
-                g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout,
-                       n=cout, taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
+                if self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and self.winograd_upsamplers:
+                    # Upsample2D + conv at the deep levels: the input transform reads the nearest-x2 upsampling in place
+                    g.conv3x3_winograd(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=2 * H, in_w=2 * W, c0=cout, n=cout, bias=s[p + ".bias"],
+                                       upsample=True)
+                else:
+                    g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout,
+                           n=cout, taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
                 h, H, W = o, 2 * H, 2 * W
         gn = g.buf(B * H * W, cin)
         g.groupnorm(h, s["conv_norm_out.weight"], s["conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin, eps=1e-5, silu=True)

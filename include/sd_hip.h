@@ -189,12 +189,13 @@ int sd_xattn_chain_f16(const void* attn1_out, const void* h, const void* wo1, co
 
 /* Winograd F(2x2,3x3) around a plane-batched GEMM: a 3x3 / stride 1 / pad 1 convolution as 16 independent [T, C_in] x [C_in, C_out]
  * products (T = batch * h/2 * w/2 output tiles) run by sd_conv_gemm_f16 with nbatch_z = 16 -- 2.25 x fewer MFMA flops.
- *   sd_winograd_input_f16   v fp16 [16][T][c0+c1] = B^T d B of every 4x4 input patch (two concatenated NHWC sources, zero pad)
+ *   sd_winograd_input_f16   v fp16 [16][T][c0+c1] = B^T d B of every 4x4 input patch (two concatenated NHWC sources, zero pad);
+ *                           upsample = 1: [h, w] is the nearest-x2 upsampling of the [h/2, w/2] sources (diffusers Upsample2D + conv)
  *   sd_winograd_weight_f16  u fp16 [16][n][c] = G g G^T of w fp16 [n][9][c] (computed in fp32, rounded once; at prep time)
  *   sd_winograd_output_f16  out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] + bias + per-sample bias, SiLU, + residual
  * h, w even; channel counts multiples of 8.  sd_winograd_input_f16 / _output_f16 are recordable (sd_winograd_weight_f16 runs at prep time).
  * replaces: diffusers Conv2d(3x3) inside self.unet(...) / self.vae.decode, utils/adaptive_mask_inpainting.py:1001-1007, :1086, :1112. */
-int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, void* v, void* stream);
+int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, void* v, void* stream);
 int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream);
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
                            const void* res, int ldr, void* out, int ldo, int silu, void* stream);

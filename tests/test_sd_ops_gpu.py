@@ -789,3 +789,24 @@ def test_groupnorm_winograd_input_from_plane_products(ops, B, H, W, n):
     with pytest.raises(Exception, match="exceeds"):
         ops.gn_winograd_input(torch.empty(16, 1024, 2560, dtype=F16, device=DEV), rnd(2560).to(DEV), rnd(2560).to(DEV), batch=1, h=64, w=64,
                               c0=2560, x0=torch.empty(4096, 2560, dtype=F16, device=DEV))
+
+
+@pytest.mark.parametrize("B,H,W,C,n", [(2, 8, 8, 128, 64), (1, 6, 10, 64, 128)])
+def test_winograd_on_the_nearest_upsampled_input(ops, B, H, W, C, n):
+    """Upsample2D + conv (diffusers: F.interpolate(nearest, x2) then a 3x3 convolution) with the Winograd input transform reading the
+    upsampled tensor in place (upsample = 1) -- against conv2d of the materialised upsampling in fp32."""
+    M_out, T = B * 4 * H * W, B * H * W
+    x = rnd(B * H * W, C, seed=1)
+    w = rnd(n, 9, C, seed=2, scale=(9 * C) ** -0.5)
+    b = rnd(n, seed=3)
+    V = torch.empty(16, T, C, dtype=F16, device=DEV)
+    U = torch.empty(16, n, C, dtype=F16, device=DEV)
+    P = torch.empty(16, T, n, dtype=F16, device=DEV)
+    out = torch.empty(M_out, n, dtype=F16, device=DEV)
+    ops.winograd_weight(w.reshape(n, -1).to(DEV), U, n=n, c=C)
+    ops.winograd_input(x.to(DEV), V, batch=B, h=2 * H, w=2 * W, c0=C, upsample=True)
+    ops.conv_gemm(V, U, P, batch=T, in_h=1, in_w=1, c0=C, n=n, nbatch_z=16, stride_a=T * C, stride_w=n * C, stride_out=T * n)
+    ops.winograd_output(P, out, batch=B, h=2 * H, w=2 * W, n=n, bias=b.to(DEV))
+    close(out, so.conv_ref(x, w, batch=B, h=H, w_=W, taps=9, upsample=True, bias=b), tol=4e-3)
+    with pytest.raises(Exception, match="multiples of 4"):
+        ops.winograd_input(x.to(DEV), V, batch=B, h=2 * H + 2, w=2 * W, c0=C, upsample=True)
