@@ -1,8 +1,8 @@
 // sd_smallconv.hip -- 3x3 convolutions with a handful of channels on one side (gfx950): the two ends of the VAE.
 //
 // sd_conv3x3_small_n_f16: GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with n <= 4 OUTPUT channels --
-//   the decoder's conv_norm_out -> SiLU -> conv_out (128 -> 3 at 512 x 512; self.vae.decode, utils/adaptive_mask_inpainting.py:1086,
-//   :1112).  Through the implicit GEMM this layer computed a 64-column tile for 3 channels (0.45 ms per 8 images) behind a separate
+//   the VAE decoder's conv_norm_out -> SiLU -> conv_out (128 -> 3 at 512 x 512; self.vae.decode, utils/adaptive_mask_inpainting.py:1086,
+//   :1112) and the UNet's (320 -> 4 at 64 x 64; self.unet(...), :1001-1007).  Through the implicit GEMM this layer computed a 64-column tile for 3 channels (0.45 ms per 8 images) behind a separate
 //   GroupNorm pass that read and wrote the 0.5 GB tensor once more.  Here a workgroup owns a 16 x 16 pixel tile: the (18 x 18) x 64
 //   channel halo patch is normalised, activated and rounded to fp16 on its way into LDS (what the GroupNorm kernel would have
 //   stored), the weights of the chunk live in registers as 18 MFMA operands (n padded to 16 rows, 9 taps x 64 channels), and every
@@ -85,10 +85,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_n_kernel(const _Float16*
     }
   };
 
-  fetch(0);
-  __syncthreads();                                         // `aff` is visible
-#pragma unroll
-  for (int chunk = 0; chunk < C / kChunk; ++chunk) {
+  // one chunk: commit the fetched patch, bring this chunk's weights into registers, (optionally) put the next chunk's loads in
+  // flight, then 9 taps x 2 K-halves x 4 pixel rows of MFMAs
+  auto chunk_body = [&](int chunk, bool prefetch_next) {
     commit(chunk);
     // this chunk's weights -> registers (18 MFMA operands): operand row = output channel (zero rows above n_out), K octet = lane >> 4
     half8 wf[9][kChunk / 32];
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_n_kernel(const _Float16*
         if (lp < n_out) z = *reinterpret_cast<const half8*>(w + ((size_t)lp * 9 + tap) * C + chunk * kChunk + kh * 32 + lo * 8);
         wf[tap][kh] = z;
       }
-    if (chunk + 1 < C / kChunk) fetch(chunk + 1);          // in flight under this chunk's MFMAs
+    if (prefetch_next) fetch(chunk + 1);                   // in flight under this chunk's MFMAs
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -116,6 +115,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_n_kernel(const _Float16*
       }
     }
     __syncthreads();                                       // every wave is done reading the tile before the next commit overwrites it
+  };
+  if constexpr (C / kChunk <= 2) {
+    // two chunks (the VAE's 128 channels): unrolled, the second chunk's HBM latency runs under the first chunk's MFMAs
+    fetch(0);
+    __syncthreads();                                       // `aff` is visible
+#pragma unroll
+    for (int chunk = 0; chunk < C / kChunk; ++chunk) chunk_body(chunk, chunk + 1 < C / kChunk);
+  } else {
+    // more chunks (the UNet's 320 channels): a rolled loop; holding the prefetched patch across the back edge next to the weights
+    // spills, so the fetch sits in front of its commit and the second resident workgroup of the CU covers its latency
+    __syncthreads();
+#pragma unroll 1
+    for (int chunk = 0; chunk < C / kChunk; ++chunk) {
+      fetch(chunk);
+      chunk_body(chunk, false);
+    }
   }
   // D[n][pixel]: lane = pixel + 16 * (n / 4), register = n % 4 -> lanes 0..15 hold the n_out <= 4 real channels of their pixel
   if (lane < 16) {
@@ -150,12 +165,16 @@ extern "C" int sd_conv3x3_small_n_f16(const void* x, const float* gn_affine, int
     return sd::plan_record(r);
   }
   if (!x || !w || !out) return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: null pointer");
-  if (c != 128) return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: c = %d (built for 128 input channels)", c);
+  if (c != 128 && c != 320) return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: c = %d (built for 128 and 320 input channels)", c);
   if (n < 1 || n > 4 || batch <= 0 || h <= 0 || w_ <= 0 || ldo < 8 || ldo % 8)
     return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: bad shape n=%d batch=%d h=%d w=%d ldo=%d", n, batch, h, w_, ldo);
   if ((size_t)batch * h * w_ * c >= (1ull << 40)) return fail(COMA_E_INVALID, "sd_conv3x3_small_n_f16: tensor too large");
   const dim3 grid((unsigned)((w_ + kTile - 1) / kTile), (unsigned)((h + kTile - 1) / kTile), (unsigned)batch);
-  hipLaunchKernelGGL(conv3x3_small_n_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, gn_affine, silu,
-                     (const _Float16*)w, (const _Float16*)bias, n, h, w_, (_Float16*)out, ldo);
+  if (c == 128)
+    hipLaunchKernelGGL(conv3x3_small_n_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, gn_affine, silu,
+                       (const _Float16*)w, (const _Float16*)bias, n, h, w_, (_Float16*)out, ldo);
+  else
+    hipLaunchKernelGGL(conv3x3_small_n_kernel<320>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, gn_affine, silu,
+                       (const _Float16*)w, (const _Float16*)bias, n, h, w_, (_Float16*)out, ldo);
   return check_launch("conv3x3_small_n_kernel");
 }

@@ -59,6 +59,7 @@ class HipUNet2DConditionModel:
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
+        self.fuse_conv_out = os.environ.get("SD_FUSE_CONV_OUT", "1") != "0"       # conv_norm_out + SiLU + conv_out as one launch (A/B: 0)
         self.winograd_upsamplers = os.environ.get("SD_WINOGRAD_UP", "1") != "0"   # ... and the Upsample2D convolutions of those levels (A/B: 0)
         self.fuse_gn_winograd = os.environ.get("SD_GN_WINOGRAD", "1") != "0"     # GroupNorms folded into the Winograd transforms (A/B: 0)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
@@ -149,11 +150,18 @@ class HipUNet2DConditionModel:
                     g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout,
                            n=cout, taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
                 h, H, W = o, 2 * H, 2 * W
-        gn = g.buf(B * H * W, cin)
-        g.groupnorm(h, s["conv_norm_out.weight"], s["conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin, eps=1e-5, silu=True)
         self.eps = g.buf(B * H * W, 64, zero=True)                # 4 valid output channels
-        g.conv(gn, conv_weight(s["conv_out.weight"], cout_pad=64), self.eps, batch=B, in_h=H, in_w=W, c0=cin, n=64, taps=9,
-               bias=pad_vec(s["conv_out.bias"], 64))
+        nout = s["conv_out.weight"].shape[0]
+        if self.fuse_conv_out and cin == 320 and nout <= 4:
+            # conv_norm_out -> SiLU -> conv_out in one pass over the last feature map (sd_conv3x3_small_n_f16): no normalised copy, no
+            # 64-column GEMM tile for 4 channels
+            g.gn_silu_conv3x3_small_n(h, s["conv_norm_out.weight"], s["conv_norm_out.bias"], conv_weight(s["conv_out.weight"]),
+                                      s["conv_out.bias"].contiguous(), self.eps, batch=B, h=H, w_=W, c=cin, n=nout, eps=1e-5, silu=True)
+        else:
+            gn = g.buf(B * H * W, cin)
+            g.groupnorm(h, s["conv_norm_out.weight"], s["conv_norm_out.bias"], gn, batch=B, hw=H * W, c0=cin, eps=1e-5, silu=True)
+            g.conv(gn, conv_weight(s["conv_out.weight"], cout_pad=64), self.eps, batch=B, in_h=H, in_w=W, c0=cin, n=64, taps=9,
+                   bias=pad_vec(s["conv_out.bias"], 64))
 
     def _resnet(self, p, x0, c0, x1, c1, cout, H, W):
         g, s, B = self.g, self.s, self._B

@@ -213,12 +213,13 @@ int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, con
 
 /* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with FEW (n <= 4) output channels:
  *   out[m, 0:n] = conv3x3(act(x * scale + shift))[m, 0:n] + bias,   act = SiLU if silu else identity
- * x fp16 NHWC [batch, h, w, c] (c = 128); gn_affine fp32 [batch][c][2] = (scale, shift) per sample and channel (the table of
+ * x fp16 NHWC [batch, h, w, c] (c = 128 or 320); gn_affine fp32 [batch][c][2] = (scale, shift) per sample and channel (the table of
  * sd_groupnorm_table_f16) or NULL for a plain convolution; w fp16 [n][9][c]; bias fp16 [n] or NULL; out fp16 [batch*h*w, ldo]
  * (ldo >= 8, multiple of 8): channels 0..7 of every pixel are written (n results + zeros), channels >= 8 are left alone.
  * The normalised tensor is never written: the halo patch of a 16 x 16 pixel tile is activated on its way into LDS and rounded to
  * fp16 there, i.e. the result equals GroupNorm kernel -> convolution up to fp32 summation order.  Recordable.
- * replaces: decoder.conv_norm_out + SiLU + decoder.conv_out of AutoencoderKL (self.vae.decode, utils/adaptive_mask_inpainting.py:1086, :1112). */
+ * replaces: decoder.conv_norm_out + SiLU + decoder.conv_out of AutoencoderKL (self.vae.decode, utils/adaptive_mask_inpainting.py:1086, :1112)
+ *           and conv_norm_out + SiLU + conv_out of UNet2DConditionModel (self.unet(...), :1001-1007). */
 int sd_conv3x3_small_n_f16(const void* x, const float* gn_affine, int silu, const void* w, const void* bias, int batch, int h, int w_,
                            int c, int n, void* out, int ldo, void* stream);
 

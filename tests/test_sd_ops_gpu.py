@@ -667,13 +667,14 @@ def test_layernorm_folded_into_the_v_transposed_projection(ops, L, C):
     assert bool(torch.isfinite(out.float()).all())
 
 
-@pytest.mark.parametrize("B,H,W,n,norm,silu", [(2, 32, 48, 3, True, True), (1, 24, 40, 3, True, True), (2, 16, 16, 4, True, False),
-                                               (1, 50, 21, 1, False, False), (1, 64, 64, 3, False, False)])
-def test_conv3x3_small_n_with_folded_groupnorm(ops, B, H, W, n, norm, silu):
+@pytest.mark.parametrize("B,H,W,n,norm,silu,C", [(2, 32, 48, 3, True, True, 128), (1, 24, 40, 3, True, True, 128), (2, 16, 16, 4, True, False, 128),
+                                                 (1, 50, 21, 1, False, False, 128), (1, 64, 64, 3, False, False, 128), (2, 24, 40, 4, True, True, 320),
+                                                 (1, 64, 64, 4, False, False, 320)])
+def test_conv3x3_small_n_with_folded_groupnorm(ops, B, H, W, n, norm, silu, C):
     """sd_conv3x3_small_n_f16 (VAE decoder conv_norm_out + SiLU + conv_out in one pass) against GroupNorm -> SiLU -> conv2d in fp32:
     tiles ragged against the 16 x 16 workgroup tile, n = 1 / 3 / 4, with and without the folded GroupNorm; channels n..7 of every output
-    pixel are zero and channels >= 8 untouched."""
-    C, hw = 128, H * W
+    pixel are zero and channels >= 8 untouched.  C = 128 (VAE decoder) and C = 320 (UNet conv_out)."""
+    hw = H * W
     x = rnd(B * hw, C, seed=1) * 1.5 + 0.3
     w = rnd(n, 9, C, seed=2, scale=(9 * C) ** -0.5)
     b = rnd(n, seed=3)
@@ -689,7 +690,7 @@ def test_conv3x3_small_n_with_folded_groupnorm(ops, B, H, W, n, norm, silu):
     o = out.float().cpu()
     close(o[:, :n], ref)
     assert float(o[:, n:8].abs().max()) == 0.0 and bool((o[:, 8:] == 7.0).all())
-    with pytest.raises(Exception, match="128 input channels"):
+    with pytest.raises(Exception, match="128 and 320 input channels"):
         ops.conv3x3_small_n(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=64, n=n)
     with pytest.raises(Exception, match="bad shape"):
         ops.conv3x3_small_n(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=5)
