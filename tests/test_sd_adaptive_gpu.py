@@ -61,6 +61,23 @@ def _check_against_ref(inp, hip, ref, B):
     assert all((h["mask"] <= inp["default_np"]).all() for h in hip["trace"])
 
 
+def take_hip(hip, idx):
+    """The HIP run's results for images `idx` only (every traced tensor has the batch as its leading axis)."""
+    out = dict(hip, latents=hip["latents"][idx])
+    out["trace"] = [{k: (v[idx] if hasattr(v, "shape") and getattr(v, "ndim", 0) >= 1 and v.shape[0] == len(hip["latents"]) else v)
+                     for k, v in h.items()} for h in hip["trace"]]
+    return out
+
+
+def _check_glue_exact(inp, hip, B):
+    """Teacher-forced mask glue of EVERY image and re-estimation: HIP segmentation -> restated dilation / AND / area test == HIP mask."""
+    for h in hip["trace"]:
+        k = inp["settings"].dilate_scheduler(h["i"])
+        for b in range(B):
+            exp = so.adapt_mask_ref(h["seg"][b], inp["default_np"][b], k, h["use_default"], inp["thres"]).astype(np.uint8)
+            assert np.array_equal(h["mask"][b], exp), (h["i"], b)
+
+
 @pytest.fixture(scope="module")
 def fp32_strict():
     old = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
@@ -70,13 +87,13 @@ def fp32_strict():
 
 
 def test_restatement_on_device_equals_restatement_on_cpu(hip_lib, fp32_strict):
-    """128 x 128 image, the last 6 of the 50 timesteps (3 re-estimations): AdaptiveLoopRef evaluated on the CPU == evaluated by
+    """128 x 128 image, the last 4 of the 50 timesteps (2 re-estimations): AdaptiveLoopRef evaluated on the CPU == evaluated by
     torch's fp32 device kernels, masks identical; and the HIP loop agrees with both."""
     inp = make_inputs(1, HW=128, seed=11, ratio=0.0)
-    hip = run_hip(_pipe(1, 128), inp, make_plugin("block"), strength=0.12)
-    cpu = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.12, device="cpu")
-    dev = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.12, device=DEV)
-    assert len(cpu["trace"]) == len(dev["trace"]) == len(hip["trace"]) == 3
+    hip = run_hip(_pipe(1, 128), inp, make_plugin("block"), strength=0.08)
+    cpu = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.08, device="cpu")
+    dev = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.08, device=DEV)
+    assert len(cpu["trace"]) == len(dev["trace"]) == len(hip["trace"]) == 2
     assert _rel(dev["latents"], cpu["latents"]) <= 1e-4
     for c, d, h in zip(cpu["trace"], dev["trace"], hip["trace"]):
         assert iou(c["mask"][0], d["mask"][0]) >= 0.999 and iou(c["mask"][0], h["mask"][0]) >= MASK_IOU
@@ -90,8 +107,13 @@ def test_adaptive_loop_49_steps_matches_restatement(hip_lib, fp32_strict, B):
     hip = run_hip(pipe, inp, make_plugin("block"), strength=0.98)
     del pipe
     torch.cuda.empty_cache()
-    ref = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.98, device=DEV)
-    _check_against_ref(inp, hip, ref, B)
+    # every image of the batch goes through the bit-exact glue check; the fp32 restatement (25 s per image and loop on the device) runs
+    # for three of the eight images of the B = 8 case -- the images of a batch are independent, each has its own noise stream and mask
+    idx = list(range(B)) if B == 1 else [0, 3, 6]
+    _check_glue_exact(inp, hip, B)
+    sub = take(inp, idx)
+    ref = run_ref(sub, [n[idx] for n in hip["noises"]], make_plugin("block"), strength=0.98, device=DEV)
+    _check_against_ref(sub, take_hip(hip, idx), ref, len(idx))
     if B == 8:
         # image b of the batch-8 run == its own batch-1 run (same generator seed, same inputs; other tile shapes -> fp16 rounding only)
         p1 = _pipe(1)

@@ -63,22 +63,29 @@ def test_fixed_mask_loop_matches_fp32_restatement(hip_lib, B, IH, IW, steps):
     out = pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=steps,
                guidance_scale=guidance, latents=lat0, output_type="latent", use_adaptive_mask=False).images
     # fp32 restatement of the same loop with the pipeline's own masked-image latents (VAE parity is tested separately)
-    ustate = weights.random_state(weights.unet_shapes(), seed=0)
-    masked_lat = pipe._last_masked_lat.float().cpu().reshape(B, LH, LW, 4).permute(0, 3, 1, 2) if hasattr(pipe, "_last_masked_lat") else None
+    # the restatement is evaluated by torch's fp32 kernels on the device (12 s per UNet forward on the host cores); the CPU and device
+    # evaluations are tied by tests/test_sd_adaptive_gpu.py::test_restatement_on_device_equals_restatement_on_cpu
+    old_tf32 = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+    ustate = {k: v.to(DEV, torch.float32) for k, v in weights.random_state(weights.unet_shapes(), seed=0).items()}
+    masked_lat = pipe._last_masked_lat.float().reshape(B, LH, LW, 4).permute(0, 3, 1, 2) if hasattr(pipe, "_last_masked_lat") else None
     if masked_lat is None:
         pytest.skip("pipeline does not expose masked latents")
-    mask_lat = mask[:, :, ::8, ::8]
-    alphas = so.ddim_alphas()
-    x = lat0.clone().double()
-    ctx = torch.cat([ne, pe])
-    for t in so.ddim_timesteps(steps):
-        inp = torch.cat([x.float(), mask_lat, masked_lat], dim=1)
-        eps = so.unet_ref(ustate, torch.cat([inp, inp]), torch.full((2 * B,), float(t)), ctx, weights.UNET_CFG)
-        e = eps[:B] + guidance * (eps[B:] - eps[:B])
-        x, _ = so.ddim_step_ref(e, t, x, alphas, num_inference_steps=steps)
+    mask_lat = mask[:, :, ::8, ::8].to(DEV)
+    alphas = so.ddim_alphas().to(DEV)
+    x = lat0.clone().double().to(DEV)
+    ctx = torch.cat([ne, pe]).to(DEV)
+    with torch.no_grad():
+        for t in so.ddim_timesteps(steps):
+            inp = torch.cat([x.float(), mask_lat, masked_lat], dim=1)
+            eps = so.unet_ref(ustate, torch.cat([inp, inp]), torch.full((2 * B,), float(t), device=DEV), ctx, weights.UNET_CFG)
+            e = eps[:B] + guidance * (eps[B:] - eps[:B])
+            x, _ = so.ddim_step_ref(e, t, x, alphas, num_inference_steps=steps)
+    torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = old_tf32
+    x = x.cpu()
     rel = float((out.cpu().double() - x).norm() / x.norm())
     print(f"METRIC fixed-mask loop {steps} steps rel-L2 {rel:.3e}")
-    assert rel <= 5e-2, rel
+    assert rel <= 9e-3, rel                   # measured 4.0e-3 ... 4.3e-3 (profiles/r04_notes.md 3)
 
 
 def test_adaptive_loop_full_resolution(hip_lib):
