@@ -339,7 +339,6 @@ int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int ba
     return plan_record(r);
   }
   if (upsample != 0 && upsample != 1) return fail(COMA_E_INVALID, "sd_winograd_input_f16: upsample must be 0 or 1");
-  if (upsample && ((h & 3) || (w & 3))) return fail(COMA_E_INVALID, "sd_winograd_input_f16: upsample needs h, w multiples of 4 (an even source)");
   if (!x0 || !v) return fail(COMA_E_INVALID, "sd_winograd_input_f16: null pointer");
   if (c0 <= 0 || c0 % 8 || c1 < 0 || c1 % 8 || (c1 > 0 && !x1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: channel counts must be multiples of 8");
   if (batch <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: even h, w required");
