@@ -133,7 +133,7 @@ def bench_inpaint(args, dev, world, rank):
         gemm = [(fl, ms) for tag, fl, ms in prof if fam(tag)]
         exec_fl = sum(e for (tag, _), e in zip(pipe.unet.g.tags, pipe.unet.g.exec_tags) if fam(tag))
         n_gemm = sum(1 for tag, _, _ in prof if tag.startswith("gemm"))
-        alg_bytes = sum(b for (tag, _), b in zip(pipe.unet.g.tags, pipe.unet.g.alg_bytes) if fam(tag))
+        alg_bytes = sum(b for (tag, _), b in zip(pipe.unet.g.tags, pipe.unet.g.alg_bytes) if tag.startswith("gemm"))     # conv_gemm launches only, like `traffic`
         attn = [(fl, ms) for tag, fl, ms in prof if tag.startswith("attention")]
         tot_ms = sum(ms for _, _, ms in prof)
         g_fl, g_ms = sum(f for f, _ in gemm), sum(m for _, m in gemm)
