@@ -1,4 +1,7 @@
 #!/bin/bash
-python -m pytest tests/test_sd_ops_gpu.py -m gpu -q -k "winograd" 2>&1 | tail -3
-python -m pytest tests/test_sd_unet_gpu.py tests/test_sd_pipeline_gpu.py tests/test_sd_adaptive_gpu.py -m gpu -q --durations=14 -rP 2>&1 | grep -E "METRIC fixed|passed|failed|Error|s call|s setup" | head -30
-python bench.py --steps 3 --warmup 1 2>gpurun_out/bench_r4a.err | tail -1 > gpurun_out/bench_r4a.json; head -c 1500 gpurun_out/bench_r4a.json; echo; tail -3 gpurun_out/bench_r4a.err
+# r04 profiles: rocprofv3 kernel trace + PMC passes of the bench command, and the conv_gemm traffic of eager UNet forwards
+bash scripts/profile_gpu.sh inpaint --steps 2 --warmup 1 > gpurun_out/prof_inpaint.log 2>&1
+tail -40 gpurun_out/prof_inpaint.log
+bash scripts/pmc_cmd.sh unet_traffic "FETCH_SIZE" "WRITE_SIZE" -- python scripts/time_unet.py 16 3 --eager --shared > gpurun_out/pmc_unet_traffic.log 2>&1
+python scripts/unet_traffic.py gpurun_out/pmc_unet_traffic/summary.txt 4 > gpurun_out/unet_gemm_traffic.txt 2>&1
+cat gpurun_out/unet_gemm_traffic.txt
