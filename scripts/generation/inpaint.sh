@@ -2,11 +2,11 @@
 # Per-GPU fan-out of the inpainting stage (the reference's scripts/generation/inpaint.sh): one process per GPU, each taking
 # slice --parallel_idx of --parallel_num of the sorted work list; processes share nothing but the file system.
 # The accepted flags are the reference's explicit set (:72-196) -- anything else is an error, not forwarded -- plus the two
-# asset-provisioning additions of src/generation/inpaint.py.  Unset flags fall back to that module's constants (argparse
+# asset-provisioning additions of src/generation/inpaint.py and its --batch_size (images per pipeline call, default 8).  Unset flags fall back to that module's constants (argparse
 # defaults), which is what the reference's `python -c` preamble reads.
 set -e
 gpu_ids=(0 1 2 3 4 5 6 7)
-value_flags=" num_img_per_combination prompts_dir asset_render_dir asset_mask_dir asset_seg_dir save_dir ldm_model_key adaptive_mask_model_type default_cfg_scale default_strength default_ddim_steps default_pointrend_threshold default_enforce_full_mask_ratio default_human_detection_thres negative_prompt seed weights_dir mask_model "
+value_flags=" num_img_per_combination prompts_dir asset_render_dir asset_mask_dir asset_seg_dir save_dir ldm_model_key adaptive_mask_model_type default_cfg_scale default_strength default_ddim_steps default_pointrend_threshold default_enforce_full_mask_ratio default_human_detection_thres negative_prompt seed weights_dir mask_model batch_size "
 list_flags=" supercategories categories "
 bool_flags=" enable_sam_multitask_output enable_safety_checker use_visualizer verbose "
 args=()
