@@ -61,6 +61,9 @@ class HipUNet2DConditionModel:
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
         self.fuse_conv_out = os.environ.get("SD_FUSE_CONV_OUT", "1") != "0"       # conv_norm_out + SiLU + conv_out as one launch (A/B: 0)
         self.winograd_upsamplers = os.environ.get("SD_WINOGRAD_UP", "1") != "0"   # ... and the Upsample2D convolutions of those levels (A/B: 0)
+        # ... only for groups of >= 40 channels: a workgroup owns one (sample, group) slice, and with 20-channel groups (C = 640) its 40-byte
+        # pieces of every (plane, tile) row waste most of each memory transaction (48-114 us per launch at the 32 x 32 level)
+        self.gn_winograd_min_cg = int(os.environ.get("SD_GN_WINOGRAD_MIN_CG", 40))
         self.fuse_gn_winograd = os.environ.get("SD_GN_WINOGRAD", "1") != "0"     # GroupNorms folded into the Winograd transforms (A/B: 0)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
@@ -171,7 +174,8 @@ class HipUNet2DConditionModel:
         # deep levels: Winograd F(2x2,3x3), 2.25 x fewer MFMA flops where the transformed tensors stay in cache (profiles/r04_notes.md 1, 4);
         # with the GroupNorms folded into the transforms a block is five launches: [norm1 + B^T d B] -> planes -> [A^T m A + bias + temb,
         # norm2, B^T d B] -> planes -> [A^T m A + bias + shortcut]
-        fused_gn = wino and self.fuse_gn_winograd and H * W * (max(cin, cout) // 32) <= g.GN_WINO_MAX_SLICE and cin % 128 == 0 and cout % 128 == 0
+        fused_gn = (wino and self.fuse_gn_winograd and H * W * (max(cin, cout) // 32) <= g.GN_WINO_MAX_SLICE and cin % 128 == 0 and cout % 128 == 0
+                    and min(cin, cout) // 32 >= self.gn_winograd_min_cg)
         T = B * (H // 2) * (W // 2)
         if fused_gn:
             V1 = g.gn_winograd_input(s[p + ".norm1.weight"], s[p + ".norm1.bias"], batch=B, h=H, w=W, c0=c0, x0=x0, x1=x1, c1=c1, eps=1e-5)

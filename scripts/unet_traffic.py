@@ -5,7 +5,7 @@ kernel family, per forward and per launch (FETCH doubled as MI355X_MICROARCH.md 
 import re, sys
 fetch, write, n = {}, {}, {}
 for line in open(sys.argv[1]):
-    m = re.match(r"(void sd::conv_gemm_kernel<[^>]*?>?)\S*\s+\S*?\s*(FETCH_SIZE|WRITE_SIZE)\s+mean=(\S+)\s+n=(\d+)", line)   # (names may be cut off)
+    m = re.match(r"(void sd::conv_gemm_kernel<.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+mean=(\S+)\s+n=(\d+)", line)   # (names may be cut off)
     if m:
         (fetch if m.group(2) == "FETCH_SIZE" else write)[m.group(1)] = float(m.group(3))
         n[m.group(1)] = int(m.group(4))
