@@ -161,7 +161,7 @@ def bench_inpaint(args, dev, world, rank):
                          "algorithmic_bytes": alg_bytes / n_gemm, "algorithmic_bytes_what": "per launch, mean over the launch list: every input "
                          "activation, weight, bias / residual tile read once + the output written once (fp16)",
                          "traffic": UNET_GEMM_PMC_TRAFFIC_BYTES if B == 8 else None,
-                         "traffic_source": "profiles/r03_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
+                         "traffic_source": "profiles/r04_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
                                            "the launches of eager UNet forwards at batch 16 (fabric-side requests of the 8 L2s: "
                                            "weights are pulled once per XCD and mostly hit the Infinity Cache)",
                          "unet_forward_ms_eager_sum": tot_ms,
@@ -259,7 +259,7 @@ def bench_contact(args, dev, world, rank):
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                      "kernel_ms": kern_ms, "flop_per_pair": flop_per_pair(N), "algorithmic_hbm_bytes": alg_bytes,
                      "traffic": CONTACT_PMC_TRAFFIC_BYTES if (S, H, O, N) == (64, 10475, 180, 250) else None,
-                     "traffic_source": "profiles/r03_inpaint_pmc.txt (contact_accumulate_kernel): (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
+                     "traffic_source": "profiles/r04_inpaint_pmc.txt (contact_accumulate_kernel): (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
     }
 
 
@@ -389,16 +389,16 @@ def bench_occupancy(args, dev, world, rank):
 
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
-#   profiles/r03_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
-#   profiles/r03_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91545e6 KiB, WRITE_SIZE 3.71218e6 KiB per launch
-#   profiles/r03_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.12 GB, rowprep 2 * 0.21 + 0.23 GB,
+#   profiles/r04_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
+#   profiles/r04_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91545e6 KiB, WRITE_SIZE 3.71199e6 KiB per launch
+#   profiles/r04_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.12 GB, rowprep 2 * 0.21 + 0.23 GB,
 #                                        groupmax 0.06 GB
-UNET_GEMM_PMC_TRAFFIC_BYTES = int(162.64e6)
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(157.34e6)
 OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.96e9)   # fused 11.02 + 0.25, rowprep 0.42 + 0.23, groupmax 0.04 GB
-OCCUPANCY_PMC_SOURCE = ("profiles/r03_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
+OCCUPANCY_PMC_SOURCE = ("profiles/r04_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
                         "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "
                         "the grid written once + the incidences; the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
-CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91545e6 + 3.71218e6) * 1024)
+CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91545e6 + 3.71199e6) * 1024)
 
 
 def main():

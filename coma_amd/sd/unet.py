@@ -59,6 +59,7 @@ class HipUNet2DConditionModel:
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
+        self.winograd_min_batch = int(os.environ.get("SD_WINOGRAD_MIN_BATCH", 8))
         self.fuse_conv_out = os.environ.get("SD_FUSE_CONV_OUT", "1") != "0"       # conv_norm_out + SiLU + conv_out as one launch (A/B: 0)
         self.winograd_upsamplers = os.environ.get("SD_WINOGRAD_UP", "1") != "0"   # ... and the Upsample2D convolutions of those levels (A/B: 0)
         # ... only for groups of >= 40 channels: a workgroup owns one (sample, group) slice, and with 20-channel groups (C = 640) its 40-byte
@@ -145,7 +146,7 @@ class HipUNet2DConditionModel:
             if i < len(ch) - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 o = g.buf(B * 4 * H * W, cout)
-                if self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and self.winograd_upsamplers:
+                if self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and self.winograd_upsamplers and B >= self.winograd_min_batch:
                     # Upsample2D + conv at the deep levels: the input transform reads the nearest-x2 upsampling in place
                     g.conv3x3_winograd(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=2 * H, in_w=2 * W, c0=cout, n=cout, bias=s[p + ".bias"],
                                        upsample=True)
@@ -170,7 +171,8 @@ class HipUNet2DConditionModel:
         g, s, B = self.g, self.s, self._B
         M, cin = B * H * W, c0 + c1
         off = self._tb_off[p]
-        wino = self.winograd_max_h and max(H, W) <= self.winograd_max_h and H % 2 == 0 and W % 2 == 0 and min(cin, cout) >= 640
+        # (not below UNet batch 8: at batch 2 -- one image per call -- the plane products are a few tiles each and the direct form is 0.7 % faster)
+        wino = self.winograd_max_h and max(H, W) <= self.winograd_max_h and H % 2 == 0 and W % 2 == 0 and min(cin, cout) >= 640 and B >= self.winograd_min_batch
         # deep levels: Winograd F(2x2,3x3), 2.25 x fewer MFMA flops where the transformed tensors stay in cache (profiles/r04_notes.md 1, 4);
         # with the GroupNorms folded into the transforms a block is five launches: [norm1 + B^T d B] -> planes -> [A^T m A + bias + temb,
         # norm2, B^T d B] -> planes -> [A^T m A + bias + shortcut]

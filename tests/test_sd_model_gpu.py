@@ -197,3 +197,47 @@ def test_model_file_is_verified_before_it_is_trusted(tmp_path, hip_lib):
         bad.write_bytes(data)
         with pytest.raises(ComaHipError, match="truncated|checksum|not a model file"):
             SdModel.load(bad, DEV)
+
+
+def test_winograd_and_small_n_records_survive_save_and_load(tmp_path, hip_lib):
+    """The r4 entry points are recordable: a plan of [GroupNorm + Winograd input transform] -> 16 plane products -> output transform ->
+    [GroupNorm table + SiLU + 3x3 convolution with 3 output channels] is saved with its constants (the transformed weights U = G g G^T are
+    computed outside the plan and must be registered as persistent when first recorded), loaded into a fresh model and replayed there:
+    same bits."""
+    import ctypes
+    from coma_amd import _lib
+    from coma_amd.sd.graph import LaunchGraph
+    from coma_amd.sd.model import SdModel
+    g = LaunchGraph(DEV, plan="p")
+    B, H, W, C, n = 2, 8, 8, 128, 128
+    gen = torch.Generator().manual_seed(4)
+    r = lambda *s, k=1.0: (torch.randn(*s, generator=gen) * k).half().to(DEV)
+    x, out, img = g.buf(B * H * W, C), g.buf(B * H * W, n), g.buf(B * H * W, 64, zero=True)
+    w9, b9 = r(n, 9 * C, k=(9 * C) ** -0.5), r(n)
+    ga, be, ga2, be2 = r(C, k=0.2) + 1, r(C, k=0.2), r(n, k=0.2) + 1, r(n, k=0.2)
+    w3, b3 = r(3, 9 * n, k=(9 * n) ** -0.5), r(3)
+    V = g.gn_winograd_input(ga, be, batch=B, h=H, w=W, c0=C, x0=x, eps=1e-5)
+    P = g.winograd_planes(V, g.winograd_weight(w9, n=n, c=C), tiles=B * (H // 2) * (W // 2), c=C, n=n)
+    g.winograd_output(P, out, batch=B, h=H, w=W, n=n, bias=b9)
+    g.gn_silu_conv3x3_small_n(out, ga2, be2, w3, b3, img, batch=B, h=H, w_=W, c=n, n=3, eps=1e-6)
+    g.model.bind("x", x)
+    g.model.bind("img", img)
+    xin = r(B * H * W, C)
+    x.copy_(xin)
+    g.replay()                                               # records, runs eagerly, builds the hipGraph
+    g.replay()                                               # graph launch
+    torch.cuda.synchronize()
+    want = img.clone()
+    assert float(want[:, :3].float().abs().max()) > 0 and float(want[:, 3:].float().abs().max()) == 0.0
+    path = tmp_path / "w.sdm"
+    g.model.save(path)
+    m2 = SdModel.load(path, DEV)
+    assert m2.num_launches("p") == g.model.num_launches("p") >= 5
+    px, nx = m2.binding("x")
+    pi, ni = m2.binding("img")
+    _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(px), ctypes.c_void_p(xin.data_ptr()), nx, _lib.stream_ptr(xin.device)), "copy")
+    m2.replay("p")
+    got = torch.empty_like(want)
+    _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(got.data_ptr()), ctypes.c_void_p(pi), ni, _lib.stream_ptr(got.device)), "copy")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -190,10 +190,14 @@ def test_row_tile_fusions_agree_with_the_unfused_graph(setup):
         assert rel <= REL_L2 and cos >= COS, (rel, cos)
 
 
-def test_unet_ragged_resolution_matches_fp32_reference(setup):
+@pytest.mark.parametrize("winograd_min_batch", [8, 2])
+def test_unet_ragged_resolution_matches_fp32_reference(setup, monkeypatch, winograd_min_batch):
     """A latent that is neither square nor a multiple of 64 tokens anywhere (24 x 40 -> 12 x 20 -> 6 x 10 -> 3 x 5: attention over
     960 / 240 / 60 / 15 tokens, GEMMs with M = 30 ... 1920 rows): every ragged-edge path of the kernels (partial tiles, key padding,
-    small GroupNorms) and the fall-back of the row-tile fusions, against the fp32 reference."""
+    small GroupNorms) and the fall-back of the row-tile fusions, against the fp32 reference.  Second case: the Winograd path of the deep
+    ResNet levels forced on at this batch of 2 (the rule keeps it for UNet batches >= 8): odd tile grids (6 x 10, 3 x 5 tiles), the unfused
+    GroupNorm chain where a group slice does not fit, the upsampler transform over an odd source."""
+    monkeypatch.setenv("SD_WINOGRAD_MIN_BATCH", str(winograd_min_batch))
     state, _, _, _, _, UNet = setup
     from coma_amd.sd import weights
     B, h, w = 2, 24, 40
@@ -202,6 +206,7 @@ def test_unet_ragged_resolution_matches_fp32_reference(setup):
     ctx = torch.randn(B, 77, 768, generator=g).half().float()
     t = torch.tensor([741.0, 41.0])
     unet = UNet(state, batch=B, height=h, width=w, device=DEV, use_graph=True)
+    assert any("winograd" in tag for tag, _ in unet.g.tags) == (winograd_min_batch == 2)
     out = unet(sample.to(DEV), t.to(DEV), encoder_hidden_states=ctx.to(DEV), return_dict=False)[0]
     assert tuple(out.shape) == (B, 4, h, w)
     ref = so.unet_ref(state, sample, t, ctx, weights.UNET_CFG)
