@@ -126,6 +126,8 @@ static int launch(const PlanRec& r, void* st) {
     case PK_GN_WINO_IN:
       return sd_gn_winograd_input_f16(p[0], p[1], (int)i[0], (int)i[1], p[2], (int)i[2], p[3], p[4], (int)i[3], (int)i[4], (int)i[5], (int)i[6],
                                       (int)i[7], (float)f[0], p[5], p[6], (int)i[8], p[7], st);
+    case PK_IM2COL_C3:
+      return sd_im2col3x3_c3_f16(p[0], (int)i[0], (int)i[1], (int)i[2], (int)i[3], p[1], st);
     case PK_COPY:
       return sd_copy_d2d(p[0], p[1], (size_t)i[0], st);
     default:

@@ -151,6 +151,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_n_kernel(const _Float16*
   }
 }
 
+
+// ---- the other end: a 3x3 convolution with 3 INPUT channels (the VAE encoder's conv_in, 3 -> 128 at 512 x 512; self.vae.encode,
+// utils/adaptive_mask_inpainting.py:677-680).  Through the implicit GEMM it multiplied a 64-channel padded input (K = 576 for 27 real
+// products per output).  Here one elementwise pass packs every pixel's 3 x 3 x 3 neighbourhood into 32 halfs (k = 3 * tap + channel, 5
+// zeros) and the convolution becomes a plain K = 32 product of the existing GEMM.
+typedef _Float16 half4s __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void im2col3x3_c3_kernel(const _Float16* __restrict__ x, int ldx, int batch, int H, int W,
+                                                          _Float16* __restrict__ out) {
+  const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= (long long)batch * H * W) return;
+  const int xx = (int)(m % W), y = (int)((m / W) % H);
+  const long long b = m / ((long long)W * H);
+  _Float16 v[32];
+#pragma unroll
+  for (int k = 27; k < 32; ++k) v[k] = (_Float16)0.0f;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int yy = y + tap / 3 - 1, xc = xx + tap % 3 - 1;
+    half4s q = {0, 0, 0, 0};
+    if (yy >= 0 && yy < H && xc >= 0 && xc < W) q = *reinterpret_cast<const half4s*>(x + ((b * H + yy) * W + xc) * ldx);
+    v[3 * tap + 0] = q[0]; v[3 * tap + 1] = q[1]; v[3 * tap + 2] = q[2];
+  }
+  half8* o = reinterpret_cast<half8*>(out + m * 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    half8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = v[8 * j + e];
+    o[j] = t;
+  }
+}
+
 }  // namespace sc
 }  // namespace sd
 
@@ -177,4 +209,21 @@ extern "C" int sd_conv3x3_small_n_f16(const void* x, const float* gn_affine, int
     hipLaunchKernelGGL(conv3x3_small_n_kernel<320>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, gn_affine, silu,
                        (const _Float16*)w, (const _Float16*)bias, n, h, w_, (_Float16*)out, ldo);
   return check_launch("conv3x3_small_n_kernel");
+}
+
+extern "C" int sd_im2col3x3_c3_f16(const void* x, int ldx, int batch, int h, int w_, void* out, void* stream) {
+  using namespace sd::sc;
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_IM2COL_C3;
+    r.p[0] = (void*)x; r.p[1] = out; r.i[0] = ldx; r.i[1] = batch; r.i[2] = h; r.i[3] = w_;
+    return sd::plan_record(r);
+  }
+  if (!x || !out) return fail(COMA_E_INVALID, "sd_im2col3x3_c3_f16: null pointer");
+  if (ldx < 4 || ldx % 4 || batch <= 0 || h <= 0 || w_ <= 0) return fail(COMA_E_INVALID, "sd_im2col3x3_c3_f16: bad shape ldx=%d batch=%d h=%d w=%d", ldx, batch, h, w_);
+  const long long M = (long long)batch * h * w_;
+  if (M > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_im2col3x3_c3_f16: too many pixels");
+  hipLaunchKernelGGL(im2col3x3_c3_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, ldx, batch, h, w_,
+                     (_Float16*)out);
+  return check_launch("im2col3x3_c3_kernel");
 }

@@ -68,6 +68,7 @@ class LaunchGraph:
         # GroupNorm statistics of the consumer come for free from the epilogue of large, never-split GEMMs
         M = batch * oh * ow
         alg_flops = kw.pop("alg_flops", None)
+        tag_note = kw.pop("tag_note", "")
         if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= 16384 and M % 32 == 0:
             cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
             kw["colstats"] = cs
@@ -84,7 +85,7 @@ class LaunchGraph:
                  nbytes=2 * (z * batch * in_h * in_w * (c0 + c1) + (z if kw.get("stride_w") else 1) * n * taps * (c0 + c1)
                              + z * M * (n // 2 if kw.get("epi", 0) & ops.EPI_GEGLU else n) * (2 if kw.get("res") is not None else 1)
                              + (n if kw.get("bias") is not None else 0) + (batch * n if kw.get("bias_bn") is not None else 0)),
-                 tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}" + (" (winograd planes)" if alg_flops else ""))
+                 tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}" + tag_note)
         return out
 
     # ---- Winograd F(2x2,3x3) for the deep ResNet levels (profiles/r04_notes.md 1, 4): input transform -> 16 plane products (the 1x1 GEMM
@@ -99,7 +100,7 @@ class LaunchGraph:
     def winograd_planes(self, V, U, *, tiles, c, n):
         P = self.buf(16, tiles, n)
         self.conv(V, U, P, batch=tiles, in_h=1, in_w=1, c0=c, n=n, nbatch_z=16, stride_a=tiles * c, stride_w=n * c, stride_out=tiles * n,
-                  alg_flops=2 * 9 * (4 * tiles) * n * c)            # the 3x3 convolution these 16 products compute
+                  alg_flops=2 * 9 * (4 * tiles) * n * c, tag_note=" (winograd planes)")      # counted as the 3x3 convolution these 16 products compute
         return P
 
     def winograd_input(self, a0, *, batch, h, w, c0, a1=None, c1=0, upsample=False):

@@ -288,3 +288,9 @@ def gn_winograd_input(v, gamma, beta, *, batch, h, w, c0, x0=None, x1=None, c1=0
                                              ldbb, batch, h, w, groups, eps, _p(gamma), _p(beta), 1 if silu else 0, _p(v, "v"), _stream(v))
     _lib.check(rc, "sd_gn_winograd_input_f16")
     return v
+
+
+def im2col3x3_c3(x, out, *, batch, h, w, ldx):
+    """out[m][3 * tap + ch] = the 3x3x3 neighbourhood of pixel m of a 3-channel NHWC image (zero pad; columns 27..31 zero)."""
+    _lib.check(_lib.lib().sd_im2col3x3_c3_f16(_p(x, "x"), ldx, batch, h, w, _p(out, "out"), _stream(out)), "sd_im2col3x3_c3_f16")
+    return out

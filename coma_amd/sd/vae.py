@@ -20,6 +20,7 @@ class _Cfg(dict):
 
 
 class _VaeBase:
+    packed_conv_in = True        # class-level switch (tests / A-B): False = encoder conv_in as a K = 576 implicit GEMM over the 64-channel padded input
     fused_conv_out = True        # class-level switch (tests / A-B): False = GroupNorm kernel + 64-column implicit-GEMM tile for conv_out
     fused_attention = True       # class-level switch (tests / A-B): False = QK^T GEMM -> softmax -> PV GEMM through memory
 
@@ -153,8 +154,16 @@ class HipVaeEncoder(_VaeBase):
         H, W = height, width
         self.x = g.buf(B, H * W, 64, zero=True)
         x = g.buf(B * H * W, ch[0])
-        g.conv(self.x, conv_weight(s["encoder.conv_in.weight"], cin_pad=64), x, batch=B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9,
-               bias=s["encoder.conv_in.bias"])
+        if self.packed_conv_in and s["encoder.conv_in.weight"].shape[1] == 3:
+            # 3 input channels: one elementwise pass packs every pixel's 3x3x3 neighbourhood into 32 halfs and conv_in is a plain K = 32 product
+            # (the implicit GEMM multiplied a 64-channel padded input: K = 576 for 27 real products)
+            xp = g.buf(B * H * W, 32)
+            g.add(lambda: ops.im2col3x3_c3(self.x, xp, batch=B, h=H, w=W, ldx=64), tag=f"im2col 3x3x3 B={B} {H}x{W}", nbytes=2 * B * H * W * (4 + 32))
+            w27 = torch.nn.functional.pad(conv_weight(s["encoder.conv_in.weight"]), (0, 5)).contiguous()       # [n][ky][kx][c] -> [n][32]
+            g.conv(xp, w27, x, batch=B * H * W, in_h=1, in_w=1, c0=32, n=ch[0], bias=s["encoder.conv_in.bias"], alg_flops=2 * B * H * W * ch[0] * 27, tag_note=" (conv_in, packed 3x3x3)")
+        else:
+            g.conv(self.x, conv_weight(s["encoder.conv_in.weight"], cin_pad=64), x, batch=B, in_h=H, in_w=W, c0=64, n=ch[0], taps=9,
+                   bias=s["encoder.conv_in.bias"])
         cin = ch[0]
         for i, cout in enumerate(ch):
             for j in range(cfg["layers_per_block"]):

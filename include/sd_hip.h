@@ -223,6 +223,13 @@ int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, con
 int sd_conv3x3_small_n_f16(const void* x, const float* gn_affine, int silu, const void* w, const void* bias, int batch, int h, int w_,
                            int c, int n, void* out, int ldo, void* stream);
 
+/* 3x3 / stride 1 / pad 1 neighbourhoods of a 3-channel image as rows of 32 halfs: out[m][3 * tap + ch] = x[pixel m shifted by tap][ch]
+ * (tap = 3 * ky + kx, zero padding, columns 27..31 zero), so that a convolution with 3 input channels is a plain K = 32 product
+ * (sd_conv_gemm_f16 with weights [n][32] = [n][ky][kx][c] padded).  x fp16 NHWC [batch, h, w, ldx] (channels 0..2 read, ldx % 4 == 0),
+ * out fp16 [batch*h*w][32].  Recordable.
+ * replaces: the im2col half of encoder.conv_in of AutoencoderKL (self.vae.encode, utils/adaptive_mask_inpainting.py:677-680). */
+int sd_im2col3x3_c3_f16(const void* x, int ldx, int batch, int h, int w_, void* out, void* stream);
+
 /* Row softmax in place over fp16 [rows, n] with scale (VAE mid-block attention, un-fused). */
 int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream);
 

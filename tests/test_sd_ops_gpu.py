@@ -811,3 +811,27 @@ def test_winograd_on_the_nearest_upsampled_input(ops, B, H, W, C, n):
     close(out, so.conv_ref(x, w, batch=B, h=H, w_=W, taps=9, upsample=True, bias=b), tol=4e-3)
     with pytest.raises(Exception, match="even h, w"):
         ops.winograd_input(x.to(DEV), V, batch=B, h=2 * H + 1, w=2 * W, c0=C, upsample=True)
+
+
+@pytest.mark.parametrize("B,H,W,n", [(2, 16, 24, 128), (1, 7, 5, 64)])
+def test_conv3x3_with_three_input_channels_as_a_packed_k32_product(ops, B, H, W, n):
+    """sd_im2col3x3_c3_f16 + a K = 32 product (the VAE encoder's conv_in) against conv2d in fp32; the packed rows hold exactly the
+    neighbourhood (bit-exact gather, zeros in the pad columns and outside the image)."""
+    M = B * H * W
+    x = torch.zeros(M, 64, dtype=F16)
+    x[:, :3] = rnd(M, 3, seed=1)
+    x[:, 3:8] = 9.0                                              # channels >= 3 must be ignored
+    w = rnd(n, 3, 3, 3, seed=2, scale=27 ** -0.5)                # [n][c][ky][kx] as torch stores it
+    b = rnd(n, seed=3)
+    xp = torch.empty(M, 32, dtype=F16, device=DEV)
+    ops.im2col3x3_c3(x.to(DEV), xp, batch=B, h=H, w=W, ldx=64)
+    img = x[:, :3].float().reshape(B, H, W, 3)
+    pad = torch.nn.functional.pad(img, (0, 0, 1, 1, 1, 1))
+    ref_rows = torch.stack([pad[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).reshape(M, 27)
+    got = xp.float().cpu()
+    assert torch.equal(got[:, :27], ref_rows) and float(got[:, 27:].abs().max()) == 0.0
+    w27 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(n, 27), (0, 5)).contiguous()
+    out = torch.empty(M, n, dtype=F16, device=DEV)
+    ops.conv_gemm(xp, w27.to(DEV), out, batch=M, in_h=1, in_w=1, c0=32, n=n, bias=b.to(DEV))
+    ref = torch.nn.functional.conv2d(img.permute(0, 3, 1, 2), w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(M, n)
+    close(out, ref)
