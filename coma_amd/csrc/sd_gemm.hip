@@ -76,7 +76,18 @@ struct GemmArgs {
   float* rowstats;            // producer side: [N/32][M][2] per-row (sum, sum of squares) of every stored 32-column tile
   _Float16* out_t;            // optional: columns >= n_split leave transposed per sample, keys in the PERM16 order (sd_conv_gemm_desc.out_t)
   int n_split, ldo_t, rps;
+  // Sub-pixel phase of `conv3x3(nearest-upsample-x2(x))` (sd_conv_gemm_desc.phase): taps = 4 is a 2 x 2 window over the SOURCE whose origin
+  // is (y - pad, x - pad_x), and row m = (b, y, x) of the product is output pixel (2 y + a, 2 x + b): row 2 m + 2 W floor(m / W) + a 2 W + b
+  // of `out` (W = in_w, a power of two).  kw = taps per window row (3, or 2 in phase mode).
+  int kw, pad_x;
+  int phase;                  // 0: off; 1 + 2 a + b otherwise
+  int ph_wshift, ph_rowoff;   // log2(in_w); a * 2 W + b
 };
+
+// output row of product row `m` (identity unless this launch is a sub-pixel phase)
+__device__ __forceinline__ long long out_row(const GemmArgs& g, int m) {
+  return g.phase ? 2LL * m + ((long long)(m >> g.ph_wshift) << (g.ph_wshift + 1)) + g.ph_rowoff : (long long)m;
+}
 
 __device__ __forceinline__ void dbg_stamp(const GemmArgs& g, int slot) {
   if (g.dbg && blockIdx.y == 0 && blockIdx.x < DBG_BLOCKS && threadIdx.x == 0) g.dbg[blockIdx.x * 4 + slot] = __builtin_readcyclecounter();
@@ -283,7 +294,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
         const int rl = it / CH, c = it % CH;
         const int row = m0 + wr * (TM * 32) + rl;
         const half8 o = *reinterpret_cast<const half8*>(gs + rl * GST + c * 8);
-        if (row < g.M) *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + ocolw + c * 8) = o;
+        if (row < g.M) *reinterpret_cast<half8*>(outp + out_row(g, row) * g.ldo + ocolw + c * 8) = o;
       }
     }
     return;
@@ -302,11 +313,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
     const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
   };
-  const bool fast = vec_ok && (long long)(g.M + 512) * g.ldo * 2 < 0x7fffffffLL &&
+  const bool fast = vec_ok && (long long)(g.M + 512) * g.ldo * 2 * (g.phase ? 4 : 1) < 0x7fffffffLL &&
                     (!resp || (long long)(g.M + 512) * g.ldr * 2 < 0x7fffffffLL) && !(g.bias_bn && resp);
   if (fast) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t out_rsrc = rsrc_of(outp, (long long)g.M * g.ldo * 2);
+    const __amdgpu_buffer_rsrc_t out_rsrc = rsrc_of(outp, (long long)g.M * g.ldo * 2 * (g.phase ? 4 : 1));
     const __amdgpu_buffer_rsrc_t pre_rsrc = resp ? rsrc_of(resp, (long long)g.M * g.ldr * 2)
                                                  : rsrc_of(g.bias_bn ? g.bias_bn : g.out, g.bias_bn ? 0x7fffffffLL : 0);
     const int colbase = n0 + wc * (TN * 32) + cl;
@@ -317,6 +328,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
     for (int k = 0; k < 2; ++k) {
       voff_out[k] = ((rowbase + 16 * k) * g.ldo + colbase) * 2;
       voff_pre[k] = ((rowbase + 16 * k) * ld_pre + colbase) * 2;
+    }
+    int voff_ph[TM][2];                                          // sub-pixel phase: the rows of a tile are not equally spaced in `out`
+    const bool phase_on = !LNX && g.phase != 0;                  // (never with a folded LayerNorm: those variants have no register to spare)
+    if (phase_on) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int row = rowbase + 16 * k + 32 * i;
+          voff_ph[i][k] = row < g.M ? (int)((out_row(g, row) * g.ldo + colbase) * 2) : (int)0x80000000;
+        }
     }
     float2 lnrow[TM][2];                                         // folded LayerNorm: (mean, rstd) of this lane's rows (j-invariant)
     if (LNX && lnst && !(g.epi & SD_EPI_BIAS_ROWS)) {
@@ -416,7 +438,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
           half8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rsrc, oob ? (int)0x80000000 : voff_out[k], soff_out, 0);
+          if (phase_on) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rsrc, oob ? (int)0x80000000 : voff_ph[i][k], j * 64, 0);
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rsrc, oob ? (int)0x80000000 : voff_out[k], soff_out, 0);
           if (LNX && g.rowstats) {
             // statistics of the consumer's LayerNorm: (sum, sum of squares) of this row over the 32 columns of the tile, from
             // the stored (fp16-rounded) values; the four lanes of a row fold by two quad permutes, lane & 3 == 0 writes
@@ -462,7 +485,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
               cq[e] += __shfl_xor(cq[e], mask);
             }
           if (lane < 4 && !oob) {
-            float* dst = g.colstats + (long long)((m0 + wr * (TM * 32) + i * 32) >> 5) * 2 * g.N + colbase + j * 32;
+            int slot = (m0 + wr * (TM * 32) + i * 32) >> 5;
+            if (g.phase) {               // the consumer's GroupNorm sums the slots of a sample in any order: phase p of sample b owns
+              const int per = g.rows_per_batch >> 5, b = slot / per;     // slots [4 b per + p per, 4 b per + (p + 1) per)
+              slot = (4 * b + g.phase - 1) * per + (slot - b * per);
+            }
+            float* dst = g.colstats + (long long)slot * 2 * g.N + colbase + j * 32;
             *reinterpret_cast<float4*>(dst) = make_float4(cs[0], cs[1], cs[2], cs[3]);
             *reinterpret_cast<float4*>(dst + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
             *reinterpret_cast<float4*>(dst + g.N) = make_float4(cq[0], cq[1], cq[2], cq[3]);
@@ -525,11 +553,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
           half8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
-          *reinterpret_cast<half8*>(outp + (long long)row * g.ldo + col) = o;
+          *reinterpret_cast<half8*>(outp + out_row(g, row) * g.ldo + col) = o;
         } else {
           for (int e = 0; e < 8; ++e)
             if (col + e < g.N)
-              outp[(long long)row * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp, lnst);
+              outp[out_row(g, row) * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp, lnst);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -629,7 +657,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
     const int rem = mm - a_n[j] * g.rows_per_batch;
     const int oy = rem / g.out_w;
     const int y = ok ? oy * g.stride - g.pad : -16384;
-    const int x = (rem - oy * g.out_w) * g.stride - g.pad;
+    const int x = (rem - oy * g.out_w) * g.stride - g.pad_x;
     a_yx[j] = (y << 16) | (x & 0xffff);
   }
   unsigned b_off[B_LD];               // byte offset of (weight row, swizzled chunk); rows >= N re-read row N-1 (never stored)
@@ -671,8 +699,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   unsigned a_off[A_LD];
   unsigned a_base[A_LD];              // tap-minor: byte offset of tap (0,0) in the current source (may wrap below zero)
   auto repoint = [&]() {
-    const int ky = g.taps == 9 ? ld_tap / 3 : 0;
-    const int kx = g.taps == 9 ? ld_tap - ky * 3 : 0;
+    const int ky = g.taps == 9 ? ld_tap / 3 : (g.taps == 4 ? ld_tap >> 1 : 0);      // (constant divisors: no runtime division in the K loop)
+    const int kx = g.taps == 9 ? ld_tap - ky * 3 : (g.taps == 4 ? ld_tap & 1 : 0);
     ld_src = __builtin_amdgcn_readfirstlane(ld_ci >= g.c0 ? 1 : 0);
     const int csrc2 = (ld_src ? g.c1 : g.c0) * 2;
 #pragma unroll
@@ -941,7 +969,8 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
     for (int k = 0; k < 23; ++k) r.i[k] = is[k];
     if (d.out_t && (d.n_split < 0 || d.n_split >= (1 << 20) || d.ldo_t < 0 || d.ldo_t >= (1 << 20) || d.rows_per_sample < 0 || d.rows_per_sample >= (1 << 20)))
       return sd::fail(COMA_E_INVALID, "sd_conv_gemm_f16: out_t sizes out of range");
-    r.i[23] = (int64_t)d.n_split | ((int64_t)d.ldo_t << 20) | ((int64_t)d.rows_per_sample << 40);    // three 20-bit fields
+    if (d.phase < 0 || d.phase > 4) return sd::fail(COMA_E_INVALID, "sd_conv_gemm_f16: phase must be 0..4");
+    r.i[23] = (int64_t)d.n_split | ((int64_t)d.ldo_t << 20) | ((int64_t)d.rows_per_sample << 40) | ((int64_t)d.phase << 60);    // three 20-bit fields + the phase
     return sd::plan_record(r);
   }
   if (!d_in) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
@@ -972,9 +1001,29 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
     for (const Force& f : forced)
       if (f.n == d_in->n && f.k == d_in->taps * (d_in->c0 + d_in->c1)) d_copy.epi |= f.mask;
   }
+  // a plain product with more than 65536 rows given as batch x 1 x 1: the kernel keeps the sample index in 16 bits, so fold a power of
+  // two of the rows into the "image" (same row order; not with a per-sample bias, whose index is the sample)
+  if (d_copy.taps == 1 && d_copy.in_h == 1 && d_copy.in_w == 1 && d_copy.out_h == 1 && d_copy.out_w == 1 && d_copy.batch > 65536 && !d_copy.bias_bn &&
+      !d_copy.out_t) {
+    int f = 1;
+    while (d_copy.batch / f > 65536 && (d_copy.batch % (2 * f)) == 0 && f < 32768) f *= 2;
+    d_copy.batch /= f; d_copy.in_w = d_copy.out_w = f;
+  }
   const sd_conv_gemm_desc* d = &d_copy;
   if (!d->a0 || !d->w || !d->out) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null pointer");
-  if (d->taps != 1 && d->taps != 9) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: taps must be 1 or 9");
+  const int phase = d->phase;
+  if (phase < 0 || phase > 4) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: phase must be 0..4");
+  if (phase) {
+    // sub-pixel phase of conv3x3(nearest-upsample-x2(x)): a 2 x 2 window over the source, rows scattered to the output pixels of that parity
+    if (d->taps != 4 || d->stride != 1 || d->upsample || d->out_h != d->in_h || d->out_w != d->in_w || (d->in_w & (d->in_w - 1)) ||
+        (d->nbatch_z > 1) || d->res || d->bias_bn || d->rowstats || d->ln_stats || d->out_t || (d->epi & ~SD_EPI_TUNING_MASK) || d->n % 8 ||
+        (d->ldo > 0 && d->ldo % 8))
+      return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a phase launch needs taps = 4, stride 1, out = in size, in_w a power of two, n %% 8 == 0 and "
+                                  "a plain epilogue (bias, optional colstats)");
+    const long long ldo_eff = d->ldo > 0 ? d->ldo : d->n;
+    if ((4LL * d->batch * d->in_h * d->in_w + 2048) * ldo_eff * 2 >= 0x7fffffffLL)
+      return fail(COMA_E_INVALID, "sd_conv_gemm_f16: the output of a phase launch must stay below 2 GiB");
+  } else if (d->taps != 1 && d->taps != 9) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: taps must be 1 or 9 (4 only with a phase)");
   if (d->stride != 1 && d->stride != 2) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: stride must be 1 or 2");
   if (d->c0 <= 0 || d->c0 % BKMIN || d->c1 < 0 || d->c1 % BKMIN || (d->c1 > 0 && !d->a1))
     return fail(COMA_E_INVALID, "sd_conv_gemm_f16: source channels must be multiples of %d (c0=%d c1=%d)", BKMIN, d->c0, d->c1);
@@ -988,11 +1037,20 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   g.a0 = (const _Float16*)d->a0; g.a1 = (const _Float16*)d->a1; g.c0 = d->c0; g.c1 = d->c1;
   g.in_h = d->in_h; g.in_w = d->in_w; g.out_h = d->out_h; g.out_w = d->out_w;
   g.taps = d->taps; g.stride = d->stride; g.upsample = d->upsample; g.pad = d->taps == 9 ? d->pad : 0;
+  g.kw = 3; g.pad_x = g.pad; g.phase = phase; g.ph_wshift = 0; g.ph_rowoff = 0;
+  if (phase) {
+    const int pa = (phase - 1) >> 1, pb = (phase - 1) & 1;
+    g.kw = 2; g.pad = 1 - pa; g.pad_x = 1 - pb;                  // window rows y - 1 + a, y + a; columns x - 1 + b, x + b
+    while ((1 << g.ph_wshift) < d->in_w) ++g.ph_wshift;
+    g.ph_rowoff = pa * 2 * d->in_w + pb;
+  }
   g.ldbb = d->ldbb > 0 ? d->ldbb : d->n;
   g.rows_per_batch = d->out_h * d->out_w;
   long long M = (long long)d->batch * g.rows_per_batch;
   if (M > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: M too large");
-  if (d->taps == 9 && d->batch > 65535) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a 3x3 convolution takes at most 65535 samples per launch");
+  if (d->batch > 65536) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: at most 65536 samples per launch (the kernel keeps the sample index in 16 bits): "
+                                    "pass a large row count as batch x in_h x in_w");
+  if (d->taps != 1 && d->batch > 65535) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a 3x3 convolution takes at most 65535 samples per launch");
   // the LDS-DMA addresses rows with 32-bit byte offsets from the tensor base (bit 31 marks zero padding)
   const long long a_bytes = (long long)d->batch * d->in_h * d->in_w * (d->c0 > d->c1 ? d->c0 : d->c1) * 2;
   const long long w_bytes = (long long)d->n * d->taps * (d->c0 + d->c1) * 2;
@@ -1094,7 +1152,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
-  if (!g.colstats && !g.rowstats && !g.out_t && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
+  if (!phase && !g.colstats && !g.rowstats && !g.out_t && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((mid8 ? 256 : 512) / blocks);         // the 8-wave 128 x 320 tile is resident once per CU, the others twice
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;

@@ -84,6 +84,7 @@ static int launch(const PlanRec& r, void* st) {
       d.ldr = (int)i[13]; d.ldo = (int)i[14]; d.epi = (int)i[15]; d.nbatch_z = (int)i[16]; d.stride_a = i[17]; d.stride_w = i[18];
       d.stride_out = i[19]; d.stride_res = i[20]; d.workspace_bytes = (size_t)i[21]; d.stride_ln_stats = i[22];
       d.out_t = p[12]; d.n_split = (int)(i[23] & 0xfffff); d.ldo_t = (int)((i[23] >> 20) & 0xfffff); d.rows_per_sample = (int)((i[23] >> 40) & 0xfffff);
+      d.phase = (int)((i[23] >> 60) & 7);
       return sd_conv_gemm_f16(&d, st);
     }
     case PK_GN:

@@ -88,6 +88,23 @@ class LaunchGraph:
                  tag=f"gemm M={batch * oh * ow} N={n} K={taps * (c0 + c1)} taps={taps} z={z}" + tag_note)
         return out
 
+    def conv3x3_upsampled(self, a0, w_raw, out, *, batch, in_h, in_w, c0, n, bias=None, stats=False):
+        """diffusers Upsample2D: conv3x3(nearest-upsample-x2(a0)) as FOUR sub-pixel phase products over the source (sd_conv_gemm_desc.phase):
+        16 multiplies per output 2 x 2 block instead of 36, exact (the folded weights are sums of the 3x3 taps), no transformed tensors.
+        w_raw: the torch-layout weight [n, c0, 3, 3]; out: [batch * 2 in_h * 2 in_w, n]."""
+        from .weights import upsample_phase_weights
+        assert in_w & (in_w - 1) == 0, "phase launches need a power-of-two source width"
+        M = batch * in_h * in_w
+        ws = upsample_phase_weights(w_raw)
+        cs = None
+        if stats and self.fuse_gn_stats and 4 * M >= 16384 and (in_h * in_w) % 32 == 0:
+            cs = self.buf(4 * M // 32, 2, n, dtype=torch.float32, zero=True)          # 4 M / 32 slots: phase p of sample b owns a quarter of b's range
+            self._colstats[out.data_ptr()] = cs
+        for ph in range(4):
+            self.conv(a0, ws[ph], out, batch=batch, in_h=in_h, in_w=in_w, c0=c0, n=n, taps=4, phase=ph + 1, bias=bias, colstats=cs,
+                      alg_flops=2 * M * n * 9 * c0, tag_note=f" (upsample phase {ph})")
+        return out
+
     # ---- Winograd F(2x2,3x3) for the deep ResNet levels (profiles/r04_notes.md 1, 4): input transform -> 16 plane products (the 1x1 GEMM
     # path, nbatch_z = 16) -> output transform with the epilogue.  2.25 x fewer MFMA flops; only worth it where the 4 x larger transformed
     # tensors stay in the Infinity Cache and K = C_in is long -- the 16 x 16 / 8 x 8 levels of the UNet.

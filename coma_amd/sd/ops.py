@@ -21,7 +21,7 @@ class ConvGemmDesc(C.Structure):
                 ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colstats", C.c_void_p),
                 ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("stride_ln_stats", C.c_int64), ("rowstats", C.c_void_p),
-                ("out_t", C.c_void_p), ("n_split", C.c_int), ("ldo_t", C.c_int), ("rows_per_sample", C.c_int)]
+                ("out_t", C.c_void_p), ("n_split", C.c_int), ("ldo_t", C.c_int), ("rows_per_sample", C.c_int), ("phase", C.c_int)]
 
 
 def _p(t, name="tensor", dtype=F16):
@@ -41,8 +41,9 @@ def _stream(t):
 def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a1=None, c1=0, taps=1, stride=1, upsample=0,
               pad=1, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, epi=EPI_NONE, nbatch_z=1, stride_a=0, stride_w=0,
               stride_out=0, stride_res=0, workspace=None, colstats=None, ln_stats=None, ln_colsum=None, stride_ln_stats=0, rowstats=None,
-              out_t=None, n_split=0, ldo_t=0, rows_per_sample=0):
+              out_t=None, n_split=0, ldo_t=0, rows_per_sample=0, phase=0):
     d = ConvGemmDesc()
+    d.phase = phase
     d.a0, d.a1, d.c0, d.c1 = _p(a0, "a0"), _p(a1, "a1"), c0, c1
     d.batch, d.in_h, d.in_w = batch, in_h, in_w
     d.out_h = out_h if out_h is not None else in_h

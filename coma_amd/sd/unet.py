@@ -59,6 +59,7 @@ class HipUNet2DConditionModel:
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
+        self.upsample_phases = os.environ.get("SD_UPSAMPLE_PHASES", "1") != "0"     # Upsample2D convolutions as four sub-pixel phase products (A/B: 0)
         self.winograd_min_batch = int(os.environ.get("SD_WINOGRAD_MIN_BATCH", 8))
         self.fuse_conv_out = os.environ.get("SD_FUSE_CONV_OUT", "1") != "0"       # conv_norm_out + SiLU + conv_out as one launch (A/B: 0)
         self.winograd_upsamplers = os.environ.get("SD_WINOGRAD_UP", "1") != "0"   # ... and the Upsample2D convolutions of those levels (A/B: 0)
@@ -146,7 +147,11 @@ class HipUNet2DConditionModel:
             if i < len(ch) - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 o = g.buf(B * 4 * H * W, cout)
-                if self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and self.winograd_upsamplers and B >= self.winograd_min_batch:
+                if self.upsample_phases and W & (W - 1) == 0 and (H * W) % 32 == 0:
+                    # Upsample2D + conv as four sub-pixel phase products over the source: 16 multiplies per output 2 x 2 block instead of 36,
+                    # exact, no transformed tensors (sd_conv_gemm_desc.phase)
+                    g.conv3x3_upsampled(h, s[p + ".weight"], o, batch=B, in_h=H, in_w=W, c0=cout, n=cout, bias=s[p + ".bias"], stats=True)
+                elif self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and self.winograd_upsamplers and B >= self.winograd_min_batch:
                     # Upsample2D + conv at the deep levels: the input transform reads the nearest-x2 upsampling in place
                     g.conv3x3_winograd(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=2 * H, in_w=2 * W, c0=cout, n=cout, bias=s[p + ".bias"],
                                        upsample=True)

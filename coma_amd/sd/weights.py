@@ -207,6 +207,20 @@ def conv_weight(w, cin_pad=None, cout_pad=None):
     return w.contiguous()
 
 
+def upsample_phase_weights(w):
+    """[Cout, Cin, 3, 3] -> four [Cout, 4 * Cin] fp16 matrices, one per output parity (a, b) of `conv3x3(nearest-upsample-x2(x))`: output
+    pixel (2y + a, 2x + b) only sees the 2 x 2 source pixels (y - 1 + a .. y + a) x (x - 1 + b .. x + b), each weighted by the sum of the
+    3x3 taps that land on it (summed in fp32, rounded once).  K order (dy, dx, ci), what sd_conv_gemm_f16(taps = 4, phase = 1 + 2a + b) reads."""
+    sets = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}                 # parity -> taps folded onto window position 0 / 1
+    w32 = w.float()
+    out = []
+    for a in (0, 1):
+        for b in (0, 1):
+            taps = [sum(w32[:, :, ky, kx] for ky in sets[a][dy] for kx in sets[b][dx]) for dy in (0, 1) for dx in (0, 1)]      # each [Cout, Cin]
+            out.append(torch.stack(taps, dim=1).reshape(w.shape[0], -1).to(w.dtype).contiguous())
+    return out
+
+
 def pad_vec(b, n):
     return torch.nn.functional.pad(b, (0, n - b.shape[0])).contiguous() if n > b.shape[0] else b.contiguous()
 

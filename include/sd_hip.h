@@ -41,7 +41,7 @@ extern "C" {
 #define SD_EPI_TUNING_MASK 0x1ff00000
 
 /* out[m, n] = sum_k A[m, k] * W[n, k] (+ epilogue) with A gathered from one or two NHWC sources:
- *   m = (b, oy, ox), k = (tap, ci);  taps = 9: 3x3, zero pad 1;  taps = 1: 1x1 / linear
+ *   m = (b, oy, ox), k = (tap, ci);  taps = 9: 3x3, zero pad 1;  taps = 1: 1x1 / linear;  taps = 4: one sub-pixel phase (see `phase`)
  *   upsample = 1: the 3x3 window slides over the nearest-x2 upsampling of the [in_h, in_w] input
  *   ci runs over the concatenation [a0 (c0 channels) | a1 (c1 channels)]; c0, c1 multiples of 64
  * replaces: torch.nn.Conv2d / nn.Linear / torch.cat / F.interpolate(nearest) inside diffusers'
@@ -88,6 +88,14 @@ typedef struct sd_conv_gemm_desc {
    * statistics / batching / split-K); n_split and n - n_split multiples of 640, M and rows_per_sample multiples of 32, ldo_t % 8 == 0. */
   void* out_t;
   int n_split, ldo_t, rows_per_sample;
+  /* Sub-pixel phase of `conv3x3(F.interpolate(x, scale_factor=2, mode="nearest"))` (diffusers Upsample2D): output pixel (2y + a, 2x + b) only
+   * sees the 2 x 2 source pixels (y - 1 + a .. y + a) x (x - 1 + b .. x + b), each weighted by the SUM of the 3x3 taps that land on it -- 16
+   * products per output 2 x 2 block instead of 36, exactly (no transform).  phase = 1 + 2 a + b selects the parity; taps = 4, w fp16
+   * [n][4][c0+c1] = the summed weights of that phase (window order (dy, dx) row-major), batch / in_h / in_w = the SOURCE size (out_h = in_h,
+   * out_w = in_w, in_w a power of two), `out` = the full [batch, 2 in_h, 2 in_w, ldo] tensor: row m = (b, y, x) of the product is written to
+   * pixel (2y + a, 2x + b).  Four launches (phase 1..4) make the convolution; colstats (optional) must have room for 4 M / 32 slots.
+   * Plain epilogue only (bias).  0 = off (every other launch; a zero-initialised descriptor). */
+  int phase;
 } sd_conv_gemm_desc;
 
 int sd_conv_gemm_f16(const sd_conv_gemm_desc* desc, void* stream);

@@ -835,3 +835,39 @@ def test_conv3x3_with_three_input_channels_as_a_packed_k32_product(ops, B, H, W,
     ops.conv_gemm(xp, w27.to(DEV), out, batch=M, in_h=1, in_w=1, c0=32, n=n, bias=b.to(DEV))
     ref = torch.nn.functional.conv2d(img.permute(0, 3, 1, 2), w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(M, n)
     close(out, ref)
+
+
+@pytest.mark.parametrize("B,H,W,C,n,stats", [(2, 8, 8, 64, 64, False), (2, 16, 32, 128, 320, True), (1, 32, 16, 64, 128, True), (3, 4, 4, 64, 64, False),
+                                             (16, 32, 32, 640, 640, True)])
+def test_upsample_conv_as_four_subpixel_phases(ops, B, H, W, C, n, stats):
+    """Upsample2D + conv (nearest x2, then 3x3) as four phase products over the source (sd_conv_gemm_desc.phase, taps = 4) against conv2d of
+    the materialised upsampling in fp32; the column statistics the four launches leave (4 M / 32 slots) give the consumer's GroupNorm."""
+    from coma_amd.sd.weights import upsample_phase_weights
+    M, Mo = B * H * W, 4 * B * H * W
+    x = rnd(M, C, seed=1)
+    w = rnd(n, C, 3, 3, seed=2, scale=(9 * C) ** -0.5)            # torch layout
+    b = rnd(n, seed=3)
+    out = torch.full((Mo, n), 7.0, dtype=F16, device=DEV)
+    cs = torch.zeros(Mo // 32, 2, n, dtype=torch.float32, device=DEV) if stats else None
+    for ph, wp in enumerate(upsample_phase_weights(w)):
+        ops.conv_gemm(x.to(DEV), wp.to(DEV), out, batch=B, in_h=H, in_w=W, c0=C, n=n, taps=4, phase=ph + 1, bias=b.to(DEV), colstats=cs)
+    ref = so.conv_ref(x, w.permute(0, 2, 3, 1).reshape(n, 9, C), batch=B, h=H, w_=W, taps=9, upsample=True, bias=b)
+    close(out, ref)
+    if stats:
+        hw = 4 * H * W
+        ga, be = rnd(n, seed=6) * 0.2 + 1, rnd(n, seed=7) * 0.2
+        y = torch.empty(Mo, n, dtype=F16, device=DEV)
+        st = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+        ops.groupnorm_colstats(out, ga.to(DEV), be.to(DEV), y, st, cs, batch=B, hw=hw, c0=n, eps=1e-5, silu=True)
+        close(y, so.groupnorm_ref(out.cpu(), ga, be, batch=B, hw=hw, eps=1e-5, silu=True))
+    with pytest.raises(Exception, match="phase"):
+        ops.conv_gemm(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, in_h=H, in_w=W, c0=C, n=n, taps=9, phase=1)
+
+
+def test_plain_product_with_more_than_65536_rows(ops):
+    """A linear given as batch x 1 x 1 with more rows than the kernel's 16-bit sample index: folded into batch x 1 x f on the host."""
+    rows, k, n = 3 * 65536 + 4096, 64, 64
+    x, w = rnd(rows, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5)
+    out = torch.empty(rows, n, dtype=F16, device=DEV)
+    ops.linear(x.to(DEV), w.to(DEV), out, rows=rows, k=k, n=n)
+    close(out, x.float() @ w.float().t())
