@@ -59,7 +59,10 @@ class HipUNet2DConditionModel:
         self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
         # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
-        self.upsample_phases = os.environ.get("SD_UPSAMPLE_PHASES", "1") != "0"     # Upsample2D convolutions as four sub-pixel phase products (A/B: 0)
+        # Upsample2D convolutions as four sub-pixel phase products: OFF in the UNet (measured 17.67 / 17.72 ms with, 17.55 / 17.64 without: at
+        # M = 1024 ... 16384 source rows four launches cost more than their 2.25 x fewer multiplies buy, and the two deep ones already run as
+        # Winograd); the VAE decoder, whose upsamplers are 21 % of it, uses them (coma_amd/sd/vae.py).  A/B: SD_UPSAMPLE_PHASES=1
+        self.upsample_phases = os.environ.get("SD_UPSAMPLE_PHASES", "0") != "0"
         self.winograd_min_batch = int(os.environ.get("SD_WINOGRAD_MIN_BATCH", 8))
         self.fuse_conv_out = os.environ.get("SD_FUSE_CONV_OUT", "1") != "0"       # conv_norm_out + SiLU + conv_out as one launch (A/B: 0)
         self.winograd_upsamplers = os.environ.get("SD_WINOGRAD_UP", "1") != "0"   # ... and the Upsample2D convolutions of those levels (A/B: 0)

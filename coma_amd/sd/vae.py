@@ -164,7 +164,8 @@ class HipVaeEncoder(_VaeBase):
             # 3 input channels: one elementwise pass packs every pixel's 3x3x3 neighbourhood into 32 halfs and conv_in is a plain K = 32 product
             # (the implicit GEMM multiplied a 64-channel padded input: K = 576 for 27 real products)
             xp = g.buf(B * H * W, 32)
-            g.add(lambda: ops.im2col3x3_c3(self.x, xp, batch=B, h=H, w=W, ldx=64), tag=f"im2col 3x3x3 B={B} {H}x{W}", nbytes=2 * B * H * W * (4 + 32))
+            g.add(lambda h0=H, w0=W: ops.im2col3x3_c3(self.x, xp, batch=B, h=h0, w=w0, ldx=64),     # (H, W are rebound by the level loop below)
+                  tag=f"im2col 3x3x3 B={B} {H}x{W}", nbytes=2 * B * H * W * (4 + 32))
             w27 = torch.nn.functional.pad(conv_weight(s["encoder.conv_in.weight"]), (0, 5)).contiguous()       # [n][ky][kx][c] -> [n][32]
             g.conv(xp, w27, x, batch=B, in_h=H, in_w=W, c0=32, n=ch[0], bias=s["encoder.conv_in.bias"], alg_flops=2 * B * H * W * ch[0] * 27,
                    tag_note=" (conv_in, packed 3x3x3)")        # (a 1x1 over [B, H, W]: the kernel keeps the sample index in 16 bits)
