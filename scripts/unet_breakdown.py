@@ -21,6 +21,8 @@ for tag, fl, ms in unet.g.profile(reps=3):
         M, N, K, taps, z = map(int, m.groups())
         if taps == 9:
             cat = f"conv3x3 M={M}"
+        elif "winograd planes" in tag:
+            cat = f"winograd plane products (conv3x3 M={4 * M})"
         elif z > 1:
             cat = "batched V^T projection"
         elif N >= 2 * K and N >= 2560:
@@ -30,7 +32,7 @@ for tag, fl, ms in unet.g.profile(reps=3):
         else:
             cat = "ff2 and skip 1x1 (K>1280)"
     else:
-        cat = (tag.split() or ["other"])[0].split("(")[0]
+        cat = "winograd transforms (+ folded GroupNorm)" if "winograd" in tag else (tag.split() or ["other"])[0].split("(")[0]
     acc[cat][0] += ms; acc[cat][1] += 1; acc[cat][2] += fl
 tot = sum(v[0] for v in acc.values())
 print(f"eager per-launch total {tot:.2f} ms")
