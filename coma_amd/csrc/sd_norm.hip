@@ -615,3 +615,25 @@ extern "C" int sd_groupnorm_table_f16(const void* x0, int c0, int batch, int hw,
   }
   return check_launch("groupnorm table kernels");
 }
+
+// The affine table of a GroupNorm over the channel concatenation of TWO tensors, from the column sums their producers left (no pass over
+// the tensors): fp32 [batch][c0 + c1][2] at the start of `stats`.  For consumers that apply the affine themselves
+// (sd_winograd_input_f16 with gn_affine: norm1 of the UNet's up-block ResNets, whose input is [hidden | skip]).
+extern "C" int sd_groupnorm_table_cat_f16(int c0, int c1, int batch, int hw, int groups, float eps, const void* gamma, const void* beta, float* stats,
+                                          const float* colstats0, const float* colstats1, void* stream) {
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_GN_TABLE_CAT;
+    r.p[0] = (void*)gamma; r.p[1] = (void*)beta; r.p[2] = stats; r.p[3] = (void*)colstats0; r.p[4] = (void*)colstats1;
+    r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = hw; r.i[4] = groups; r.f[0] = eps;
+    return sd::plan_record(r);
+  }
+  if (!gamma || !beta || !stats || !colstats0 || (c1 > 0 && !colstats1)) return fail(COMA_E_INVALID, "sd_groupnorm_table_cat_f16: null pointer");
+  const int C = c0 + c1;
+  if (batch <= 0 || hw <= 0 || hw % 32 || groups <= 0 || groups > GN_MAX_GROUPS || c0 <= 0 || c1 < 0 || C % groups || c0 % 8 || c1 % 8 || C > GN_MAX_C ||
+      C / groups > 256)
+    return fail(COMA_E_INVALID, "sd_groupnorm_table_cat_f16: bad shape c0=%d c1=%d groups=%d hw=%d", c0, c1, groups, hw);
+  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(batch * groups), dim3(256), 0, (hipStream_t)stream, colstats0, colstats1, c0, c1, hw, groups, eps,
+                     (const _Float16*)gamma, (const _Float16*)beta, stats);
+  return check_launch("gn_finalize_colstats_kernel");
+}

@@ -22,8 +22,11 @@ using coma::fail;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // thread = (tile, chunk of 8 channels); V[p][t][c], p = 4 i + j
+// affine != nullptr: the source is first normalised per (sample, channel) -- y = x * scale + shift, fp32 [batch][c0+c1][2], the table of a
+// GroupNorm -- optionally passed through SiLU, and rounded to fp16 (what the GroupNorm kernel would have stored); pad pixels stay zero.
 __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1, int c0,
-                                                            int c1, int batch, int h, int w, int up, _Float16* __restrict__ v) {
+                                                            int c1, int batch, int h, int w, int up, const float* __restrict__ affine,
+                                                            int silu, _Float16* __restrict__ v) {
   const int c = c0 + c1, cch = c >> 3;
   const int th = h >> 1, tw = w >> 1;
   const long long ntile = (long long)batch * th * tw;
@@ -37,6 +40,14 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __r
   const _Float16* src;
   int ld, cc;
   if (ch < c0) { src = x0; ld = c0; cc = ch; } else { src = x1; ld = c1; cc = ch - c0; }
+  float sc[8], sh[8];
+  if (affine) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float2 a = reinterpret_cast<const float2*>(affine)[(long long)b * c + ch + e];
+      sc[e] = a.x; sh[e] = a.y;
+    }
+  }
   float d[4][4][8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -47,7 +58,17 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __r
       half8 q = {0, 0, 0, 0, 0, 0, 0, 0};
       // up = 1: the 3x3 window slides over the nearest-x2 upsampling of the [h/2, w/2] source (diffusers Upsample2D)
       if (y >= 0 && y < h && x >= 0 && x < w)
+      {
         q = *reinterpret_cast<const half8*>(src + (((long long)b * (h >> up) + (y >> up)) * (w >> up) + (x >> up)) * ld + cc);
+        if (affine) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = fmaf((float)q[e], sc[e], sh[e]);
+            if (silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
+            q[e] = (_Float16)f;
+          }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) d[i][j][e] = (float)q[e];
     }
@@ -162,6 +183,88 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const _Float16* __
       }
       *reinterpret_cast<half8*>(out + row * ldo + ch) = o;
     }
+}
+
+// The same output transform with the consumer's GroupNorm statistics: one block = one ROW of 2x2 tiles (w / 2 = 16 tiles) x 128 output
+// channels, thread = (tile, chunk of 8 channels).  The two image rows the block writes are one 32-row slot each of the column-sum buffer
+// cs fp32 [batch * h * w / 32][2][n] (sd_conv_gemm_desc.colstats layout): sums and sums of squares of the STORED fp16 values, folded over
+// the 16 tiles through LDS in a fixed order (reproducible).  w == 32 only (the 32 x 32 level of the UNet).
+__global__ void __launch_bounds__(256) winograd_output_cs_kernel(const _Float16* __restrict__ m, int ldm, int batch, int h, int n,
+                                                                const _Float16* __restrict__ bias, const _Float16* __restrict__ bias_bn,
+                                                                int ldbb, const _Float16* __restrict__ res, int ldr,
+                                                                _Float16* __restrict__ out, int ldo, int silu, float* __restrict__ cs) {
+  constexpr int w = 32, tw = 16;
+  __shared__ float red[2][2][16][128];                      // [sum | sumsq][image row a][tile][channel of the block]
+  const int th = h >> 1;
+  const long long ntile = (long long)batch * th * tw;
+  const int tx = threadIdx.x >> 4, chunk = threadIdx.x & 15;
+  const int R = blockIdx.x, b = R / th, ty = R - b * th;
+  const int ch = blockIdx.y * 128 + chunk * 8;
+  const long long t = (long long)R * tw + tx;
+  float s[2][4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float mm[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const half8 q = *reinterpret_cast<const half8*>(m + ((long long)(4 * i + j) * ntile + t) * ldm + ch);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mm[i][e] = (float)q[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[0][j][e] = mm[0][e] + mm[1][e] + mm[2][e];
+      s[1][j][e] = mm[1][e] - mm[2][e] - mm[3][e];
+    }
+  }
+  float add[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) add[e] = 0.0f;
+  if (bias) {
+    const half8 q = *reinterpret_cast<const half8*>(bias + ch);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) add[e] += (float)q[e];
+  }
+  if (bias_bn) {
+    const half8 q = *reinterpret_cast<const half8*>(bias_bn + (long long)b * ldbb + ch);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) add[e] += (float)q[e];
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    float ps[8], pq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ps[e] = pq[e] = 0.0f;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const long long row = ((long long)b * h + 2 * ty + a) * w + 2 * tx + bb;
+      half8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (res) r = *reinterpret_cast<const half8*>(res + row * ldr + ch);
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y = (bb == 0 ? s[a][0][e] + s[a][1][e] + s[a][2][e] : s[a][1][e] - s[a][2][e] - s[a][3][e]) + add[e];
+        if (silu) y = y / (1.0f + __expf(-y));
+        o[e] = (_Float16)(y + (float)r[e]);
+        const float f = (float)o[e];
+        ps[e] += f; pq[e] += f * f;
+      }
+      *reinterpret_cast<half8*>(out + row * ldo + ch) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][a][tx][chunk * 8 + e] = ps[e]; red[1][a][tx][chunk * 8 + e] = pq[e]; }
+  }
+  __syncthreads();
+  // 2 (sum | sumsq) x 2 rows x 128 channels = 512 results, two per thread, each the fixed-order sum over the 16 tiles
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = threadIdx.x + 256 * k, which = idx >> 8, a = (idx >> 7) & 1, c = idx & 127;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += red[which][a][i][c];
+    const long long slot = (long long)b * h + 2 * ty + a;              // w == 32: one image row = one 32-row slot
+    cs[(slot * 2 + which) * n + blockIdx.y * 128 + c] = acc;
+  }
 }
 
 
@@ -330,12 +433,14 @@ __global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
 
 extern "C" {
 
-int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, void* v, void* stream) {
+int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, const float* gn_affine,
+                          int silu, void* v, void* stream) {
   using namespace sd;
   if (plan_recording()) {
     PlanRec r{};
     r.kind = PK_WINO_IN;
-    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = v; r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = h; r.i[4] = w; r.i[5] = upsample;
+    r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = v; r.p[3] = (void*)gn_affine;
+    r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = h; r.i[4] = w; r.i[5] = upsample; r.i[6] = silu;
     return plan_record(r);
   }
   if (upsample != 0 && upsample != 1) return fail(COMA_E_INVALID, "sd_winograd_input_f16: upsample must be 0 or 1");
@@ -344,7 +449,7 @@ int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int ba
   if (batch <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: even h, w required");
   const long long total = (long long)batch * (h / 2) * (w / 2) * ((c0 + c1) / 8);
   hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const _Float16*)x0, (const _Float16*)x1, c0, c1, batch, h, w, upsample, (_Float16*)v);
+                     (const _Float16*)x0, (const _Float16*)x1, c0, c1, batch, h, w, upsample, gn_affine, silu, (_Float16*)v);
   return check_launch("sd_winograd_input_f16");
 }
 
@@ -358,12 +463,12 @@ int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream) {
 }
 
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
-                           const void* res, int ldr, void* out, int ldo, int silu, void* stream) {
+                           const void* res, int ldr, void* out, int ldo, int silu, float* colstats, void* stream) {
   using namespace sd;
   if (plan_recording()) {
     PlanRec r{};
     r.kind = PK_WINO_OUT;
-    r.p[0] = (void*)m; r.p[1] = (void*)bias; r.p[2] = (void*)bias_bn; r.p[3] = (void*)res; r.p[4] = out;
+    r.p[0] = (void*)m; r.p[1] = (void*)bias; r.p[2] = (void*)bias_bn; r.p[3] = (void*)res; r.p[4] = out; r.p[5] = colstats;
     r.i[0] = ldm; r.i[1] = batch; r.i[2] = h; r.i[3] = w; r.i[4] = n; r.i[5] = ldbb; r.i[6] = ldr; r.i[7] = ldo; r.i[8] = silu;
     return plan_record(r);
   }
@@ -372,6 +477,13 @@ int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int 
   if (ldo == 0) ldo = n;
   if (ldr == 0) ldr = n;
   if (ldbb == 0) ldbb = n;
+  if (colstats) {
+    if (w != 32 || n % 128) return fail(COMA_E_INVALID, "sd_winograd_output_f16: column sums need w = 32 and n %% 128 == 0 (w=%d n=%d)", w, n);
+    hipLaunchKernelGGL(winograd_output_cs_kernel, dim3((unsigned)(batch * (h / 2)), (unsigned)(n / 128)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)m, ldm, batch, h, n, (const _Float16*)bias, (const _Float16*)bias_bn, ldbb, (const _Float16*)res, ldr,
+                       (_Float16*)out, ldo, silu, colstats);
+    return check_launch("sd_winograd_output_f16");
+  }
   const long long total = (long long)batch * (h / 2) * (w / 2) * (n / 8);
   hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const _Float16*)m, ldm, batch, h, w, n, (const _Float16*)bias, (const _Float16*)bias_bn, ldbb, (const _Float16*)res,

@@ -142,18 +142,43 @@ class LaunchGraph:
                  nbytes=2 * (5 + (16 if m is not None else 1)) * batch * h * w * C // (4 if m is not None else 1))
         return V
 
-    def winograd_output(self, P, out, *, batch, h, w, n, bias=None, bias_bn=None, ldbb=0, res=None):
-        self.add(lambda: ops.winograd_output(P, out, batch=batch, h=h, w=w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res),
-                 tag=f"winograd output B={batch} {h}x{w} N={n}", nbytes=2 * (5 + (1 if res is not None else 0)) * batch * h * w * n)
+    def winograd_output(self, P, out, *, batch, h, w, n, bias=None, bias_bn=None, ldbb=0, res=None, stats=False):
+        """stats: also leave the column sums of `out` for the consumer's GroupNorm (w = 32 only: one image row = one 32-row slot)."""
+        cs, M = None, batch * h * w
+        if stats and self.fuse_gn_stats and w == 32 and n % 128 == 0 and M >= 16384:
+            cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
+            self._colstats[out.data_ptr()] = cs
+        self.add(lambda: ops.winograd_output(P, out, batch=batch, h=h, w=w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res, colstats=cs),
+                 tag=f"winograd output{' (+ colstats)' if cs is not None else ''} B={batch} {h}x{w} N={n}",
+                 nbytes=2 * (5 + (1 if res is not None else 0)) * batch * h * w * n)
         return out
 
-    def conv3x3_winograd(self, a0, w9, out, *, batch, in_h, in_w, c0, n, a1=None, c1=0, bias=None, bias_bn=None, ldbb=0, res=None, upsample=False):
+    def gn_table_winograd_input(self, x0, gamma, beta, *, batch, h, w, c0, x1=None, c1=0, eps, silu=True):
+        """GroupNorm (+ SiLU) folded into the input transform through the per-(sample, channel) affine table, for slices too large for
+        gn_winograd_input: needs the column sums of every source (left by its producer); returns None when one is missing.  Two launches
+        (table, transform), and the normalised tensor is never written."""
+        hw = h * w
+        cs0 = self._colstats.get(x0.data_ptr()) if hw % 32 == 0 else None
+        cs1 = self._colstats.get(x1.data_ptr()) if (x1 is not None and hw % 32 == 0) else None
+        if cs0 is None or (x1 is not None and cs1 is None):
+            return None
+        table = self.gn_scratch(batch, hw)
+        C, T = c0 + c1, batch * (h // 2) * (w // 2)
+        self.add(lambda: ops.groupnorm_table_cat(gamma, beta, table, cs0, cs1, batch=batch, hw=hw, c0=c0, c1=c1, eps=eps),
+                 tag=f"groupnorm(table) B={batch} hw={hw} C={C}")
+        V = self.buf(16, T, C)
+        self.add(lambda: ops.winograd_input(x0, V, batch=batch, h=h, w=w, c0=c0, x1=x1, c1=c1, gn_affine=table, silu=silu),
+                 tag=f"groupnorm apply + winograd input B={batch} {h}x{w} C={C}", nbytes=2 * 5 * batch * h * w * C)
+        return V
+
+    def conv3x3_winograd(self, a0, w9, out, *, batch, in_h, in_w, c0, n, a1=None, c1=0, bias=None, bias_bn=None, ldbb=0, res=None, upsample=False,
+                         stats=False):
         """The unfused chain: input transform -> plane products -> output transform (+ bias, per-sample bias, residual).  in_h, in_w are
         the convolution's own (= output) resolution; with upsample the sources are [in_h / 2, in_w / 2]."""
         C, T = c0 + c1, batch * (in_h // 2) * (in_w // 2)
         V = self.winograd_input(a0, batch=batch, h=in_h, w=in_w, c0=c0, a1=a1, c1=c1, upsample=upsample)
         P = self.winograd_planes(V, self.winograd_weight(w9, n=n, c=C), tiles=T, c=C, n=n)
-        return self.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res)
+        return self.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res, stats=stats)
 
     def dup(self, src, dst):
         """dst = [src | src] along the batch axis (two identical CFG halves); the GroupNorm column sums of src follow."""

@@ -252,10 +252,20 @@ def copy_d2d(dst, src):
     _lib.check(_lib.lib().sd_copy_d2d(dst.data_ptr(), src.data_ptr(), n, _stream(dst)), "sd_copy_d2d")
 
 
-def winograd_input(x0, v, *, batch, h, w, c0, x1=None, c1=0, upsample=False):
+def groupnorm_table_cat(gamma, beta, stats, colstats0, colstats1, *, batch, hw, c0, c1, groups=32, eps=1e-5):
+    """(scale, shift) per (sample, channel) of a GroupNorm over [x0 | x1], from the two producers' column sums only."""
+    f32 = torch.float32
+    rc = _lib.lib().sd_groupnorm_table_cat_f16(c0, c1, batch, hw, groups, eps, _p(gamma), _p(beta), _p(stats, "stats", f32),
+                                               _p(colstats0, "colstats0", f32), _p(colstats1, "colstats1", f32), _stream(stats))
+    _lib.check(rc, "sd_groupnorm_table_cat_f16")
+    return stats
+
+
+def winograd_input(x0, v, *, batch, h, w, c0, x1=None, c1=0, upsample=False, gn_affine=None, silu=False):
     """v fp16 [16][batch*h/2*w/2][c0+c1] = B^T d B of every 4x4 patch (F(2x2,3x3), zero pad 1); upsample: [h, w] is the nearest-x2
     upsampling of the [h/2, w/2] sources."""
-    _lib.check(_lib.lib().sd_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, h, w, 1 if upsample else 0, _p(v, "v"), _stream(v)),
+    _lib.check(_lib.lib().sd_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, h, w, 1 if upsample else 0,
+                                                _p(gn_affine, "gn_affine", torch.float32), 1 if silu else 0, _p(v, "v"), _stream(v)),
                "sd_winograd_input_f16")
     return v
 
@@ -266,10 +276,11 @@ def winograd_weight(w, u, *, n, c):
     return u
 
 
-def winograd_output(m, out, *, batch, h, w, n, ldm=0, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, silu=False):
+def winograd_output(m, out, *, batch, h, w, n, ldm=0, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, silu=False, colstats=None):
     """out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] (+ bias, per-sample bias, SiLU, residual)."""
     rc = _lib.lib().sd_winograd_output_f16(_p(m, "m"), ldm or n, batch, h, w, n, _p(bias, "bias"), _p(bias_bn, "bias_bn"), ldbb,
-                                           _p(res, "res"), ldr, _p(out, "out"), ldo, 1 if silu else 0, _stream(out))
+                                           _p(res, "res"), ldr, _p(out, "out"), ldo, 1 if silu else 0, _p(colstats, "colstats", torch.float32),
+                                           _stream(out))
     _lib.check(rc, "sd_winograd_output_f16")
     return out
 

@@ -69,6 +69,8 @@ class HipUNet2DConditionModel:
         # ... only for groups of >= 40 channels: a workgroup owns one (sample, group) slice, and with 20-channel groups (C = 640) its 40-byte
         # pieces of every (plane, tile) row waste most of each memory transaction (48-114 us per launch at the 32 x 32 level)
         self.gn_winograd_min_cg = int(os.environ.get("SD_GN_WINOGRAD_MIN_CG", 40))
+        # unfused Winograd blocks (32 x 32): output transforms leave column sums, GroupNorms become table + affine inside the input transform (A/B: 0)
+        self.gn_table_winograd = os.environ.get("SD_GN_TABLE_WINOGRAD", "1") != "0"
         self.fuse_gn_winograd = os.environ.get("SD_GN_WINOGRAD", "1") != "0"     # GroupNorms folded into the Winograd transforms (A/B: 0)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
@@ -157,7 +159,7 @@ class HipUNet2DConditionModel:
                 elif self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and self.winograd_upsamplers and B >= self.winograd_min_batch:
                     # Upsample2D + conv at the deep levels: the input transform reads the nearest-x2 upsampling in place
                     g.conv3x3_winograd(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=2 * H, in_w=2 * W, c0=cout, n=cout, bias=s[p + ".bias"],
-                                       upsample=True)
+                                       upsample=True, stats=self.gn_table_winograd)
                 else:
                     g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout,
                            n=cout, taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
@@ -192,17 +194,32 @@ class HipUNet2DConditionModel:
             P1 = g.winograd_planes(V1, g.winograd_weight(conv_weight(s[p + ".conv1.weight"]), n=cout, c=cin), tiles=T, c=cin, n=cout)
             V2 = g.gn_winograd_input(s[p + ".norm2.weight"], s[p + ".norm2.bias"], batch=B, h=H, w=W, c0=cout, m=P1, bias=s[p + ".conv1.bias"],
                                      bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, eps=1e-5)
+        elif wino:
+            # slices too large (or groups too narrow) for the LDS-resident fusion: GroupNorm through the affine table inside the input
+            # transform when the producers left their column sums (the Winograd output transform does, at the 32 x 32 level)
+            U1 = g.winograd_weight(conv_weight(s[p + ".conv1.weight"]), n=cout, c=cin)
+            V1 = g.gn_table_winograd_input(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], batch=B, h=H, w=W, c0=c0, x1=x1, c1=c1, eps=1e-5) \
+                if self.gn_table_winograd else None
+            if V1 is None:
+                n1 = g.buf(M, cin)
+                g.groupnorm(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=c0, x1=x1, c1=c1, eps=1e-5, silu=True)
+                V1 = g.winograd_input(n1, batch=B, h=H, w=W, c0=cin)
+            h = g.buf(M, cout)
+            g.winograd_output(g.winograd_planes(V1, U1, tiles=T, c=cin, n=cout), h, batch=B, h=H, w=W, n=cout, bias=s[p + ".conv1.bias"],
+                              bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=self.gn_table_winograd)
+            V2 = g.gn_table_winograd_input(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], batch=B, h=H, w=W, c0=cout, eps=1e-5) \
+                if self.gn_table_winograd else None
+            if V2 is None:
+                n2 = g.buf(M, cout)
+                g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
+                V2 = g.winograd_input(n2, batch=B, h=H, w=W, c0=cout)
         else:
             n1 = g.buf(M, cin)
             g.groupnorm(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=c0, x1=x1, c1=c1, eps=1e-5,
                         silu=True)
             h = g.buf(M, cout)
-            if wino:
-                g.conv3x3_winograd(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout,
-                                   bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld)
-            else:
-                g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
-                       bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
+            g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9,
+                   bias=s[p + ".conv1.bias"], bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
             n2 = g.buf(M, cout)
             g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
         if p + ".conv_shortcut.weight" in s:
@@ -213,12 +230,9 @@ class HipUNet2DConditionModel:
             assert x1 is None and c0 == cout
             sc = x0
         out = g.buf(M, cout)
-        if fused_gn:
+        if wino:
             P2 = g.winograd_planes(V2, g.winograd_weight(conv_weight(s[p + ".conv2.weight"]), n=cout, c=cout), tiles=T, c=cout, n=cout)
-            g.winograd_output(P2, out, batch=B, h=H, w=W, n=cout, bias=s[p + ".conv2.bias"], res=sc)
-        elif wino:
-            g.conv3x3_winograd(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout,
-                               bias=s[p + ".conv2.bias"], res=sc)
+            g.winograd_output(P2, out, batch=B, h=H, w=W, n=cout, bias=s[p + ".conv2.bias"], res=sc, stats=self.gn_table_winograd)
         else:
             g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
                    bias=s[p + ".conv2.bias"], res=sc, stats=True)

@@ -157,6 +157,9 @@ int sd_attention_wide_f16(const void* q, const void* k, const void* vt, void* ou
  * x0; nothing is applied.  For consumers that apply the affine themselves (sd_xfront_f16). */
 int sd_groupnorm_table_f16(const void* x0, int c0, int batch, int hw, int groups, float eps, const void* gamma, const void* beta,
                            float* stats, const float* colstats0, void* stream);
+/* The same table for a GroupNorm over the channel concatenation of two tensors, from both producers' column sums only (hw % 32 == 0). */
+int sd_groupnorm_table_cat_f16(int c0, int c1, int batch, int hw, int groups, float eps, const void* gamma, const void* beta, float* stats,
+                               const float* colstats0, const float* colstats1, void* stream);
 
 /* The row-local FRONT of a transformer block at C = 320 in ONE launch (five launches of the unfused graph):
  *   n = x * scale + shift (gn_affine [samples][320][2], Transformer2DModel.norm without SiLU);  h = n Wpi^T + bpi (proj_in);
@@ -198,15 +201,20 @@ int sd_xattn_chain_f16(const void* attn1_out, const void* h, const void* wo1, co
 /* Winograd F(2x2,3x3) around a plane-batched GEMM: a 3x3 / stride 1 / pad 1 convolution as 16 independent [T, C_in] x [C_in, C_out]
  * products (T = batch * h/2 * w/2 output tiles) run by sd_conv_gemm_f16 with nbatch_z = 16 -- 2.25 x fewer MFMA flops.
  *   sd_winograd_input_f16   v fp16 [16][T][c0+c1] = B^T d B of every 4x4 input patch (two concatenated NHWC sources, zero pad);
- *                           upsample = 1: [h, w] is the nearest-x2 upsampling of the [h/2, w/2] sources (diffusers Upsample2D + conv)
+ *                           upsample = 1: [h, w] is the nearest-x2 upsampling of the [h/2, w/2] sources (diffusers Upsample2D + conv);
+ *                           gn_affine != NULL: fp32 [batch][c0+c1][2] = (scale, shift) of a GroupNorm applied to the source on the fly
+ *                           (+ SiLU if silu), rounded to fp16 as the GroupNorm kernel would have stored it -- the normalised tensor is never written
  *   sd_winograd_weight_f16  u fp16 [16][n][c] = G g G^T of w fp16 [n][9][c] (computed in fp32, rounded once; at prep time)
- *   sd_winograd_output_f16  out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] + bias + per-sample bias, SiLU, + residual
+ *   sd_winograd_output_f16  out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] + bias + per-sample bias, SiLU, + residual;
+ *                           colstats != NULL (w = 32, n % 128 == 0): also fp32 [batch*h*w/32][2][n], the column sums / sums of squares of
+ *                           `out` per 32 rows (sd_conv_gemm_desc.colstats layout: the consumer's GroupNorm statistics)
  * h, w even; channel counts multiples of 8.  sd_winograd_input_f16 / _output_f16 are recordable (sd_winograd_weight_f16 runs at prep time).
  * replaces: diffusers Conv2d(3x3) inside self.unet(...) / self.vae.decode, utils/adaptive_mask_inpainting.py:1001-1007, :1086, :1112. */
-int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, void* v, void* stream);
+int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, const float* gn_affine, int silu,
+                          void* v, void* stream);
 int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream);
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
-                           const void* res, int ldr, void* out, int ldo, int silu, void* stream);
+                           const void* res, int ldr, void* out, int ldo, int silu, float* colstats, void* stream);
 /* GroupNorm (+ SiLU) of a SMALL feature map fused with the Winograd input transform, one workgroup per (sample, group), the group's
  * slice in LDS (h * w * C / groups <= 20480 elements: the 16 x 16 / 8 x 8 levels of the UNet):
  *   source = the channel concatenation [x0 | x1] (NHWC fp16; m == NULL), or

@@ -871,3 +871,47 @@ def test_plain_product_with_more_than_65536_rows(ops):
     out = torch.empty(rows, n, dtype=F16, device=DEV)
     ops.linear(x.to(DEV), w.to(DEV), out, rows=rows, k=k, n=n)
     close(out, x.float() @ w.float().t())
+
+
+@pytest.mark.parametrize("B,n,c1", [(2, 640, 0), (1, 128, 128)])
+def test_winograd_output_column_sums_and_table_affine_input(ops, B, n, c1):
+    """The unfused Winograd chain of the 32 x 32 level: the output transform leaves the column sums of its (stored, fp16) result in the
+    sd_conv_gemm_desc.colstats layout, the GroupNorm of the consumer becomes a table from those sums (two concatenated sources through
+    sd_groupnorm_table_cat_f16) applied inside the next input transform -- against GroupNorm kernel -> plain input transform."""
+    H = W = 32
+    hw, T, M = H * W, B * 16 * 16, B * H * W
+    m = rnd(16, T, n, seed=1)
+    b, r = rnd(n, seed=2), rnd(M, n, seed=3)
+    out = torch.empty(M, n, dtype=F16, device=DEV)
+    cs = torch.zeros(M // 32, 2, n, dtype=torch.float32, device=DEV)
+    ops.winograd_output(m.to(DEV), out, batch=B, h=H, w=W, n=n, bias=b.to(DEV), res=r.to(DEV), colstats=cs)
+    plain = torch.empty_like(out)
+    ops.winograd_output(m.to(DEV), plain, batch=B, h=H, w=W, n=n, bias=b.to(DEV), res=r.to(DEV))
+    assert torch.equal(out, plain)                                             # the two thread mappings store the same bits
+    o = out.float().cpu()
+    ref_sum, ref_sq = o.reshape(M // 32, 32, n).sum(1), (o * o).reshape(M // 32, 32, n).sum(1)
+    assert float((cs[:, 0].cpu() - ref_sum).abs().max()) <= 1e-3 * float(ref_sum.abs().max()) + 1e-3
+    assert float((cs[:, 1].cpu() - ref_sq).abs().max()) <= 1e-3 * float(ref_sq.abs().max())
+    # consumer: GroupNorm over [out | x1] + SiLU + input transform, through the table
+    C = n + c1
+    x1 = cs1 = None
+    if c1:
+        x1 = rnd(M, c1, seed=4).to(DEV)
+        x1f = x1.float().cpu()
+        cs1 = torch.stack([x1f.reshape(M // 32, 32, c1).sum(1), (x1f * x1f).reshape(M // 32, 32, c1).sum(1)], dim=1).to(DEV)
+    ga, be = (rnd(C, seed=5) * 0.2 + 1).to(DEV), (rnd(C, seed=6) * 0.2).to(DEV)
+    table = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+    ops.groupnorm_table_cat(ga, be, table, cs, cs1, batch=B, hw=hw, c0=n, c1=c1, eps=1e-5)
+    V = torch.empty(16, T, C, dtype=F16, device=DEV)
+    ops.winograd_input(out, V, batch=B, h=H, w=W, c0=n, x1=x1, c1=c1, gn_affine=table, silu=True)
+    nb = torch.empty(M, C, dtype=F16, device=DEV)
+    stats = torch.empty(ops.gn_scratch_floats(B, hw), dtype=torch.float32, device=DEV)
+    ops.groupnorm(out, ga, be, nb, stats, batch=B, hw=hw, c0=n, x1=x1, c1=c1, eps=1e-5, silu=True)
+    V2 = torch.empty_like(V)
+    ops.winograd_input(nb, V2, batch=B, h=H, w=W, c0=C)
+    close(V, V2.float(), tol=2e-3)                                             # statistics summed in another order: fp16-rounding tolerance
+    xc = torch.cat([out.cpu(), x1.cpu()], -1) if c1 else out.cpu()
+    nrm = so.groupnorm_ref(xc, ga.cpu(), be.cpu(), batch=B, hw=hw, eps=1e-5, silu=True).half().float()
+    close(V, _wino_input_ref(nrm.reshape(B, H, W, C)))
+    with pytest.raises(Exception, match="w = 32"):
+        ops.winograd_output(m[:, :B * 64].contiguous().to(DEV), out, batch=B, h=16, w=16, n=n, colstats=cs)
