@@ -393,7 +393,7 @@ def bench_occupancy(args, dev, world, rank):
 #   profiles/r04_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91545e6 KiB, WRITE_SIZE 3.71199e6 KiB per launch
 #   profiles/r04_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.12 GB, rowprep 2 * 0.21 + 0.23 GB,
 #                                        groupmax 0.06 GB
-UNET_GEMM_PMC_TRAFFIC_BYTES = int(157.34e6)
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(157.19e6)
 OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.96e9)   # fused 11.02 + 0.25, rowprep 0.42 + 0.23, groupmax 0.04 GB
 OCCUPANCY_PMC_SOURCE = ("profiles/r04_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
                         "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "

@@ -87,13 +87,13 @@ def fp32_strict():
 
 
 def test_restatement_on_device_equals_restatement_on_cpu(hip_lib, fp32_strict):
-    """128 x 128 image, the last 4 of the 50 timesteps (2 re-estimations): AdaptiveLoopRef evaluated on the CPU == evaluated by
-    torch's fp32 device kernels, masks identical; and the HIP loop agrees with both."""
+    """128 x 128 image, the last 2 of the 50 timesteps (1 re-estimation; every CPU step costs ~15 s of the suite's budget): AdaptiveLoopRef
+    evaluated on the CPU == evaluated by torch's fp32 device kernels, masks identical; and the HIP loop agrees with both."""
     inp = make_inputs(1, HW=128, seed=11, ratio=0.0)
-    hip = run_hip(_pipe(1, 128), inp, make_plugin("block"), strength=0.08)
-    cpu = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.08, device="cpu")
-    dev = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.08, device=DEV)
-    assert len(cpu["trace"]) == len(dev["trace"]) == len(hip["trace"]) == 2
+    hip = run_hip(_pipe(1, 128), inp, make_plugin("block"), strength=0.04)
+    cpu = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.04, device="cpu")
+    dev = run_ref(inp, hip["noises"], make_plugin("block"), strength=0.04, device=DEV)
+    assert len(cpu["trace"]) == len(dev["trace"]) == len(hip["trace"]) == 1
     assert _rel(dev["latents"], cpu["latents"]) <= 1e-4
     for c, d, h in zip(cpu["trace"], dev["trace"], hip["trace"]):
         assert iou(c["mask"][0], d["mask"][0]) >= 0.999 and iou(c["mask"][0], h["mask"][0]) >= MASK_IOU
@@ -108,8 +108,8 @@ def test_adaptive_loop_49_steps_matches_restatement(hip_lib, fp32_strict, B):
     del pipe
     torch.cuda.empty_cache()
     # every image of the batch goes through the bit-exact glue check; the fp32 restatement (25 s per image and loop on the device) runs
-    # for three of the eight images of the B = 8 case -- the images of a batch are independent, each has its own noise stream and mask
-    idx = list(range(B)) if B == 1 else [0, 3, 6]
+    # for two of the eight images of the B = 8 case -- the images of a batch are independent, each has its own noise stream and mask
+    idx = list(range(B)) if B == 1 else [0, 6]
     _check_glue_exact(inp, hip, B)
     sub = take(inp, idx)
     ref = run_ref(sub, [n[idx] for n in hip["noises"]], make_plugin("block"), strength=0.98, device=DEV)
