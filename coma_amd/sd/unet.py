@@ -51,7 +51,8 @@ class HipUNet2DConditionModel:
         self.heads = cfg["heads"]
         self.ctx_dim = cfg["cross_attention_dim"]
         self.use_graph = use_graph
-        self.fold_layernorm = fold_layernorm
+        self.fold_layernorm = fold_layernorm or os.environ.get("SD_LN_FOLD", "0") != "0"
+        self.fold_min_c = int(os.environ.get("SD_LN_FOLD_MIN_C", 0))    # A/B: fold only from this width (the C = 320 blocks have their row-tile kernels)
         self.fuse_xchain = fuse_xchain      # C = 320 blocks: attn1.to_out ... norm3 in one launch (sd_xattn_chain_f16)
         self.fuse_xfront = fuse_xfront      # C = 320 blocks: norm, proj_in, norm1, to_q | to_k, to_v^T in one launch (sd_xfront_f16)
         self.fuse_qkv = fuse_qkv            # C = 640 / 1280 blocks: to_q | to_k | to_v one GEMM, V^T written transposed by its epilogue (sd_conv_gemm_desc.out_t)
@@ -245,7 +246,7 @@ class HipUNet2DConditionModel:
         # The three LayerNorms are folded into the GEMMs that consume them (weights.ln_fold): their inputs' row statistics
         # come out of the producing GEMM's epilogue, (mean, rstd) from a tiny finalise launch, and the normalised tensors are
         # never written.  Tiny feature maps keep the LayerNorm kernel: their producers want split-K, which has no statistics.
-        fold = self.fold_layernorm and M >= self.fold_min_rows
+        fold = self.fold_layernorm and M >= self.fold_min_rows and C >= self.fold_min_c
         wqk = torch.cat([s[t + ".attn1.to_q.weight"], s[t + ".attn1.to_k.weight"]]).contiguous()
         wv = s[t + ".attn1.to_v.weight"]
         h = g.buf(M, C)

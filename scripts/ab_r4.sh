@@ -1,3 +1,6 @@
 #!/bin/bash
-python -m pytest tests/test_sd_adaptive_gpu.py -m gpu -q --durations=5 2>&1 | tail -9
-for b in 8 4 2; do python scripts/time_vae.py $b 2>&1 | grep -E "decoder|encoder"; done
+for i in 1 2; do
+  echo -n "base                "; python scripts/time_unet.py 16 20 --shared 2>&1 | tail -1
+  echo -n "LN fold from C=640  "; SD_LN_FOLD=1 SD_LN_FOLD_MIN_C=640 python scripts/time_unet.py 16 20 --shared 2>&1 | tail -1
+  echo -n "LN fold from C=1280 "; SD_LN_FOLD=1 SD_LN_FOLD_MIN_C=1280 python scripts/time_unet.py 16 20 --shared 2>&1 | tail -1
+done
