@@ -1,16 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of ComA's dense hot path on MI355X (contract: see the round brief).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload contact|occupancy]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload inpaint|contact]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-  contact   (default): the fused K1-K3 accumulator over S samples of H=10475 SMPL-X vertices x O=180 object
-            points x N=250 orientation bins per GPU (BASELINE.json config 4, per-GPU slice), followed -- when
-            N_gpus > 1 -- by the RCCL all-reduce(SUM) of the ComA state (2*H*O*N + 3*H*O floats), i.e. one
-            complete "learn a ComA from S*N_gpus samples" job per step.  Weak scaling: S per GPU is fixed.
-  occupancy : K5 splat of S samples at H=10475, R=128 rows sharded across ranks + K6 reduce + all-reduce(MAX).
-Rank 0 prints ONE JSON line.  `value` = vertex-pair contacts/s summed over all GPUs.
+Both forms work for N > 1: started as a plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) the script re-executes
+itself under torch.distributed.run with one rank per GPU (the fan-out the reference does with one process per GPU,
+scripts/generation/inpaint.sh:205-268 of the reference); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.
+
+Primary workload (`metric` / `value`, BASELINE.json config 2): SD-1.5 inpaint 512 x 512, 50 DDIM steps, batch 8 images per GPU
+(UNet batch 16 with classifier-free guidance), fixed mask.  One "step" = one whole image batch with inputs resident in HBM:
+masked-image VAE encode, 50 x (UNet hipGraph + CFG / DDIM kernel), VAE decode to uint8.  `value` = images/s summed over all ranks
+(weak scaling: independent image batches, no data-path collective), time = MAX over ranks between two barrier + synchronize pairs.
+Further sections on the same line, every rank taking part (only rank 0 prints):
+  secondary        ComA K1-K3 accumulation at config 4's per-GPU slice (H=10475 x O=180 x N=250 bins, 64 samples per step), K steps and
+                   then ONE all-reduce(SUM) of the state when N > 1 (timed inside, reported as final_allreduce_ms)
+  occupancy        config 5's per-GPU row share (H=1310, R=128, S=2000) through the fused pass + all-reduce(MAX) when N > 1
+  adaptive_loop    config 3's shape: the full adaptive-mask loop (49 steps, 21 re-estimations) at batch 8, synthetic mask plug-in
+  adaptive_loop_b1 the same, one image per pipeline call (the reference's own call shape)
+  roofline         conv / linear GEMM family of one UNet forward: algorithmic flops / HIP-event time against the 2.5 PF dense MFMA peak
+  cpu_baseline     the oracle restatements timed on the host cores (N = 1 only; bounded samples, stated)
+`--workload contact` swaps primary and secondary.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -423,10 +433,24 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50, help="only for profiling runs; the metric is defined at 50")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on a free local port
+        # (the form the driver uses for N = 1 must also work for N > 1); the children see WORLD_SIZE and take the branch below
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("COMA_BENCH_PRINT_LAUNCH") == "1":       # CPU test hook: show the launcher command instead of running it
+            print(json.dumps(cmd))
+            return
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # COMA_BENCH_SHARED_DEVICE=1: control-flow test of the N>1 path on a 1-GPU box (all ranks on cuda:0, gloo instead of
     # RCCL, which refuses two ranks on one device); never set by the driver
     shared = os.environ.get("COMA_BENCH_SHARED_DEVICE") == "1"

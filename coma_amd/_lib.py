@@ -46,7 +46,6 @@ SIGNATURES = {
     "sd_debug_timestamps": (_i, [_vp, _i]),
     "sd_groupnorm_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp]),
     "sd_groupnorm_colstats_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
-    "sd_ln_rowstats_finalize": (_i, [_vp, _i64, _i, _i, _f, _vp, _vp]),
     "sd_layernorm_f16": (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp]),
     "sd_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sd_attention_wide_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),

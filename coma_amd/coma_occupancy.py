@@ -329,8 +329,11 @@ class ComA_Occupancy:
         to_export = {k: v for k, v in vars(self).items() if k not in ("cache", "used") and not k.startswith("_")}
         self._materialize()
         to_export["spatial_occupancy_grids"] = self._grid
-        to_export = {k: (v if isinstance(v, torch.Tensor) else deepcopy(v)) for k, v in to_export.items()}
-        to_export = to_np_torch_recursive(to_export, use_torch=False, device="cpu")      # .cpu().numpy(): already a copy of every tensor
+        # device tensors are copied by .cpu().numpy() below (no 11 GB device-side clone first); a tensor that already lives on the CPU
+        # would be aliased by .numpy(), so it is cloned here
+        to_export = {k: ((v.detach().clone() if v.device.type == "cpu" else v) if isinstance(v, torch.Tensor) else deepcopy(v))
+                     for k, v in to_export.items()}
+        to_export = to_np_torch_recursive(to_export, use_torch=False, device="cpu")
         if shard is not None:
             from .dist import shard_slice
             rank, world, total = (int(x) for x in shard)

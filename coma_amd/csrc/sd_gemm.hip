@@ -67,13 +67,7 @@ struct GemmArgs {
   int ksplit;                 // >1: blockIdx.z selects a K range and fp32 partials go to `partial`
   float* partial;             // [ksplit][M][N] fp32
   long long sa, sw, so, sr;   // per-blockIdx.z strides in elements (batched mode, ksplit == 1)
-  long long sln;              // ... of ln_stats, in floats
   unsigned long long* dbg;    // nullptr unless SD_GEMM_DBG is set
-  // LayerNorm folded into this GEMM (see sd_conv_gemm_desc): out = rstd * (acc - mean * colsum) + bias, statistics per A row
-  // (or per output column with SD_EPI_BIAS_ROWS: the normalised tensor is then the W operand)
-  const float* ln_stats;      // [rows][2] = (mean, rstd)
-  const float* ln_colsum;     // [N] (or [M] with SD_EPI_BIAS_ROWS): sum_k (gamma o W)[n, k]
-  float* rowstats;            // producer side: [N/32][M][2] per-row (sum, sum of squares) of every stored 32-column tile
   _Float16* out_t;            // optional: columns >= n_split leave transposed per sample, keys in the PERM16 order (sd_conv_gemm_desc.out_t)
   int n_split, ldo_t, rps;
   // Sub-pixel phase of `conv3x3(nearest-upsample-x2(x))` (sd_conv_gemm_desc.phase): taps = 4 is a 2 x 2 window over the SOURCE whose origin
@@ -99,13 +93,8 @@ __device__ __forceinline__ int kappa16(int j) { return (j & ~12) | ((j & 4) << 1
 // SD_EPI_PERM32_N: position p = 8g + e of every group of 32 columns holds key 16 (e >> 2) + 4g + (e & 3)
 __device__ __forceinline__ int kappa32(int p) { return (p & ~28) | (((p >> 3) & 3) << 2) | (((p >> 2) & 1) << 4); }
 
-// Shared epilogue math: v = acc (folded LayerNorm)(+bias)(+per-batch bias) -> SiLU -> (+residual)
-__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int row, int col, const _Float16* resp, const float* lnst) {
-  if (lnst) {
-    const bool by_col = (g.epi & SD_EPI_BIAS_ROWS) != 0;
-    const int si = by_col ? ((g.epi & SD_EPI_PERM16_N) ? min(kappa16(col), g.n_valid - 1) : col) : row;
-    v = lnst[2 * si + 1] * (v - lnst[2 * si] * g.ln_colsum[by_col ? row : col]);
-  }
+// Shared epilogue math: v = acc (+bias)(+per-batch bias) -> SiLU -> (+residual)
+__device__ __forceinline__ float epilogue_value(const GemmArgs& g, float v, int row, int col, const _Float16* resp) {
   if (g.bias) v += (float)g.bias[(g.epi & SD_EPI_BIAS_ROWS) ? row : col];
   if (g.bias_bn) v += (float)g.bias_bn[(long long)(row / g.rows_per_batch) * g.ldbb + col];
   if (g.epi & SD_EPI_SILU) v = silu(v);
@@ -132,13 +121,11 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 // Epilogue shared by every kernel of the family: acc[2][TN] (MFMA C layout, see below) -> bias / per-sample bias / SiLU /
 // residual / GEGLU / GroupNorm column statistics -> fp16 output (or fp32 split-K slab), staged through LDS per wave.
-// LNX = true: the variant for GEMMs that fold a LayerNorm (ln_stats) or leave row statistics for one (rowstats); it carries no
-// GroupNorm column statistics, and vice versa -- the two sets of live registers never have to fit next to the accumulators together.
 // accq(i, j, q) = the q-th register quad of output tile (i, j) of this wave: four consecutive columns starting at column qcol(q) of row
 // qrow(q) of the tile.  32x32x16 MFMAs (M16 = false): row = lane & 31, column 8 q + 4 (lane >> 5).  16x16x32 MFMAs (M16 = true): quad
 // q = 2 a + b is sub-tile (a, b): row 16 a + (lane & 15), column 16 b + 4 (lane >> 4).  Everything after the staging write works on the
 // row-major read-back and does not care.
-template <int WM, int WN, int TN, int TM, bool LNX, bool M16, class AccQ>
+template <int WM, int WN, int TN, int TM, bool M16, class AccQ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Float16* lds, const int m0, const int n0,
                                               const int wave, const int lane, const long long z, const bool split) {
   constexpr int EP_STRIDE = 32 + 4;                 // floats per staged row (one 32x32 MFMA tile per wave at a time)
@@ -211,10 +198,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
   }
   _Float16* outp = g.out + z * g.so;
   const _Float16* resp = g.res ? g.res + z * g.sr : nullptr;
-  const float* lnst = g.ln_stats ? g.ln_stats + z * g.sln : nullptr;
   const bool geglu = (g.epi & SD_EPI_GEGLU) != 0;
-  // (a per-row bias is only vectorised in the LNX variant, where V^T = Wv . LN(x)^T needs it; elsewhere it takes the generic path)
-  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && ((LNX && TN <= 2) || !(g.epi & SD_EPI_BIAS_ROWS)) &&
+  // (a per-row bias takes the generic path)
+  const bool vec_ok = (g.ldo % 8 == 0) && (g.N % 8 == 0) && (!resp || g.ldr % 8 == 0) && !(g.epi & SD_EPI_BIAS_ROWS) &&
                       (!g.bias_bn || (g.rows_per_batch % 32 == 0 && g.ldbb % 8 == 0));
   // read-back role: 32 rows x 4 chunks of 8 columns = 128 items, two per lane; the column chunk is fixed per lane
   const int cl = (lane & 3) * 8;
@@ -237,29 +223,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
           hbg[p][q] = half4{0, 0, 0, 0};
           if (g.bias) { hbv[p][q] = *reinterpret_cast<const half4*>(g.bias + c); hbg[p][q] = *reinterpret_cast<const half4*>(g.bias + c + 32); }
         }
-      float ln_mu[TM][2], ln_r[TM][2];                       // folded LayerNorm: this lane's row(s) of each tile (two with M16)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          ln_mu[i][a] = 0.0f;
-          ln_r[i][a] = 1.0f;
-          if (LNX && g.ln_stats) {
-            const int rr = min(m0 + wr * (TM * 32) + i * 32 + qrow(2 * a), g.M - 1);
-            ln_mu[i][a] = lnst[2 * rr];
-            ln_r[i][a] = lnst[2 * rr + 1];
-          }
-        }
 #pragma unroll
       for (int p = 0; p < P; ++p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float4 sv = {0, 0, 0, 0}, sg = {0, 0, 0, 0};
-          if (LNX && g.ln_stats) {
-            const int c = ncolw + p * 64 + qcol(q);
-            sv = *reinterpret_cast<const float4*>(g.ln_colsum + c);
-            sg = *reinterpret_cast<const float4*>(g.ln_colsum + c + 32);
-          }
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             half4 o;
@@ -268,13 +235,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
             for (int e = 0; e < 4; e += 2) {
               f32x2 av = e == 0 ? (f32x2){qv.x, qv.y} : (f32x2){qv.z, qv.w};
               f32x2 ag = e == 0 ? (f32x2){qg.x, qg.y} : (f32x2){qg.z, qg.w};
-              if (LNX && g.ln_stats) {
-                const f32x2 cv = e == 0 ? (f32x2){sv.x, sv.y} : (f32x2){sv.z, sv.w};
-                const f32x2 cg = e == 0 ? (f32x2){sg.x, sg.y} : (f32x2){sg.z, sg.w};
-                const int a = M16 ? (q >> 1) : 0;
-                av = ln_r[i][a] * (av - ln_mu[i][a] * cv);
-                ag = ln_r[i][a] * (ag - ln_mu[i][a] * cg);
-              }
               const f32x2 r = (av + (f32x2){(float)hbv[p][q][e], (float)hbv[p][q][e + 1]}) *
                               gelu_erf2(ag + (f32x2){(float)hbg[p][q][e], (float)hbg[p][q][e + 1]});
               o[e] = (_Float16)r.x;
@@ -305,7 +265,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
   // 32-bit row offset per lane for the whole epilogue, the tile position in the scalar offset, rows >= M dropped by the
   // range check -- no 64-bit address arithmetic and few live registers next to the 32 * TN accumulators.
   constexpr int NT = TM * TN;                           // 32 x 32 tiles of this wave, j-major (column tile), i-minor
-  constexpr int DEPTH = NT <= 4 ? NT : (TN >= 5 ? (LNX && TM >= 2 ? 1 : 2) : 4);
+  constexpr int DEPTH = NT <= 4 ? NT : (TN >= 5 ? 2 : 4);
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   auto rsrc_of = [](const void* p, long long bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -330,7 +290,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
       voff_pre[k] = ((rowbase + 16 * k) * ld_pre + colbase) * 2;
     }
     int voff_ph[TM][2];                                          // sub-pixel phase: the rows of a tile are not equally spaced in `out`
-    const bool phase_on = !LNX && g.phase != 0;                  // (never with a folded LayerNorm: those variants have no register to spare)
+    const bool phase_on = g.phase != 0;
     if (phase_on) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -339,13 +299,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
           const int row = rowbase + 16 * k + 32 * i;
           voff_ph[i][k] = row < g.M ? (int)((out_row(g, row) * g.ldo + colbase) * 2) : (int)0x80000000;
         }
-    }
-    float2 lnrow[TM][2];                                         // folded LayerNorm: (mean, rstd) of this lane's rows (j-invariant)
-    if (LNX && lnst && !(g.epi & SD_EPI_BIAS_ROWS)) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) lnrow[i][k] = *reinterpret_cast<const float2*>(lnst + 2 * min(rowbase + 16 * k + 32 * i, g.M - 1));
     }
     u32x4 pf[NT][2];                                             // residual rows (k = 0, 1) or, in [0], the per-sample bias
     auto prefetch = [&](const int t) {
@@ -366,13 +319,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
     for (int j = 0; j < TN; ++j) {
       half8 bcol = {0, 0, 0, 0, 0, 0, 0, 0};                        // kept packed: registers are scarce next to 32 * TN accumulators
       const bool oob = colbase + j * 32 + 8 > g.N;                // column chunk of this lane beyond N: loads give 0, stores are dropped
-      const bool row_bias = LNX && TN <= 2 && (g.epi & SD_EPI_BIAS_ROWS);   // (batched V^T projections only ever pick the 128-wide tiles)
-      if (g.bias && !oob && !row_bias) bcol = *reinterpret_cast<const half8*>(g.bias + colbase + j * 32);
-      float4 lnc0 = make_float4(0, 0, 0, 0), lnc1 = lnc0;        // column sums of the folded LayerNorm for this column tile
-      if (LNX && lnst && !row_bias && !oob) {
-        lnc0 = *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32);
-        lnc1 = *reinterpret_cast<const float4*>(g.ln_colsum + colbase + j * 32 + 4);
-      }
+      if (g.bias && !oob) bcol = *reinterpret_cast<const half8*>(g.bias + colbase + j * 32);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int t = TM * j + i;
@@ -392,35 +339,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
           const float4 x = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl);
           const float4 y = *reinterpret_cast<const float4*>(stage + rl * EP_STRIDE + cl + 4);
           float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-          if (LNX && g.ln_stats && row_bias) {
-            // the normalised tensor is the W operand (V^T = Wv . LN(x)^T): statistics per output column (= key; with
-            // SD_EPI_PERM16_N column j holds key kappa(j): the 8 columns of this lane are two runs of 4 keys), colsum per row
-            const int rr = min(rowbase + 16 * k + 32 * i, g.M - 1);
-            const float srow = g.ln_colsum[rr];
-            const int c0 = colbase + j * 32;
-            int k0 = c0, k1 = c0 + 4;
-            if (g.epi & SD_EPI_PERM16_N) { k0 = (c0 & ~15) + ((c0 & 8) ? 4 : 0); k1 = k0 + 8; }
-            float2 stc[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              stc[e] = *reinterpret_cast<const float2*>(lnst + 2 * min(k0 + e, g.n_valid - 1));
-              stc[4 + e] = *reinterpret_cast<const float2*>(lnst + 2 * min(k1 + e, g.n_valid - 1));
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = stc[e].y * (v[e] - stc[e].x * srow);
-          } else if (LNX && g.ln_stats) {                         // folded LayerNorm of the A operand
-            const float2 st = lnrow[i][k];
-            const float sc[8] = {lnc0.x, lnc0.y, lnc0.z, lnc0.w, lnc1.x, lnc1.y, lnc1.z, lnc1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = st.y * (v[e] - st.x * sc[e]);
-          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)bcol[e];
-          if (row_bias && g.bias) {
-            const float br = (float)g.bias[min(rowbase + 16 * k + 32 * i, g.M - 1)];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += br;
-          }
           if (g.bias_bn) {
             const half8 tb = __builtin_bit_cast(half8, pf[t][0]);
 #pragma unroll
@@ -440,25 +360,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
           for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
           if (phase_on) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rsrc, oob ? (int)0x80000000 : voff_ph[i][k], j * 64, 0);
           else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rsrc, oob ? (int)0x80000000 : voff_out[k], soff_out, 0);
-          if (LNX && g.rowstats) {
-            // statistics of the consumer's LayerNorm: (sum, sum of squares) of this row over the 32 columns of the tile, from
-            // the stored (fp16-rounded) values; the four lanes of a row fold by two quad permutes, lane & 3 == 0 writes
-            float rs = 0.0f, rq = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float f = (float)o[e];
-              rs += f;
-              rq += f * f;
-            }
-            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0xb1, 0xf, 0xf, false));
-            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x4e, 0xf, 0xf, false));
-            const int row = rowbase + 16 * k + 32 * i;
-            if ((lane & 3) == 0 && row < g.M && colbase + j * 32 < g.N)
-              *reinterpret_cast<float2*>(g.rowstats + ((long long)((colbase + j * 32) >> 5) * g.M + row) * 2) = make_float2(rs, rq);
-          }
-          if (!LNX && g.colstats && !oob && m0 + wr * (TM * 32) + i * 32 + rl < g.M) {
+          if (g.colstats && !oob && m0 + wr * (TM * 32) + i * 32 + rl < g.M) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float f = (float)o[e];     // statistics of the stored (fp16-rounded) tensor, as a GroupNorm pass would see it
@@ -467,7 +369,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
             }
           }
         }
-        if (!LNX && g.colstats) {
+        if (g.colstats) {
           // fold the 16 lanes that share a column chunk (lane & 3 fixed), fixed order -> reproducible: lanes +4, +8, +12 of
           // the 16-lane row by two DPP row rotations (VALU speed), then the four rows by two cross-lane exchanges
 #pragma unroll
@@ -557,7 +459,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
         } else {
           for (int e = 0; e < 8; ++e)
             if (col + e < g.N)
-              outp[out_row(g, row) * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp, lnst);
+              outp[out_row(g, row) * g.ldo + col + e] = (_Float16)epilogue_value(g, v[e], row, col + e, resp);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -575,7 +477,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, AccQ accq, _Flo
 //        cycles per wave instruction and NOT overlapped with MFMA issue, the limiter of the 128 x 128 tile (0.5 DMA per
 //        MFMA) -- drops to 0.225 DMA per MFMA.
 //   <WM=2, WN=1/2, ...> 64-wide fallbacks for small N.
-template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false, int TM = 2, bool LNX = false, bool M16 = false>
+template <int WM, int WN, int TN, int BK, int STAGES, bool SPREAD = false, int TM = 2, bool M16 = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per block
   constexpr int BM_ = WM * TM * 32, BN = WN * TN * 32;
@@ -908,12 +810,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_gemm_kernel(GemmArgs g) {
   dbg_stamp(g, 2);
 
   if constexpr (M16) {
-    gemm_epilogue<WM, WN, TN, TM, LNX, true>(g, [&](int i, int j, int q) {
+    gemm_epilogue<WM, WN, TN, TM, true>(g, [&](int i, int j, int q) {
       const float4v v = acc16[2 * i + (q >> 1)][2 * j + (q & 1)];
       return make_float4(v[0], v[1], v[2], v[3]);
     }, lds, m0, n0, wave, lane, z, split);
   } else {
-    gemm_epilogue<WM, WN, TN, TM, LNX, false>(g, [&](int i, int j, int q) {
+    gemm_epilogue<WM, WN, TN, TM, false>(g, [&](int i, int j, int q) {
       return make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
     }, lds, m0, n0, wave, lane, z, split);
   }
@@ -938,7 +840,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
   half8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (_Float16)epilogue_value(g, v[j], row, col0 + j, g.res, g.ln_stats);
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)epilogue_value(g, v[j], row, col0 + j, g.res);
   *reinterpret_cast<half8*>(g.out + (long long)row * g.ldo + col0) = o;
 }
 
@@ -961,16 +863,15 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
     const sd_conv_gemm_desc& d = *d_in;
     sd::PlanRec r{};
     r.kind = sd::PK_CONV;
-    void* ps[13] = {(void*)d.a0, (void*)d.a1, (void*)d.w, (void*)d.bias, (void*)d.bias_bn, (void*)d.res, d.out, d.workspace, d.colstats,
-                    (void*)d.ln_stats, (void*)d.ln_colsum, d.rowstats, d.out_t};
-    for (int k = 0; k < 13; ++k) r.p[k] = ps[k];
-    const int64_t is[23] = {d.c0, d.c1, d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.taps, d.stride, d.upsample, d.pad, d.n, d.ldbb, d.ldr, d.ldo,
-                            d.epi, d.nbatch_z, d.stride_a, d.stride_w, d.stride_out, d.stride_res, (int64_t)d.workspace_bytes, d.stride_ln_stats};
-    for (int k = 0; k < 23; ++k) r.i[k] = is[k];
+    void* ps[10] = {(void*)d.a0, (void*)d.a1, (void*)d.w, (void*)d.bias, (void*)d.bias_bn, (void*)d.res, d.out, d.workspace, d.colstats, d.out_t};
+    for (int k = 0; k < 10; ++k) r.p[k] = ps[k];
+    const int64_t is[22] = {d.c0, d.c1, d.batch, d.in_h, d.in_w, d.out_h, d.out_w, d.taps, d.stride, d.upsample, d.pad, d.n, d.ldbb, d.ldr, d.ldo,
+                            d.epi, d.nbatch_z, d.stride_a, d.stride_w, d.stride_out, d.stride_res, (int64_t)d.workspace_bytes};
+    for (int k = 0; k < 22; ++k) r.i[k] = is[k];
     if (d.out_t && (d.n_split < 0 || d.n_split >= (1 << 20) || d.ldo_t < 0 || d.ldo_t >= (1 << 20) || d.rows_per_sample < 0 || d.rows_per_sample >= (1 << 20)))
       return sd::fail(COMA_E_INVALID, "sd_conv_gemm_f16: out_t sizes out of range");
     if (d.phase < 0 || d.phase > 4) return sd::fail(COMA_E_INVALID, "sd_conv_gemm_f16: phase must be 0..4");
-    r.i[23] = (int64_t)d.n_split | ((int64_t)d.ldo_t << 20) | ((int64_t)d.rows_per_sample << 40) | ((int64_t)d.phase << 60);    // three 20-bit fields + the phase
+    r.i[22] = (int64_t)d.n_split | ((int64_t)d.ldo_t << 20) | ((int64_t)d.rows_per_sample << 40) | ((int64_t)d.phase << 60);    // three 20-bit fields + the phase
     return sd::plan_record(r);
   }
   if (!d_in) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: null descriptor");
@@ -1016,7 +917,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   if (phase) {
     // sub-pixel phase of conv3x3(nearest-upsample-x2(x)): a 2 x 2 window over the source, rows scattered to the output pixels of that parity
     if (d->taps != 4 || d->stride != 1 || d->upsample || d->out_h != d->in_h || d->out_w != d->in_w || (d->in_w & (d->in_w - 1)) ||
-        (d->nbatch_z > 1) || d->res || d->bias_bn || d->rowstats || d->ln_stats || d->out_t || (d->epi & ~SD_EPI_TUNING_MASK) || d->n % 8 ||
+        (d->nbatch_z > 1) || d->res || d->bias_bn || d->out_t || (d->epi & ~SD_EPI_TUNING_MASK) || d->n % 8 ||
         (d->ldo > 0 && d->ldo % 8))
       return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a phase launch needs taps = 4, stride 1, out = in size, in_w a power of two, n %% 8 == 0 and "
                                   "a plain epilogue (bias, optional colstats)");
@@ -1065,7 +966,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
     if ((d->epi & SD_EPI_GEGLU) || d->res || d->bias_bn || d->colstats) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: SD_EPI_PERM16_N takes no GEGLU / residual / per-sample bias / colstats");
   }
   if (d->epi & SD_EPI_PERM32_N) {
-    if ((d->epi & (SD_EPI_PERM16_N | SD_EPI_GEGLU)) || d->n % 32 || d->res || d->bias_bn || d->colstats || d->ln_stats || d->rowstats)
+    if ((d->epi & (SD_EPI_PERM16_N | SD_EPI_GEGLU)) || d->n % 32 || d->res || d->bias_bn || d->colstats)
       return fail(COMA_E_INVALID, "sd_conv_gemm_f16: SD_EPI_PERM32_N needs n %% 32 == 0 and takes no other column-dependent epilogue");
   }
   g.w = (const _Float16*)d->w; g.bias = (const _Float16*)d->bias; g.bias_bn = (const _Float16*)d->bias_bn;
@@ -1085,7 +986,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   // ... or z-batched plain products whose tiles fill it together (the 16 plane products of a Winograd convolution at the 16 x 16 level:
   // 4 x 4 tiles x 16 planes = one block per CU, where the generic 128 x 128 tile needs 2.5 rounds; SD_GEMM_ZBIG=0 switches it off for A/B)
   static const bool zbig_on = !getenv("SD_GEMM_ZBIG") || atoi(getenv("SD_GEMM_ZBIG")) != 0;
-  const bool zplain = nz > 1 && zbig_on && d->taps == 1 && !d->colstats && !d->rowstats && !d->ln_stats && !d->out_t &&
+  const bool zplain = nz > 1 && zbig_on && d->taps == 1 && !d->colstats && !d->out_t &&
                       !(d->epi & ~SD_EPI_TUNING_MASK);
   const bool big = !geglu && (nz == 1 || zplain) && k64 && g.N % 320 == 0 && (long long)((g.M + 255) / 256) * (g.N / 320) * nz >= 192 &&
                    !(d->epi & ((1 << 20) | (1 << 21)));
@@ -1103,7 +1004,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   // ... and, split in two along K, for the deep 3x3 convs at 16 x 16 (M = 4096, N = 1280, K >= 11520): 32 x 4 tiles x 2 splits = one
   // block per CU, where 128 x 128 tiles leave 320 blocks for 512 slots (+4 % at K = 11520, +15 % at K = 23040, profiles/r02_notes.md 12)
   const bool midsk = !big && !geglu && nz == 1 && k64 && g.N % 320 == 0 && g.N >= 1280 && g.M >= 4096 && g.M < 128 * 64 && g.K >= 8192 &&
-                     !d->colstats && !d->rowstats && d->workspace && d->workspace_bytes >= (size_t)2 * g.M * g.N * sizeof(float) &&
+                     !d->colstats && d->workspace && d->workspace_bytes >= (size_t)2 * g.M * g.N * sizeof(float) &&
                      (long long)((g.M + 127) / 128) * (g.N / 320) * 2 <= 256 && !(d->epi & ((1 << 20) | (1 << 21)));
   const bool mid = (!big && !big256 && !big128 && !geglu && nz == 1 && g.N % 320 == 0 && (g.M >= 128 * 64 || (d->epi & (1 << 21))) &&
                     (g.N <= 640 || (d->epi & (1 << 21))) && !(d->epi & (1 << 20))) || midsk;
@@ -1123,10 +1024,9 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   if (dbg_on) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dbg_stamps)) == hipSuccess) g.dbg = (unsigned long long*)p; }
   g.partial = (float*)d->workspace;
   g.colstats = (float*)d->colstats;
-  g.ln_stats = d->ln_stats; g.ln_colsum = d->ln_colsum; g.rowstats = d->rowstats; g.sln = d->stride_ln_stats;
   g.out_t = (_Float16*)d->out_t; g.n_split = d->n_split; g.ldo_t = d->ldo_t; g.rps = d->rows_per_sample;
   if (g.out_t) {
-    if (geglu || nz != 1 || d->taps != 1 || d->c1 > 0 || d->bias || d->bias_bn || d->res || d->colstats || d->rowstats || d->ln_stats ||
+    if (geglu || nz != 1 || d->taps != 1 || d->c1 > 0 || d->bias || d->bias_bn || d->res || d->colstats ||
         (d->epi & ~SD_EPI_TUNING_MASK) || d->n_split <= 0 || d->n_split % 640 || (d->n - d->n_split) <= 0 || (d->n - d->n_split) % 640 ||
         g.M % 32 || d->rows_per_sample <= 0 || d->rows_per_sample % 32 || g.M % d->rows_per_sample || d->ldo_t % 8 || d->ldo_t < d->rows_per_sample ||
         g.ldo < d->n_split || g.ldo % 8)
@@ -1134,12 +1034,6 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
                                   "n - n_split multiples of 640, M and rows_per_sample multiples of 32, ldo >= n_split, ldo_t >= rows_per_sample, both % 8 == 0");
     if (d->n_split % bn) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: out_t: the %d-column tile of this shape does not divide n_split = %d", bn, d->n_split);
   }
-  if ((g.ln_stats == nullptr) != (g.ln_colsum == nullptr)) return fail(COMA_E_INVALID, "sd_conv_gemm_f16: ln_stats and ln_colsum come together");
-  if (g.ln_stats && (d->bias_bn || d->colstats || d->c1 > 0 || d->taps != 1))
-    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: a folded LayerNorm needs a single-source 1x1 / linear GEMM without per-sample bias / colstats");
-  if (g.rowstats && (geglu || nz != 1 || d->n % 32 || (d->epi & (SD_EPI_BIAS_ROWS | SD_EPI_PERM16_N)) || d->bias_bn || g.ldo % 8 || (g.res && g.ldr % 8) ||
-                     (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL || (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
-    return fail(COMA_E_INVALID, "sd_conv_gemm_f16: rowstats needs N %% 32 == 0, 16-byte aligned rows, < 2 GiB tensors, no GEGLU / batching / row bias");
   if (g.colstats && (geglu || nz != 1 || g.M % 32 || g.N % 8 || (d->epi & SD_EPI_BIAS_ROWS) || g.ldo % 8 || (g.res && g.ldr % 8) ||
                      (g.bias_bn && (g.res || g.rows_per_batch % 32 || g.ldbb % 8)) || (long long)(g.M + 512) * g.ldo * 2 >= 0x7fffffffLL ||
                      (g.res && (long long)(g.M + 512) * g.ldr * 2 >= 0x7fffffffLL)))
@@ -1152,7 +1046,7 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   const long long blocks = (long long)gx * gy;
   const int nk = g.K / bk;
   const int min_tiles = 384 / bk;
-  if (!phase && !g.colstats && !g.rowstats && !g.out_t && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
+  if (!phase && !g.colstats && !g.out_t && !big && !big256 && !big128 && nz == 1 && !geglu && d->workspace && blocks < 200 && nk >= 2 * min_tiles && g.N % 8 == 0 && g.ldo % 8 == 0) {
     int s = (int)((mid8 ? 256 : 512) / blocks);         // the 8-wave 128 x 320 tile is resident once per CU, the others twice
     if (s > nk / min_tiles) s = nk / min_tiles;
     if (s > 16) s = 16;
@@ -1170,18 +1064,15 @@ extern "C" int sd_conv_gemm_f16(const sd_conv_gemm_desc* d_in, void* stream) {
   const bool spread = !(d->epi & (1 << 22)) && d->taps == 9;
 #define GEMM_LAUNCH(WM_, WN_, TN_, BK_, ST_, SP_, TM_, THREADS_)                                                                  \
   do {                                                                                                                           \
-    if (lnx) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, true>), grid, dim3(THREADS_), 0, st, g);    \
-    else if (m16) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, false, true>), grid, dim3(THREADS_), 0, st, g); \
+    if (m16) hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, true>), grid, dim3(THREADS_), 0, st, g);    \
     else hipLaunchKernelGGL((conv_gemm_kernel<WM_, WN_, TN_, BK_, ST_, SP_, TM_, false>), grid, dim3(THREADS_), 0, st, g);       \
   } while (0)
-  const bool lnx = g.ln_stats != nullptr || g.rowstats != nullptr;
   // 16x16x32 MFMAs in the K loop of every launch with K >= 256 (measured inside the captured graphs, A B A B: UNet forward -0.2 ms from the
   // 3x3 convolutions -- the power-limited ones -- and another -0.45 ms from the 1x1 / linear launches, most of it at K = 320; VAE decode
-  // -0.65 ms).  SD_GEMM_M16 / SD_GEMM_M16_1X1 = <minimum K, 0 = off> override the rule for A/B runs; the LayerNorm-folding variants
-  // (optional, off by default) keep 32x32x16.
+  // -0.65 ms).  SD_GEMM_M16 / SD_GEMM_M16_1X1 = <minimum K, 0 = off> override the rule for A/B runs.
   static const int m16_env = getenv("SD_GEMM_M16") ? atoi(getenv("SD_GEMM_M16")) : 256;
   static const int m16_1x1 = getenv("SD_GEMM_M16_1X1") ? atoi(getenv("SD_GEMM_M16_1X1")) : 256;
-  const bool m16 = !lnx && (d->taps == 9 ? (m16_env && g.K >= m16_env) : (m16_1x1 && g.K >= m16_1x1));
+  const bool m16 = (d->taps == 9 ? (m16_env && g.K >= m16_env) : (m16_1x1 && g.K >= m16_1x1));
   if (big && spread) GEMM_LAUNCH(4, 2, 5, 64, 2, true, 2, 512);
   else if (wide && deep && spread && !big_geglu && !big256 && !big128 && !mid) GEMM_LAUNCH(2, 2, 2, 64, 2, true, 2, 256);
   else if (big) GEMM_LAUNCH(4, 2, 5, 64, 2, false, 2, 512);

@@ -518,45 +518,6 @@ extern "C" int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale,
   return check_launch("softmax_kernel");
 }
 
-namespace sd {
-// (mean, rstd) per row from the [parts][rows][2] partial sums the producing GEMM left behind (fixed summation order)
-__global__ __launch_bounds__(256) void ln_rowstats_finalize_kernel(const float* __restrict__ partial, long long rows, int parts, float inv_c,
-                                                                   float eps, float* __restrict__ stats) {
-  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (r >= rows) return;
-  const float2* p = reinterpret_cast<const float2*>(partial) + r;      // [parts][rows]: neighbouring threads read neighbouring rows
-  float s = 0.0f, q = 0.0f;
-  int i = 0;
-  for (; i + 4 <= parts; i += 4) {                  // four independent loads in flight, summed in index order
-    const float2 v0 = p[(long long)i * rows], v1 = p[(long long)(i + 1) * rows], v2 = p[(long long)(i + 2) * rows], v3 = p[(long long)(i + 3) * rows];
-    s = (((s + v0.x) + v1.x) + v2.x) + v3.x;
-    q = (((q + v0.y) + v1.y) + v2.y) + v3.y;
-  }
-  for (; i < parts; ++i) {
-    const float2 v = p[(long long)i * rows];
-    s += v.x;
-    q += v.y;
-  }
-  const float mean = s * inv_c;
-  const float var = fmaxf(q * inv_c - mean * mean, 0.0f);
-  reinterpret_cast<float2*>(stats)[r] = make_float2(mean, 1.0f / sqrtf(var + eps));
-}
-}  // namespace sd
-
-extern "C" int sd_ln_rowstats_finalize(const float* partial, int64_t rows, int parts, int c, float eps, float* stats, void* stream) {
-  if (sd::plan_recording()) {
-    sd::PlanRec r{};
-    r.kind = sd::PK_LN_STATS;
-    r.p[0] = (void*)partial; r.p[1] = stats; r.i[0] = rows; r.i[1] = parts; r.i[2] = c; r.f[0] = eps;
-    return sd::plan_record(r);
-  }
-  if (!partial || !stats) return coma::fail(COMA_E_INVALID, "sd_ln_rowstats_finalize: null pointer");
-  if (rows <= 0 || parts <= 0 || c != parts * 32) return coma::fail(COMA_E_INVALID, "sd_ln_rowstats_finalize: bad sizes rows=%lld parts=%d c=%d", (long long)rows, parts, c);
-  hipLaunchKernelGGL(sd::ln_rowstats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
-                     (long long)rows, parts, 1.0f / (float)c, eps, stats);
-  return coma::check_launch("ln_rowstats_finalize_kernel");
-}
-
 extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                                          const void* gamma, const void* beta, int silu, void* out, float* stats,
                                          const float* colstats0, const float* colstats1, void* stream) {

@@ -78,13 +78,13 @@ static int launch(const PlanRec& r, void* st) {
       sd_conv_gemm_desc d;
       memset(&d, 0, sizeof d);
       d.a0 = p[0]; d.a1 = p[1]; d.w = p[2]; d.bias = p[3]; d.bias_bn = p[4]; d.res = p[5]; d.out = p[6]; d.workspace = p[7];
-      d.colstats = (float*)p[8]; d.ln_stats = (const float*)p[9]; d.ln_colsum = (const float*)p[10]; d.rowstats = (float*)p[11];
+      d.colstats = (float*)p[8];
       d.c0 = (int)i[0]; d.c1 = (int)i[1]; d.batch = (int)i[2]; d.in_h = (int)i[3]; d.in_w = (int)i[4]; d.out_h = (int)i[5]; d.out_w = (int)i[6];
       d.taps = (int)i[7]; d.stride = (int)i[8]; d.upsample = (int)i[9]; d.pad = (int)i[10]; d.n = (int)i[11]; d.ldbb = (int)i[12];
       d.ldr = (int)i[13]; d.ldo = (int)i[14]; d.epi = (int)i[15]; d.nbatch_z = (int)i[16]; d.stride_a = i[17]; d.stride_w = i[18];
-      d.stride_out = i[19]; d.stride_res = i[20]; d.workspace_bytes = (size_t)i[21]; d.stride_ln_stats = i[22];
-      d.out_t = p[12]; d.n_split = (int)(i[23] & 0xfffff); d.ldo_t = (int)((i[23] >> 20) & 0xfffff); d.rows_per_sample = (int)((i[23] >> 40) & 0xfffff);
-      d.phase = (int)((i[23] >> 60) & 7);
+      d.stride_out = i[19]; d.stride_res = i[20]; d.workspace_bytes = (size_t)i[21];
+      d.out_t = p[9]; d.n_split = (int)(i[22] & 0xfffff); d.ldo_t = (int)((i[22] >> 20) & 0xfffff); d.rows_per_sample = (int)((i[22] >> 40) & 0xfffff);
+      d.phase = (int)((i[22] >> 60) & 7);
       return sd_conv_gemm_f16(&d, st);
     }
     case PK_GN:
@@ -93,8 +93,6 @@ static int launch(const PlanRec& r, void* st) {
     case PK_GN_COLSTATS:
       return sd_groupnorm_colstats_f16(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], p[2], p[3], (int)i[5],
                                        p[4], (float*)p[5], (const float*)p[6], (const float*)p[7], st);
-    case PK_LN_STATS:
-      return sd_ln_rowstats_finalize((const float*)p[0], i[0], (int)i[1], (int)i[2], (float)f[0], (float*)p[1], st);
     case PK_LN:
       return sd_layernorm_f16(p[0], i[0], (int)i[1], (float)f[0], p[1], p[2], p[3], st);
     case PK_ATTN:
@@ -188,17 +186,27 @@ extern "C" int sd_model_register_buffer(void* model, void* ptr, size_t bytes, in
   Model* m = as_model(model);
   char* lo = static_cast<char*>(ptr);
   char* hi = lo + bytes;
+  // SD_BUF_IF_NEW (what the recording hook passes for every tensor a launch touches): a range some entry already covers keeps that
+  // entry's flags -- scratch the owner registered with 0 / SD_BUF_ZEROED must not become part of a saved model just because a
+  // recorded launch points into it (a UNet at batch 16 would save GBs of activations) -- and anything else is a constant
+  // seen for the first time: registered SD_BUF_PERSISTENT.
+  if (flags & SD_BUF_IF_NEW) {
+    for (const Buffer& b : m->bufs)
+      if (lo >= b.ptr && hi <= b.ptr + b.bytes) return COMA_OK;
+    flags = (flags & ~SD_BUF_IF_NEW) | SD_BUF_PERSISTENT;
+  }
+  // validate before mutating: a range that straddles a buffer the model owns is refused with the registry untouched
+  for (const Buffer& b : m->bufs)
+    if (b.owned && lo < b.ptr + b.bytes && b.ptr < hi && !(lo >= b.ptr && hi <= b.ptr + b.bytes))
+      return fail(COMA_E_INVALID, "sd_model_register_buffer: range straddles a buffer the model owns");
   // Fold EVERY entry the range touches into one (a range bridging two entries must not leave overlapping entries behind) and OR
-  // the flags also when the range was already covered: a buffer first seen as scratch and later registered SD_BUF_PERSISTENT
-  // (constants Python filled outside a plan) must be saved with the model.  Anything filled outside a plan has to be registered
-  // PERSISTENT by its owner; a persistent sub-range makes the whole entry persistent (larger file, never a missing constant).
+  // the flags also when the range was already covered: a buffer first seen as scratch and later EXPLICITLY registered
+  // SD_BUF_PERSISTENT (constants Python filled outside a plan) must be saved with the model.  Anything filled outside a plan has to
+  // be registered PERSISTENT by its owner; a persistent sub-range makes the whole entry persistent (larger file, never a missing constant).
   for (size_t k = 0; k < m->bufs.size();) {
     Buffer& b = m->bufs[k];
     if (lo < b.ptr + b.bytes && b.ptr < hi) {
-      if (b.owned) {                          // library-allocated (loaded model): never merged away, it already covers what it must
-        if (lo >= b.ptr && hi <= b.ptr + b.bytes) { b.flags |= flags; return COMA_OK; }
-        return fail(COMA_E_INVALID, "sd_model_register_buffer: range straddles a buffer the model owns");
-      }
+      if (b.owned) { b.flags |= flags; return COMA_OK; }     // library-allocated (loaded model), range inside it (checked above)
       if (b.ptr < lo) lo = b.ptr;
       if (b.ptr + b.bytes > hi) hi = b.ptr + b.bytes;
       flags |= b.flags;
@@ -316,8 +324,8 @@ extern "C" int sd_model_replay(void* model, const char* plan_name, void* stream)
   return COMA_OK;
 }
 
-// ---- file format (little endian, version 2):
-//   "SDMODEL2" | u64 file_bytes | u64 checksum (FNV-1a over 64-bit words of everything after this 24-byte header)
+// ---- file format (little endian, version 3: the launch-record kinds / conv descriptor of r5 -- version 2 files carried LayerNorm-fold fields):
+//   "SDMODEL3" | u64 file_bytes | u64 checksum (FNV-1a over 64-bit words of everything after this 24-byte header)
 //   | u32 nbuf | { u64 bytes, u32 flags } x nbuf | u32 nbind | { char name[32], u32 buf, u64 offset, u64 bytes } x nbind
 //   | u32 nplans | { char name[32], u32 nrec, PlanRec x nrec with every non-null pointer rewritten as ((buf + 1) << 48) | offset }
 //   | the bytes of every SD_BUF_PERSISTENT buffer, in registry order
@@ -357,7 +365,7 @@ extern "C" int sd_model_save(const void* model, const char* path) {
   FILE* f = fopen(path, "wb");
   if (!f) return fail(COMA_E_INVALID, "sd_model_save: cannot open %s", path);
   const uint64_t zero2[2] = {0, 0};
-  bool ok = fwrite("SDMODEL2", 1, 8, f) == 8 && fwrite(zero2, 1, 16, f) == 16;      // size + checksum are patched in at the end
+  bool ok = fwrite("SDMODEL3", 1, 8, f) == 8 && fwrite(zero2, 1, 16, f) == 16;      // size + checksum are patched in at the end
   Writer w{f};
   const uint32_t nbuf = (uint32_t)m->bufs.size();
   w.put(&nbuf, 4);
@@ -411,7 +419,7 @@ extern "C" int sd_model_load(const char* path, void** model) {
   auto bail = [&](const char* what) { fclose(f); sd_model_destroy(m); return fail(COMA_E_INVALID, "sd_model_load: %s (%s)", what, path); };
   char magic[8];
   uint64_t header[2];
-  if (!rd(f, magic, 8) || memcmp(magic, "SDMODEL2", 8) || !rd(f, header, 16)) return bail("not a model file (or one of format version 1)");
+  if (!rd(f, magic, 8) || memcmp(magic, "SDMODEL3", 8) || !rd(f, header, 16)) return bail("not a model file (or one of an older format version)");
   {
     // first pass: the file must be exactly what sd_model_save wrote -- size and checksum -- before anything is allocated or trusted
     Hasher hs;

@@ -32,8 +32,6 @@ class LaunchGraph:
         self._gn_stats = None
         self._ws = None             # split-K workspace shared by every GEMM of the graph (launches are serial)
         self._colstats = {}         # data_ptr of a GEMM output -> its [M/32][2][N] column-sum buffer (GroupNorm statistics)
-        self._rowstats = {}         # data_ptr of a GEMM output -> its [M][N/32][2] row-sum buffer (LayerNorm statistics)
-        self._lnstats = {}          # data_ptr of a tensor -> [M][2] (mean, rstd) once finalised
         self.fuse_gn_stats = True
 
     # ---- memory
@@ -73,11 +71,6 @@ class LaunchGraph:
             cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
             kw["colstats"] = cs
             self._colstats[out.data_ptr()] = cs
-        # ... and the LayerNorm statistics of a transformer-block consumer from the same epilogue (never with split-K)
-        if kw.pop("rowstats", False):
-            rs = self.buf(n // 32, M, 2, dtype=torch.float32, zero=True)
-            kw["rowstats"] = rs
-            self._rowstats[out.data_ptr()] = rs
         self.add(lambda: ops.conv_gemm(a0, w, out, batch=batch, in_h=in_h, in_w=in_w, out_h=oh, out_w=ow, c0=c0, n=n, a1=a1,
                                        c1=c1, taps=taps, **kw),
                  flops=2 * batch * oh * ow * n * taps * (c0 + c1) * z, alg_flops=alg_flops,
@@ -184,12 +177,6 @@ class LaunchGraph:
         """dst = [src | src] along the batch axis (two identical CFG halves); the GroupNorm column sums of src follow."""
         assert dst.numel() == 2 * src.numel()
         self._dup(src, dst, tag=f"dup {src.numel() * 2 >> 20} MiB")
-        rs = self._rowstats.get(src.data_ptr())
-        if rs is not None:
-            rs2 = self.buf(rs.shape[0], 2 * rs.shape[1], 2, dtype=rs.dtype, zero=True)      # [parts][rows][2]: rows double
-            for part in range(rs.shape[0]):
-                self._dup(rs[part], rs2[part], tag="dup rowstats")
-            self._rowstats[dst.data_ptr()] = rs2
         cs = self._colstats.get(src.data_ptr())
         if cs is not None:
             cs2 = self.buf(2 * cs.shape[0], *cs.shape[1:], dtype=cs.dtype, zero=True)
@@ -214,18 +201,6 @@ class LaunchGraph:
             self.add(lambda: ops.groupnorm(x0, gamma, beta, out, stats, batch=batch, hw=hw, c0=c0, x1=x1, c1=c1, eps=eps, silu=silu),
                      tag=f"groupnorm B={batch} hw={hw} C={c0 + c1}")
         return out
-
-    def ln_stats(self, x, *, rows, c, eps=1e-5):
-        """(mean, rstd) [rows,2] of x from the row sums its producer left (conv(..., rowstats=True)); None if it left none."""
-        st = self._lnstats.get(x.data_ptr())
-        if st is None:
-            rs = self._rowstats.get(x.data_ptr())
-            if rs is None:
-                return None
-            st = torch.empty(rows, 2, dtype=torch.float32, device=self.device)
-            self.add(lambda: ops.ln_rowstats_finalize(rs, st, rows=rows, c=c, eps=eps), tag=f"ln_stats rows={rows} C={c}")
-            self._lnstats[x.data_ptr()] = st
-        return st
 
     def layernorm(self, x, gamma, beta, out, *, rows, c):
         self.add(lambda: ops.layernorm(x, gamma, beta, out, rows=rows, c=c), tag=f"layernorm rows={rows} C={c}")

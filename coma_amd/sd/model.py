@@ -10,7 +10,7 @@ import torch
 
 from .. import _lib
 
-BUF_PERSISTENT, BUF_ZEROED = 1, 2
+BUF_PERSISTENT, BUF_ZEROED, BUF_IF_NEW = 1, 2, 4
 
 
 class _Recording(threading.local):

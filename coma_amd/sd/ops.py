@@ -20,7 +20,6 @@ class ConvGemmDesc(C.Structure):
                 ("out", C.c_void_p), ("ldo", C.c_int), ("epi", C.c_int), ("nbatch_z", C.c_int),
                 ("stride_a", C.c_int64), ("stride_w", C.c_int64), ("stride_out", C.c_int64), ("stride_res", C.c_int64),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("colstats", C.c_void_p),
-                ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("stride_ln_stats", C.c_int64), ("rowstats", C.c_void_p),
                 ("out_t", C.c_void_p), ("n_split", C.c_int), ("ldo_t", C.c_int), ("rows_per_sample", C.c_int), ("phase", C.c_int)]
 
 
@@ -30,7 +29,7 @@ def _p(t, name="tensor", dtype=F16):
     from . import model
     rec = model.recording()
     if rec is not None:                         # this thread is recording a plan: whatever it points into belongs to the model
-        rec.register(t)                         # (buffers of LaunchGraph.buf were registered as scratch before: no-op for them)
+        rec.register(t, model.BUF_IF_NEW)       # scratch of LaunchGraph.buf stays scratch; a constant seen for the first time is PERSISTENT
     return _lib.ptr(t, dtype, name).value
 
 
@@ -40,7 +39,7 @@ def _stream(t):
 
 def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a1=None, c1=0, taps=1, stride=1, upsample=0,
               pad=1, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, epi=EPI_NONE, nbatch_z=1, stride_a=0, stride_w=0,
-              stride_out=0, stride_res=0, workspace=None, colstats=None, ln_stats=None, ln_colsum=None, stride_ln_stats=0, rowstats=None,
+              stride_out=0, stride_res=0, workspace=None, colstats=None,
               out_t=None, n_split=0, ldo_t=0, rows_per_sample=0, phase=0):
     d = ConvGemmDesc()
     d.phase = phase
@@ -57,11 +56,6 @@ def conv_gemm(a0, w, out, *, batch, in_h, in_w, out_h=None, out_w=None, c0, n, a
         d.workspace, d.workspace_bytes = _p(workspace, "workspace", torch.float32), workspace.numel() * 4
     if colstats is not None:
         d.colstats = _p(colstats, "colstats", torch.float32)
-    if ln_stats is not None:
-        d.ln_stats, d.ln_colsum = _p(ln_stats, "ln_stats", torch.float32), _p(ln_colsum, "ln_colsum", torch.float32)
-        d.stride_ln_stats = stride_ln_stats
-    if rowstats is not None:
-        d.rowstats = _p(rowstats, "rowstats", torch.float32)
     if out_t is not None:          # columns [n_split, n) leave transposed per sample in the PERM16 key order (to_q | to_k | to_v in one launch)
         d.out_t, d.n_split, d.ldo_t, d.rows_per_sample = _p(out_t, "out_t"), n_split, ldo_t, rows_per_sample
     _lib.check(_lib.lib().sd_conv_gemm_f16(C.byref(d), _stream(out)), "sd_conv_gemm_f16")
@@ -92,12 +86,6 @@ def groupnorm_colstats(x0, gamma, beta, out, stats, colstats0, *, batch, hw, c0,
 
 def gn_scratch_floats(batch, hw, groups=32, channels=2560):
     return batch * channels * 2 + batch * groups * 2 * ((hw + 63) // 64)
-
-
-def ln_rowstats_finalize(partial, stats, *, rows, c, eps=1e-5):
-    _lib.check(_lib.lib().sd_ln_rowstats_finalize(_p(partial, "partial", torch.float32), rows, c // 32, c, eps, _p(stats, "stats", torch.float32),
-                                                  _stream(stats)), "sd_ln_rowstats_finalize")
-    return stats
 
 
 def layernorm(x, gamma, beta, out, *, rows, c, eps=1e-5):

@@ -221,11 +221,19 @@ class PerItemState:
         for b in range(batch):
             self.states[b] = dict(first)            # every slot starts from the state the model was constructed with
 
-    def select(self, b):
+    def select(self, b, inherit_from=None):
+        """inherit_from: slot whose CURRENT state slot b starts from (the harness: the item before it in list order, so that an item
+        that is not primed sees what the reference's sequential loop would have left in the plug-in)."""
+        m = self.model
+        if inherit_from is not None and inherit_from != b:
+            src = ({k: getattr(m, k, self._MISSING) for k in self.STATE_ATTRS} if inherit_from == self.slot else self.states[inherit_from])
+            if b == self.slot:                      # overwrite the live attributes
+                self.__dict__["slot"] = -1
+            self.states[b] = dict(src)
         if b == self.slot:
             return
-        m = self.model
-        self.states[self.slot] = {k: getattr(m, k, self._MISSING) for k in self.STATE_ATTRS}
+        if self.slot >= 0:
+            self.states[self.slot] = {k: getattr(m, k, self._MISSING) for k in self.STATE_ATTRS}
         for k, v in self.states[b].items():
             if v is self._MISSING:
                 if hasattr(m, k):

@@ -12,10 +12,10 @@ concatenation -> GroupNorm/SiLU -> conv_out.  Fusions done here, none of which c
   * Q and K projections are one GEMM; V is produced transposed by swapping the GEMM operands (what the
     attention kernel wants), so there is no transpose or head-split copy anywhere;
   * nearest-x2 upsampling and stride-2 downsampling are index arithmetic inside the conv's operand gather;
-  * cross-attention K/V of the text context are computed once per prompt, not once per step;
-  * (fold_layernorm=True, off by default) the three LayerNorms of a transformer block folded algebraically into the GEMMs that
-    consume them, row statistics from the producing GEMM's epilogue: exact and tested, but measured 0.67 ms SLOWER per forward
-    on MI355X than the LayerNorm kernel (profiles/r02_notes.md) -- the epilogue loads it adds cost more than the pass it removes.
+  * cross-attention K/V of the text context are computed once per prompt, not once per step.
+Measured and removed (A/B history in profiles/r02_notes.md 6, r04_notes.md 4-7, r05_notes.md): the LayerNorms folded algebraically into
+their consumer GEMMs (0.2-0.7 ms SLOWER per forward in three rounds of A/B), Upsample2D as four sub-pixel phase products inside the UNet
+(slower; the VAE decoder uses them), and the run-time switches of the Winograd sub-features, whose winning settings are now code.
 """
 from __future__ import annotations
 
@@ -25,13 +25,16 @@ import torch
 
 from . import ops
 from .graph import F16, LaunchGraph
-from .weights import UNET_CFG, conv_weight, geglu_interleave, ln_fold, pad_vec
+from .weights import UNET_CFG, conv_weight, geglu_interleave, pad_vec
 
 
 class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
+GN_WINOGRAD_MIN_CG = 40     # GroupNorm folded into the Winograd input transform only for groups of >= 40 channels: a workgroup owns one (sample, group)
+                            # slice, and with 20-channel groups (C = 640) its 40-byte pieces of every (plane, tile) row waste most of each memory
+                            # transaction (48-114 us per launch at the 32 x 32 level against 18 us at C = 1280, profiles/r04_notes.md 4)
 WINOGRAD_MAX_H = 32         # ResNet 3x3 convolutions of feature maps up to 32 x 32 with >= 640 channels run as Winograd F(2x2,3x3).  Measured inside
                             # the captured batch-16 forward (A B A B on one box, profiles/r04_notes.md 4): 19.02 ms direct, 18.18 ms with the
                             # 16 x 16 / 8 x 8 levels, 18.01 ms with the 32 x 32 level as well; the 64 x 64 level (C = 320) loses.
@@ -39,7 +42,8 @@ WINOGRAD_MAX_H = 32         # ResNet 3x3 convolutions of feature maps up to 32 x
 
 class HipUNet2DConditionModel:
     def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
-                 cfg_shared_prefix=False, fold_layernorm=False, fuse_xchain=True, fuse_xfront=True, fuse_xtail=True, fuse_qkv=True):
+                 cfg_shared_prefix=False, fuse_xchain=True, fuse_xfront=True, fuse_xtail=True, fuse_qkv=True, winograd_max_h=None,
+                 winograd_min_batch=8):
         """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
         (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
         Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
@@ -51,28 +55,14 @@ class HipUNet2DConditionModel:
         self.heads = cfg["heads"]
         self.ctx_dim = cfg["cross_attention_dim"]
         self.use_graph = use_graph
-        self.fold_layernorm = fold_layernorm or os.environ.get("SD_LN_FOLD", "0") != "0"
-        self.fold_min_c = int(os.environ.get("SD_LN_FOLD_MIN_C", 0))    # A/B: fold only from this width (the C = 320 blocks have their row-tile kernels)
         self.fuse_xchain = fuse_xchain      # C = 320 blocks: attn1.to_out ... norm3 in one launch (sd_xattn_chain_f16)
         self.fuse_xfront = fuse_xfront      # C = 320 blocks: norm, proj_in, norm1, to_q | to_k, to_v^T in one launch (sd_xfront_f16)
         self.fuse_qkv = fuse_qkv            # C = 640 / 1280 blocks: to_q | to_k | to_v one GEMM, V^T written transposed by its epilogue (sd_conv_gemm_desc.out_t)
         self.fuse_xtail = fuse_xtail        # C = 320 blocks: ff (GEGLU, Linear) + residual, proj_out + residual in one launch (sd_xtail_f16)
-        self.fold_min_rows = 2048        # below that the producers want split-K (no statistics epilogue there)
-        # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs)
-        self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H))
-        # Upsample2D convolutions as four sub-pixel phase products: OFF in the UNet (measured 17.67 / 17.72 ms with, 17.55 / 17.64 without: at
-        # M = 1024 ... 16384 source rows four launches cost more than their 2.25 x fewer multiplies buy, and the two deep ones already run as
-        # Winograd); the VAE decoder, whose upsamplers are 21 % of it, uses them (coma_amd/sd/vae.py).  A/B: SD_UPSAMPLE_PHASES=1
-        self.upsample_phases = os.environ.get("SD_UPSAMPLE_PHASES", "0") != "0"
-        self.winograd_min_batch = int(os.environ.get("SD_WINOGRAD_MIN_BATCH", 8))
-        self.fuse_conv_out = os.environ.get("SD_FUSE_CONV_OUT", "1") != "0"       # conv_norm_out + SiLU + conv_out as one launch (A/B: 0)
-        self.winograd_upsamplers = os.environ.get("SD_WINOGRAD_UP", "1") != "0"   # ... and the Upsample2D convolutions of those levels (A/B: 0)
-        # ... only for groups of >= 40 channels: a workgroup owns one (sample, group) slice, and with 20-channel groups (C = 640) its 40-byte
-        # pieces of every (plane, tile) row waste most of each memory transaction (48-114 us per launch at the 32 x 32 level)
-        self.gn_winograd_min_cg = int(os.environ.get("SD_GN_WINOGRAD_MIN_CG", 40))
-        # unfused Winograd blocks (32 x 32): output transforms leave column sums, GroupNorms become table + affine inside the input transform (A/B: 0)
-        self.gn_table_winograd = os.environ.get("SD_GN_TABLE_WINOGRAD", "1") != "0"
-        self.fuse_gn_winograd = os.environ.get("SD_GN_WINOGRAD", "1") != "0"     # GroupNorms folded into the Winograd transforms (A/B: 0)
+        # ResNet 3x3 convolutions of feature maps up to this edge run as Winograd F(2x2,3x3) (0 = never; SD_WINOGRAD=<edge> for A/B runs), from
+        # this UNet batch on (at batch 2 -- one image per call -- the plane products are a few tiles each and the direct form is 0.7 % faster)
+        self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H)) if winograd_max_h is None else int(winograd_max_h)
+        self.winograd_min_batch = int(winograd_min_batch)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
         self.dtype = F16
@@ -153,21 +143,18 @@ class HipUNet2DConditionModel:
             if i < len(ch) - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 o = g.buf(B * 4 * H * W, cout)
-                if self.upsample_phases and W & (W - 1) == 0 and (H * W) % 32 == 0:
-                    # Upsample2D + conv as four sub-pixel phase products over the source: 16 multiplies per output 2 x 2 block instead of 36,
-                    # exact, no transformed tensors (sd_conv_gemm_desc.phase)
-                    g.conv3x3_upsampled(h, s[p + ".weight"], o, batch=B, in_h=H, in_w=W, c0=cout, n=cout, bias=s[p + ".bias"], stats=True)
-                elif self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and self.winograd_upsamplers and B >= self.winograd_min_batch:
-                    # Upsample2D + conv at the deep levels: the input transform reads the nearest-x2 upsampling in place
+                if self.winograd_max_h and 2 * max(H, W) <= self.winograd_max_h and cout >= 1280 and B >= self.winograd_min_batch:
+                    # Upsample2D + conv at the deep levels: the input transform reads the nearest-x2 upsampling in place.  (The four sub-pixel
+                    # phase products the VAE decoder uses lose here: 17.55 -> 17.67 ms per forward at M = 1024 ... 16384 source rows.)
                     g.conv3x3_winograd(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=2 * H, in_w=2 * W, c0=cout, n=cout, bias=s[p + ".bias"],
-                                       upsample=True, stats=self.gn_table_winograd)
+                                       upsample=True, stats=True)
                 else:
                     g.conv(h, conv_weight(s[p + ".weight"]), o, batch=B, in_h=H, in_w=W, out_h=2 * H, out_w=2 * W, c0=cout,
                            n=cout, taps=9, upsample=1, bias=s[p + ".bias"], stats=True)
                 h, H, W = o, 2 * H, 2 * W
         self.eps = g.buf(B * H * W, 64, zero=True)                # 4 valid output channels
         nout = s["conv_out.weight"].shape[0]
-        if self.fuse_conv_out and cin == 320 and nout <= 4:
+        if cin == 320 and nout <= 4:
             # conv_norm_out -> SiLU -> conv_out in one pass over the last feature map (sd_conv3x3_small_n_f16): no normalised copy, no
             # 64-column GEMM tile for 4 channels
             g.gn_silu_conv3x3_small_n(h, s["conv_norm_out.weight"], s["conv_norm_out.bias"], conv_weight(s["conv_out.weight"]),
@@ -187,8 +174,8 @@ class HipUNet2DConditionModel:
         # deep levels: Winograd F(2x2,3x3), 2.25 x fewer MFMA flops where the transformed tensors stay in cache (profiles/r04_notes.md 1, 4);
         # with the GroupNorms folded into the transforms a block is five launches: [norm1 + B^T d B] -> planes -> [A^T m A + bias + temb,
         # norm2, B^T d B] -> planes -> [A^T m A + bias + shortcut]
-        fused_gn = (wino and self.fuse_gn_winograd and H * W * (max(cin, cout) // 32) <= g.GN_WINO_MAX_SLICE and cin % 128 == 0 and cout % 128 == 0
-                    and min(cin, cout) // 32 >= self.gn_winograd_min_cg)
+        fused_gn = (wino and H * W * (max(cin, cout) // 32) <= g.GN_WINO_MAX_SLICE and cin % 128 == 0 and cout % 128 == 0
+                    and min(cin, cout) // 32 >= GN_WINOGRAD_MIN_CG)
         T = B * (H // 2) * (W // 2)
         if fused_gn:
             V1 = g.gn_winograd_input(s[p + ".norm1.weight"], s[p + ".norm1.bias"], batch=B, h=H, w=W, c0=c0, x0=x0, x1=x1, c1=c1, eps=1e-5)
@@ -199,17 +186,15 @@ class HipUNet2DConditionModel:
             # slices too large (or groups too narrow) for the LDS-resident fusion: GroupNorm through the affine table inside the input
             # transform when the producers left their column sums (the Winograd output transform does, at the 32 x 32 level)
             U1 = g.winograd_weight(conv_weight(s[p + ".conv1.weight"]), n=cout, c=cin)
-            V1 = g.gn_table_winograd_input(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], batch=B, h=H, w=W, c0=c0, x1=x1, c1=c1, eps=1e-5) \
-                if self.gn_table_winograd else None
+            V1 = g.gn_table_winograd_input(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], batch=B, h=H, w=W, c0=c0, x1=x1, c1=c1, eps=1e-5)
             if V1 is None:
                 n1 = g.buf(M, cin)
                 g.groupnorm(x0, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=c0, x1=x1, c1=c1, eps=1e-5, silu=True)
                 V1 = g.winograd_input(n1, batch=B, h=H, w=W, c0=cin)
             h = g.buf(M, cout)
             g.winograd_output(g.winograd_planes(V1, U1, tiles=T, c=cin, n=cout), h, batch=B, h=H, w=W, n=cout, bias=s[p + ".conv1.bias"],
-                              bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=self.gn_table_winograd)
-            V2 = g.gn_table_winograd_input(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], batch=B, h=H, w=W, c0=cout, eps=1e-5) \
-                if self.gn_table_winograd else None
+                              bias_bn=self._tb.view(-1)[off:], ldbb=self._tb_ld, stats=True)
+            V2 = g.gn_table_winograd_input(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], batch=B, h=H, w=W, c0=cout, eps=1e-5)
             if V2 is None:
                 n2 = g.buf(M, cout)
                 g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-5, silu=True)
@@ -233,7 +218,7 @@ class HipUNet2DConditionModel:
         out = g.buf(M, cout)
         if wino:
             P2 = g.winograd_planes(V2, g.winograd_weight(conv_weight(s[p + ".conv2.weight"]), n=cout, c=cout), tiles=T, c=cout, n=cout)
-            g.winograd_output(P2, out, batch=B, h=H, w=W, n=cout, bias=s[p + ".conv2.bias"], res=sc, stats=self.gn_table_winograd)
+            g.winograd_output(P2, out, batch=B, h=H, w=W, n=cout, bias=s[p + ".conv2.bias"], res=sc, stats=True)
         else:
             g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
                    bias=s[p + ".conv2.bias"], res=sc, stats=True)
@@ -243,48 +228,36 @@ class HipUNet2DConditionModel:
         g, s, B, heads = self.g, self.s, self._B, self.heads
         L, M, d = H * W, B * H * W, C // heads
         t = p + ".transformer_blocks.0"
-        # The three LayerNorms are folded into the GEMMs that consume them (weights.ln_fold): their inputs' row statistics
-        # come out of the producing GEMM's epilogue, (mean, rstd) from a tiny finalise launch, and the normalised tensors are
-        # never written.  Tiny feature maps keep the LayerNorm kernel: their producers want split-K, which has no statistics.
-        fold = self.fold_layernorm and M >= self.fold_min_rows and C >= self.fold_min_c
         wqk = torch.cat([s[t + ".attn1.to_q.weight"], s[t + ".attn1.to_k.weight"]]).contiguous()
         wv = s[t + ".attn1.to_v.weight"]
         h = g.buf(M, C)
         qk = g.buf(M, 2 * C)
         ldv = (L + 15) // 16 * 16
         vt = g.buf(B, C, ldv, zero=True)         # V^T with the keys of every 16 in the order the attention kernel's MFMA operand wants
-        if self.fuse_xfront and not fold and C == 320 and L % 64 == 0:
+        if self.fuse_xfront and C == 320 and L % 64 == 0:
             # everything before the self-attention is local to a token row once the GroupNorm statistics exist: one launch
             g.xfront(x, s[p + ".norm.weight"], s[p + ".norm.bias"], conv_weight(s[p + ".proj_in.weight"]), s[p + ".proj_in.bias"],
                      s[t + ".norm1.weight"], s[t + ".norm1.bias"], wqk, wv, h, qk, vt, batch=B, hw=L, gn_eps=1e-6)
         else:
             gn = g.buf(M, C)
             g.groupnorm(x, s[p + ".norm.weight"], s[p + ".norm.bias"], gn, batch=B, hw=L, c0=C, eps=1e-6, silu=False)
-            g.conv(gn, conv_weight(s[p + ".proj_in.weight"]), h, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".proj_in.bias"], rowstats=fold)
+            g.conv(gn, conv_weight(s[p + ".proj_in.weight"]), h, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[p + ".proj_in.bias"])
             # ---- self attention
-            if fold:
-                st = g.ln_stats(h, rows=M, c=C)
-                wqk_f, sqk, tqk = ln_fold(wqk, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
-                g.conv(h, wqk_f, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C, bias=tqk, ln_stats=st, ln_colsum=sqk)
-                wv_f, sv, tv = ln_fold(wv, s[t + ".norm1.weight"], s[t + ".norm1.bias"])
-                g.conv(wv_f, h, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv, bias=tv,
-                       epi=ops.EPI_PERM16_N | ops.EPI_BIAS_ROWS, ln_stats=st, ln_colsum=sv, stride_ln_stats=2 * L)   # statistics per key
+            n1 = g.buf(M, C)
+            g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
+            if self.fuse_qkv and C % 640 == 0 and L % 32 == 0:
+                # to_q | to_k | to_v in one launch: the V columns leave transposed per sample in the key order of the attention kernel
+                g.conv(n1, torch.cat([wqk, wv]).contiguous(), qk, batch=M, in_h=1, in_w=1, c0=C, n=3 * C, ldo=2 * C, out_t=vt, n_split=2 * C,
+                       ldo_t=ldv, rows_per_sample=L)
             else:
-                n1 = g.buf(M, C)
-                g.layernorm(h, s[t + ".norm1.weight"], s[t + ".norm1.bias"], n1, rows=M, c=C)
-                if self.fuse_qkv and C % 640 == 0 and L % 32 == 0:
-                    # to_q | to_k | to_v in one launch: the V columns leave transposed per sample in the key order of the attention kernel
-                    g.conv(n1, torch.cat([wqk, wv]).contiguous(), qk, batch=M, in_h=1, in_w=1, c0=C, n=3 * C, ldo=2 * C, out_t=vt, n_split=2 * C,
-                           ldo_t=ldv, rows_per_sample=L)
-                else:
-                    g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
-                    g.conv(wv, n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
-                           epi=ops.EPI_PERM16_N)
+                g.conv(n1, wqk, qk, batch=M, in_h=1, in_w=1, c0=C, n=2 * C)
+                g.conv(wv, n1, vt, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
+                       epi=ops.EPI_PERM16_N)
         a = g.buf(M, C)
         g.attention(qk, qk.view(-1)[C:], vt, a, batch=B, heads=heads, lq=L, lk=L, d=d, ldq=2 * C, ldk=2 * C, ldv=ldv, ldo=C, vt_perm16=True)
         Lk, cd = self.ctx_len, self.ctx_dim
         ldv2 = (Lk + 15) // 16 * 16
-        xchain = self.fuse_xchain and not fold and C == 320 and L % 64 == 0 and Lk <= 96
+        xchain = self.fuse_xchain and C == 320 and L % 64 == 0 and Lk <= 96
 
         def context_kv(Bf):
             """K / V^T of the text context for this block (per-prompt graph)."""
@@ -312,7 +285,7 @@ class HipUNet2DConditionModel:
         else:
             h1 = g.buf(M, C)
             g.conv(a, s[t + ".attn1.to_out.0.weight"], h1, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=s[t + ".attn1.to_out.0.bias"],
-                   res=h, rowstats=fold)
+                   res=h)
             if B != self.batch:
                 # end of the shared CFG prefix: from the first cross-attention on the two halves differ
                 B = self._B = self.batch
@@ -321,19 +294,15 @@ class HipUNet2DConditionModel:
                 x = g.dup(x, g.buf(M, C))
             # ---- cross attention (K, V^T of the context live in the per-prompt graph)
             q2 = g.buf(M, C)
-            if fold:
-                wq2_f, sq2, tq2 = ln_fold(s[t + ".attn2.to_q.weight"], s[t + ".norm2.weight"], s[t + ".norm2.bias"])
-                g.conv(h1, wq2_f, q2, batch=M, in_h=1, in_w=1, c0=C, n=C, bias=tq2, ln_stats=g.ln_stats(h1, rows=M, c=C), ln_colsum=sq2)
-            else:
-                n2 = g.buf(M, C)
-                g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)
-                g.conv(n2, s[t + ".attn2.to_q.weight"], q2, batch=M, in_h=1, in_w=1, c0=C, n=C)
+            n2 = g.buf(M, C)
+            g.layernorm(h1, s[t + ".norm2.weight"], s[t + ".norm2.bias"], n2, rows=M, c=C)
+            g.conv(n2, s[t + ".attn2.to_q.weight"], q2, batch=M, in_h=1, in_w=1, c0=C, n=C)
             k2, vt2 = context_kv(B)
             a2 = g.buf(M, C)
             g.attention(q2, k2, vt2, a2, batch=B, heads=heads, lq=L, lk=Lk, d=d, ldq=C, ldk=C, ldv=ldv2, ldo=C, vt_perm16=True)
             h2 = g.buf(M, C)
             g.conv(a2, s[t + ".attn2.to_out.0.weight"], h2, batch=M, in_h=1, in_w=1, c0=C, n=C,
-                   bias=s[t + ".attn2.to_out.0.bias"], res=h1, rowstats=fold)
+                   bias=s[t + ".attn2.to_out.0.bias"], res=h1)
         # ---- feed-forward (GEGLU)
         wff, bff = geglu_interleave(s[t + ".ff.net.0.proj.weight"], s[t + ".ff.net.0.proj.bias"])
         if xchain and self.fuse_xtail and M % 128 == 0:
@@ -345,10 +314,6 @@ class HipUNet2DConditionModel:
         f = g.buf(M, 4 * C)
         if xchain:
             g.conv(n3, wff, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=bff, epi=ops.EPI_GEGLU)
-        elif fold:
-            wff_f, sff, tff = ln_fold(wff, s[t + ".norm3.weight"], s[t + ".norm3.bias"], bff)
-            g.conv(h2, wff_f, f, batch=M, in_h=1, in_w=1, c0=C, n=8 * C, bias=tff, epi=ops.EPI_GEGLU, ln_stats=g.ln_stats(h2, rows=M, c=C),
-                   ln_colsum=sff)
         else:
             n3 = g.buf(M, C)
             g.layernorm(h2, s[t + ".norm3.weight"], s[t + ".norm3.bias"], n3, rows=M, c=C)

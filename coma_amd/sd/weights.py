@@ -233,15 +233,3 @@ def geglu_interleave(w, b):
     idx = torch.arange(inner).reshape(-1, 32)
     perm = torch.cat([idx, idx + inner], dim=1).reshape(-1)
     return w[perm].contiguous(), b[perm].contiguous()
-
-
-def ln_fold(w, gamma, beta, bias=None):
-    """LayerNorm folded into the linear layer that consumes it (sd_conv_gemm_desc.ln_stats):
-         LN(x) . w^T + b  =  rstd * (x . w'^T - mean * colsum) + b'      w' = gamma o w,  colsum = sum_k w',  b' = w . beta + b
-    -> (w' fp16 [n,k], colsum fp32 [n] taken from the fp16-rounded w' the MFMA will see, b' fp16 [n])."""
-    wp = (w.float() * gamma.float()[None, :]).to(torch.float16)
-    colsum = wp.float().sum(1).contiguous()
-    bp = w.float() @ beta.float()
-    if bias is not None:
-        bp = bp + bias.float()
-    return wp.contiguous(), colsum, bp.to(torch.float16).contiguous()

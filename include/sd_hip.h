@@ -70,16 +70,6 @@ typedef struct sd_conv_gemm_desc {
   size_t workspace_bytes;
   float* colstats;      /* optional fp32 [M/32][2][n]: per 32-row block, column sums and sums of squares of the stored output
                            (the GroupNorm statistics of the consumer, sd_groupnorm_colstats_f16 colstats0/1); needs M % 32 == 0 */
-  /* LayerNorm folded into the GEMM that consumes it (BasicTransformerBlock norm1/2/3 -> to_q/to_k/to_v/ff.net.0): with
-   * w' = gamma o w, colsum[n] = sum_k w'[n,k] (fp32, of the fp16-rounded w'), bias' = w . beta + bias,
-   *   out[m,n] = rstd[m] * (sum_k x[m,k] w'[n,k] - mean[m] * colsum[n]) + bias'[n]  ==  LayerNorm(x)[m,:] . w[n,:] + bias[n]
-   * so the normalised tensor is never written or re-read.  With SD_EPI_BIAS_ROWS (the normalised tensor is the W operand:
-   * V^T = Wv . LN(x)^T) the statistics are indexed by output column and colsum by output row. */
-  const float* ln_stats;   /* fp32 [rows][2] = (mean, rstd) per row of the normalised operand (sd_ln_rowstats_finalize), or NULL */
-  const float* ln_colsum;  /* fp32 [n] (or [M] with SD_EPI_BIAS_ROWS) */
-  int64_t stride_ln_stats; /* floats between the ln_stats of consecutive z problems (nbatch_z > 1) */
-  float* rowstats;         /* optional fp32 [n/32][M][2]: per row and 32-column tile the sum and sum of squares of the stored output --
-                              the raw material of the consumer's LayerNorm statistics; n % 32 == 0, no split-K */
   /* Optional second output: columns [n_split, n) of the product leave TRANSPOSED, per sample, in the key order of
    * sd_attention_f16(vt_perm16 = 1): out_t fp16 [M / rows_per_sample][n - n_split][ldo_t], element (b, c, pos) = product row
    * b * rows_per_sample + key(pos), column n_split + c, where every group of 16 positions holds the keys (0-3, 8-11, 4-7, 12-15).
@@ -116,10 +106,6 @@ int sd_groupnorm_f16(const void* x0, const void* x1, int c0, int c1, int batch, 
 int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0, int c1, int batch, int hw, int groups, float eps,
                               const void* gamma, const void* beta, int silu, void* out, float* stats, const float* colstats0,
                               const float* colstats1, void* stream);
-
-/* (mean, rstd) of every row from the producer's per-tile partial sums: partial fp32 [parts][rows][2] (sd_conv_gemm_desc.rowstats,
- * parts = c / 32) -> stats fp32 [rows][2].  replaces the statistics half of nn.LayerNorm(c, eps) in BasicTransformerBlock. */
-int sd_ln_rowstats_finalize(const float* partial, int64_t rows, int parts, int c, float eps, float* stats, void* stream);
 
 /* LayerNorm over the last dim of fp16 [rows, c].  replaces: nn.LayerNorm(C) in BasicTransformerBlock. */
 int sd_layernorm_f16(const void* x, int64_t rows, int c, float eps, const void* gamma, const void* beta, void* out,
@@ -306,7 +292,7 @@ int sd_mask_adapt_batched(const uint8_t* seg, const uint8_t* default_mask, int b
  * Models: the launch list and the hipGraph of a network live in the library (coma_amd/csrc/sd_plan.hip).
  * A model = a registry of device buffers + named bindings (inputs / outputs) + named plans (recorded launch lists).
  * Recording: between sd_model_record_begin and sd_model_record_end every sd_* LAUNCH entry point called on the thread
- * (sd_conv_gemm_f16, sd_groupnorm*_f16, sd_layernorm_f16, sd_ln_rowstats_finalize, sd_attention_f16, sd_softmax_f16,
+ * (sd_conv_gemm_f16, sd_groupnorm*_f16, sd_layernorm_f16, sd_attention_f16, sd_softmax_f16,
  * sd_timestep_embedding_f16, sd_copy_d2d) appends its arguments to the plan instead of launching; arguments are validated when
  * the plan first runs.  sd_model_run launches the list eagerly on `stream`; sd_model_replay captures it once into a hipGraph (on a
  * private stream, nothing executes during capture) and launches the graph on `stream`.
@@ -316,6 +302,8 @@ int sd_mask_adapt_batched(const uint8_t* seg, const uint8_t* default_mask, int b
  * saved.  Not thread-safe per model; distinct models are independent. */
 #define SD_BUF_PERSISTENT 1   /* contents are part of the model (saved / restored) */
 #define SD_BUF_ZEROED 2       /* must start as zeros (pad channels that kernels never write); loaded buffers always start zeroed */
+#define SD_BUF_IF_NEW 4       /* register as SD_BUF_PERSISTENT unless an entry already covers the range, whose flags then stay as they are
+                                 (the recording hook: scratch stays scratch, a constant seen for the first time is saved) */
 int sd_model_create(void** model);
 int sd_model_destroy(void* model);
 int sd_model_register_buffer(void* model, void* ptr, size_t bytes, int flags);

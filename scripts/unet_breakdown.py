@@ -8,7 +8,7 @@ from coma_amd.sd.unet import HipUNet2DConditionModel
 dev = "cuda:0"
 B = 16
 state = weights.random_state(weights.unet_shapes(), seed=0, device=dev)
-unet = HipUNet2DConditionModel(state, batch=B, height=64, width=64, device=dev, use_graph=True, fold_layernorm="--fold" in sys.argv)
+unet = HipUNet2DConditionModel(state, batch=B, height=64, width=64, device=dev, use_graph=True)
 g = torch.Generator(device=dev).manual_seed(0)
 unet.set_context(torch.randn(B, 77, 768, generator=g, device=dev))
 unet.x_in.copy_(torch.randn(unet.x_in.shape, generator=g, device=dev).half())

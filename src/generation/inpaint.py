@@ -8,7 +8,10 @@ CLI surface and host behaviour of the reference's ``src/generation/inpaint.py``:
   * per item: device generator seeded with ``inpaint_id`` (:308-309), skip-if-exists (:294-297), PNG output (:352);
   * the rank's slice is walked in groups of ``--batch_size`` (default 8) consecutive items with equal per-call settings; one
     pipeline call per group, one generator / prompt / mask / plug-in state per image (the reference's loop runs one item per
-    call, :280-352; batching it is output-preserving because every item carries its own seed).
+    call, :280-352).  Every item carries its own seed, so an item's noise draws do not depend on how the list is cut; its image is
+    equal to the one-item-per-call image up to fp16 rounding only (kernel selection -- tile shapes, split-K, Winograd from UNet batch
+    8 -- depends on the batch: measured 0.19 grey levels mean, tests/test_inpaint_cli_gpu.py), i.e. statistically equivalent, not
+    bit-identical; ``--batch_size 1`` is the reference's own call shape.
 The pipeline is :class:`coma_amd.sd.pipeline.AdaptiveMaskInpaintPipeline` (HIP kernels).  Model weights, the CLIP text
 encoder and PointRend are third-party assets that cannot be provisioned offline: ``--weights_dir`` points at a
 diffusers-format checkpoint directory when one exists (its tokenizer/ + text_encoder/ then embed the prompts); otherwise
@@ -219,7 +222,7 @@ def inpaint_human(args):
         todo.append(it)
     if not todo:
         return
-    B = max(1, int(getattr(args, "batch_size", 1)))
+    B = max(1, min(int(getattr(args, "batch_size", 1)), len(todo)))      # never a batch wider than the work that is left
     pipeline = set_pipeline(args.ldm_model_key, args.adaptive_mask_model_type, args.default_ddim_steps, args.weights_dir, args.mask_model,
                             default_pointrend_threshold=args.default_pointrend_threshold, use_visualizer=args.use_visualizer,
                             enable_sam_multitask_output=args.enable_sam_multitask_output, batch_size=B)
@@ -237,10 +240,13 @@ def inpaint_human(args):
         images = [Image.open(it["asset_render_pth"]).convert("RGB") for it in slots]
         masks = [Image.open(it["asset_mask_pth"]).convert("L") for it in slots]
         for b, it in enumerate(slots):
+            model = pipeline.adaptive_mask_model
+            if isinstance(model, PerItemState):
+                # an item without a segmentation file is not primed (reference :325): it starts from whatever the item BEFORE it in
+                # list order left in the plug-in -- the previous slot of this group, or the last slot of the previous group -- not from
+                # the unrelated item that used this slot one group earlier
+                model.select(b, inherit_from=(b - 1) % B if B > 1 else None)
             if os.path.exists(it["asset_seg_pth"]):
-                model = pipeline.adaptive_mask_model
-                if isinstance(model, PerItemState):
-                    model.select(b)
                 prime_mask_model(model, args.adaptive_mask_model_type, np.array(Image.open(it["asset_seg_pth"]).convert("L")) > 0,
                                  np.asarray(masks[b]) > 0)
         generators = []

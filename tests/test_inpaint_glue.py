@@ -215,3 +215,32 @@ def test_per_item_state_swaps_only_the_small_state():
     assert not hasattr(p, "presumed_asset_mask")
     w.select(2)
     assert p.presumed_asset_mask.shape == (4, 4)
+
+
+def test_per_item_state_inherits_from_the_previous_item():
+    """an item that is not primed (no segmentation file) starts from the state of the item before it in list order --
+    what the reference's one-item-per-call loop leaves in the plug-in -- not from the item that used its slot one group earlier."""
+    from coma_amd.sd.predictors import PerItemState
+
+    class Pred:
+        def __init__(self):
+            self.initial_human_bbox = None
+
+    p = Pred()
+    w = PerItemState(p, 3)
+    for b in range(3):                               # group 1: every slot primed with its own box
+        w.select(b, inherit_from=(b - 1) % 3)
+        w.initial_human_bbox = ("box", b)
+    # group 2: slot 0 inherits from slot 2 (the last item of group 1), slot 1 is primed, slot 2 inherits from slot 1
+    w.select(0, inherit_from=2)
+    assert p.initial_human_bbox == ("box", 2)
+    w.select(1, inherit_from=0)
+    w.initial_human_bbox = ("box", "new")
+    w.select(2, inherit_from=1)
+    assert p.initial_human_bbox == ("box", "new")
+    w.select(0)
+    assert p.initial_human_bbox == ("box", 2)        # slot 0 kept what it inherited
+    w.select(1)
+    assert p.initial_human_bbox == ("box", "new")
+    w.select(1, inherit_from=0)                      # the live slot can be overwritten too
+    assert p.initial_human_bbox == ("box", 2)

@@ -114,6 +114,12 @@ def test_model_python_roundtrip_and_errors(tmp_path, hip_lib):
     ctx, x, t = torch.randn(2, 77, 768, generator=g), torch.randn(2, 9, 16, 16, generator=g), torch.tensor([500.0, 500.0])
     ref = unet(x, t, encoder_hidden_states=ctx)[0]
     unet.save(tmp_path / "u.sdm")
+    # scratch is not part of a saved model: the file holds the constants in kernel layout -- about the size of the state
+    # dict (re-laid-out copies, a few concatenations) -- and neither the 64 MiB split-K workspace nor any activation buffer, although
+    # every recorded launch points into them
+    state_bytes = sum(v.numel() * 2 for v in unet.s.values())
+    size = os.path.getsize(tmp_path / "u.sdm")
+    assert 0.8 * state_bytes < size < 1.6 * state_bytes + (8 << 20), (size, state_bytes)
     m = SdModel.load(tmp_path / "u.sdm", DEV)
     assert m.num_launches("step") == unet.g.model.num_launches("step") and m.num_launches("nope") == -1
     eps = torch.empty_like(unet.eps)
@@ -142,7 +148,7 @@ def test_model_python_roundtrip_and_errors(tmp_path, hip_lib):
 
 
 def test_model_file_is_verified_before_it_is_trusted(tmp_path, hip_lib):
-    """Format version 2: a truncated file, a file with one flipped byte in the launch records and one with a flipped byte
+    """Format version 3 (checks of ADVICE r3): a truncated file, a file with one flipped byte in the launch records and one with a flipped byte
     in the weights are all refused by sd_model_load (size / checksum), nothing is launched; and a buffer first registered as scratch,
     later registered SD_BUF_PERSISTENT (constants filled outside a plan), is saved with the model; a range bridging two registered
     buffers leaves one entry."""
@@ -177,7 +183,7 @@ def test_model_file_is_verified_before_it_is_trusted(tmp_path, hip_lib):
     path = tmp_path / "m.sdm"
     m.save(path)
     blob = path.read_bytes()
-    assert blob[:8] == b"SDMODEL2" and int.from_bytes(blob[8:16], "little") == len(blob)
+    assert blob[:8] == b"SDMODEL3" and int.from_bytes(blob[8:16], "little") == len(blob)
     # the round trip keeps the constants (gamma = 2, beta = 0.5 live in the persistent range)
     m2 = SdModel.load(path, DEV)
     p, n = m2.binding("x")
@@ -192,7 +198,7 @@ def test_model_file_is_verified_before_it_is_trusted(tmp_path, hip_lib):
     for name, data in (("trunc", blob[:-100]), ("long", blob + b"\0" * 8),
                        ("rec", blob[:200] + bytes([blob[200] ^ 0x40]) + blob[201:]),
                        ("weights", blob[:-5] + bytes([blob[-5] ^ 1]) + blob[-4:]),
-                       ("v1", b"SDMODEL1" + blob[8:])):
+                       ("v1", b"SDMODEL1" + blob[8:]), ("v2", b"SDMODEL2" + blob[8:])):
         bad = tmp_path / f"{name}.sdm"
         bad.write_bytes(data)
         with pytest.raises(ComaHipError, match="truncated|checksum|not a model file"):

@@ -589,84 +589,6 @@ def test_conv3x3_colstats_on_big_tiles(ops, B, H, c, n):
     assert torch.allclose(cs[:, 1], (o * o).sum(1), rtol=1e-4, atol=1e-3)
 
 
-# ------------------------------------------------------------------------------------------- LayerNorm folded into its consumers
-def _ln_ref(x, ga, be, eps=1e-5):
-    return torch.nn.functional.layer_norm(x.float(), (x.shape[-1],), ga.float(), be.float(), eps)
-
-
-@pytest.mark.parametrize("M,C", [(32768, 320), (16384, 640), (4096, 1280), (700, 320)])
-def test_row_statistics_from_the_producer_epilogue(ops, M, C):
-    """rowstats: per row and 32-column tile (sum, sum of squares) of the stored output; finalised to (mean, rstd)."""
-    K = 320
-    x, w, b, r = rnd(M, K, seed=1), rnd(C, K, seed=2, scale=K**-0.5), rnd(C, seed=3), rnd(M, C, seed=4)
-    out = torch.empty(M, C, dtype=F16, device=DEV)
-    rs = torch.zeros(C // 32, M, 2, dtype=torch.float32, device=DEV)
-    ops.conv_gemm(x.to(DEV), w.to(DEV), out, batch=M, in_h=1, in_w=1, c0=K, n=C, bias=b.to(DEV), res=r.to(DEV), rowstats=rs,
-                  workspace=torch.empty(8 << 20, dtype=torch.float32, device=DEV))
-    close(out, x.float() @ w.float().T + b.float() + r.float())
-    o = out.float().reshape(M, C // 32, 32).transpose(0, 1)
-    assert torch.allclose(rs[..., 0], o.sum(-1), rtol=1e-4, atol=1e-3) and torch.allclose(rs[..., 1], (o * o).sum(-1), rtol=1e-4, atol=1e-3)
-    st = torch.empty(M, 2, dtype=torch.float32, device=DEV)
-    ops.ln_rowstats_finalize(rs, st, rows=M, c=C)
-    of = out.float()
-    assert torch.allclose(st[:, 0], of.mean(-1), rtol=1e-4, atol=1e-5)
-    assert torch.allclose(st[:, 1], (of.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=2e-3)
-
-
-def _stats_of(x):
-    xf = x.float()
-    return torch.stack([xf.mean(-1), (xf.var(-1, unbiased=False) + 1e-5).rsqrt()], -1).contiguous().to(DEV)
-
-
-@pytest.mark.parametrize("M,C,N", [(32768, 320, 640), (16384, 640, 640), (4096, 1280, 1280), (300, 320, 320), (1024, 1280, 1280)])
-def test_layernorm_folded_into_the_consumer_gemm(ops, M, C, N):
-    from coma_amd.sd.weights import ln_fold
-    x = rnd(M, C, seed=1) * 1.5 + 0.4                                 # a mean that is not negligible next to the spread
-    ga, be = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.2
-    w, b, r = rnd(N, C, seed=4, scale=C**-0.5), rnd(N, seed=5), rnd(M, N, seed=6)
-    wf, cs, bf = ln_fold(w, ga, be, b)
-    out = torch.empty(M, N, dtype=F16, device=DEV)
-    ops.conv_gemm(x.to(DEV), wf.to(DEV), out, batch=M, in_h=1, in_w=1, c0=C, n=N, bias=bf.to(DEV), res=r.to(DEV), ln_stats=_stats_of(x),
-                  ln_colsum=cs.to(DEV), workspace=torch.empty(16 << 20, dtype=torch.float32, device=DEV))
-    close(out, _ln_ref(x, ga, be) @ w.float().T + b.float() + r.float(), tol=4e-3)
-
-
-def test_layernorm_folded_into_geglu(ops):
-    from coma_amd.sd.weights import geglu_interleave, ln_fold
-    M, C, inner = 4096, 320, 1280
-    x = rnd(M, C, seed=1) * 1.5 + 0.3
-    ga, be = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.2
-    w, b = rnd(2 * inner, C, seed=4, scale=C**-0.5), rnd(2 * inner, seed=5)
-    wi, bi = geglu_interleave(w, b)
-    wf, cs, bf = ln_fold(wi, ga, be, bi)
-    out = torch.empty(M, inner, dtype=F16, device=DEV)
-    ops.linear(x.to(DEV), wf.to(DEV), out, rows=M, k=C, n=2 * inner, bias=bf.to(DEV), epi=ops.EPI_GEGLU) if False else \
-        ops.conv_gemm(x.to(DEV), wf.to(DEV), out, batch=M, in_h=1, in_w=1, c0=C, n=2 * inner, bias=bf.to(DEV), epi=ops.EPI_GEGLU,
-                      ln_stats=_stats_of(x), ln_colsum=cs.to(DEV))
-    close(out, so.geglu_ref(_ln_ref(x, ga, be), w, b), tol=4e-3)
-
-
-@pytest.mark.parametrize("L,C", [(256, 320), (77, 640), (1024, 320)])
-def test_layernorm_folded_into_the_v_transposed_projection(ops, L, C):
-    """V^T[b] = Wv . LN(x_b)^T: the normalised tensor is the W operand, statistics per output column (key), key-permuted layout."""
-    from coma_amd.sd.weights import ln_fold
-    B = 3
-    x = rnd(B, L, C, seed=1) * 1.5 + 0.3
-    ga, be = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.2
-    wv = rnd(C, C, seed=4, scale=C**-0.5)
-    wf, cs, bf = ln_fold(wv, ga, be)
-    ldv = (L + 15) // 16 * 16
-    out = torch.zeros(B, C, ldv, dtype=F16, device=DEV)
-    st = _stats_of(x.reshape(B * L, C))
-    ops.conv_gemm(wf.to(DEV), x.to(DEV), out, batch=C, in_h=1, in_w=1, c0=C, n=L, ldo=ldv, nbatch_z=B, stride_w=L * C, stride_out=C * ldv,
-                  bias=bf.to(DEV), epi=ops.EPI_PERM16_N | ops.EPI_BIAS_ROWS, ln_stats=st, ln_colsum=cs.to(DEV), stride_ln_stats=2 * L)
-    ref = ops.perm16_columns(torch.einsum("ck,blk->bcl", wv.float(), _ln_ref(x, ga, be)))
-    j = torch.arange(ldv)
-    real = ((j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1)) < L
-    close(out[:, :, real], ref[:, :, real], tol=4e-3)
-    assert bool(torch.isfinite(out.float()).all())
-
-
 @pytest.mark.parametrize("B,H,W,n,norm,silu,C", [(2, 32, 48, 3, True, True, 128), (1, 24, 40, 3, True, True, 128), (2, 16, 16, 4, True, False, 128),
                                                  (1, 50, 21, 1, False, False, 128), (1, 64, 64, 3, False, False, 128), (2, 24, 40, 4, True, True, 320),
                                                  (1, 64, 64, 4, False, False, 320)])
