@@ -53,12 +53,12 @@ SIGNATURES = {
     "sd_groupnorm_table_f16": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "sd_xfront_f16": (_i, [_vp] * 11 + [_i64, _i, _i, _f, _vp]),
     "sd_xtail_f16": (_i, [_vp] * 11 + [_i64, _vp]),
-    "sd_winograd_input_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
-    "sd_winograd_weight_f16": (_i, [_vp, _i, _i, _vp, _vp]),
-    "sd_winograd_output_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "sd_winograd_input_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp]),
+    "sd_winograd_weight_f16": (_i, [_vp, _i, _i, _f, _vp, _vp]),
+    "sd_winograd_output_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp]),
     "sd_groupnorm_table_cat_f16": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sd_conv3x3_small_n_f16": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
-    "sd_gn_winograd_input_f16": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _vp]),
+    "sd_gn_winograd_input_f16": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _f, _vp, _vp]),
     "sd_im2col3x3_c3_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sd_softmax_f16": (_i, [_vp, _i64, _i, _i, _f, _vp]),
     "sd_cfg_ddim_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp]),

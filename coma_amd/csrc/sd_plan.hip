@@ -118,13 +118,13 @@ static int launch(const PlanRec& r, void* st) {
       return sd_conv3x3_small_n_f16(p[0], (const float*)p[1], (int)i[0], p[2], p[3], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], p[4],
                                     (int)i[6], st);
     case PK_WINO_IN:
-      return sd_winograd_input_f16(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], (const float*)p[3], (int)i[6], p[2], st);
+      return sd_winograd_input_f16(p[0], p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], (const float*)p[3], (int)i[6], (float)f[0], p[2], st);
     case PK_WINO_OUT:
       return sd_winograd_output_f16(p[0], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], p[1], p[2], (int)i[5], p[3], (int)i[6], p[4],
-                                    (int)i[7], (int)i[8], (float*)p[5], st);
+                                    (int)i[7], (int)i[8], (float)f[0], (float*)p[5], st);
     case PK_GN_WINO_IN:
       return sd_gn_winograd_input_f16(p[0], p[1], (int)i[0], (int)i[1], p[2], (int)i[2], p[3], p[4], (int)i[3], (int)i[4], (int)i[5], (int)i[6],
-                                      (int)i[7], (float)f[0], p[5], p[6], (int)i[8], p[7], st);
+                                      (int)i[7], (float)f[0], p[5], p[6], (int)i[8], (float)f[1], p[7], st);
     case PK_IM2COL_C3:
       return sd_im2col3x3_c3_f16(p[0], (int)i[0], (int)i[1], (int)i[2], (int)i[3], p[1], st);
     case PK_GN_TABLE_CAT:

@@ -8,6 +8,11 @@
 // of 9 * M * C_in * C_out: 2.25 x fewer MFMA flops, paid for with a 4 x larger (transformed) activation tensor on the way in and
 // a 4 x larger product tensor on the way out.  fp16 storage / fp32 arithmetic like every other sd_* operator.
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// fp16 RANGE: V and the plane products are stored as fp16 where the direct path keeps its sum in fp32 registers.
+// V = B^T d B reaches 4 max|d| and a plane product can exceed the convolution output it cancels into, so both transforms take a
+// power-of-two scale (uscale on U = G g G^T, vscale on V) that the output transform undoes in fp32 (mscale = 1 / (uscale vscale)):
+// exact in the normal range, and the stored planes sit 4 x (ResNet convolutions, whose inputs are GroupNorm-bounded) or 16 x
+// (Upsample2D convolutions, whose input is the raw residual stream: V itself needs the headroom) further from 65504.
 #include <hip/hip_fp16.h>
 
 #include "common.h"
@@ -26,7 +31,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // GroupNorm -- optionally passed through SiLU, and rounded to fp16 (what the GroupNorm kernel would have stored); pad pixels stay zero.
 __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __restrict__ x0, const _Float16* __restrict__ x1, int c0,
                                                             int c1, int batch, int h, int w, int up, const float* __restrict__ affine,
-                                                            int silu, _Float16* __restrict__ v) {
+                                                            int silu, float vscale, _Float16* __restrict__ v) {
   const int c = c0 + c1, cch = c >> 3;
   const int th = h >> 1, tw = w >> 1;
   const long long ntile = (long long)batch * th * tw;
@@ -87,7 +92,8 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __r
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float t0 = d[i][0][e], t1 = d[i][1][e], t2 = d[i][2][e], t3 = d[i][3][e];
-      o[0][e] = (_Float16)(t0 - t2); o[1][e] = (_Float16)(t1 + t2); o[2][e] = (_Float16)(t2 - t1); o[3][e] = (_Float16)(t1 - t3);
+      o[0][e] = (_Float16)(vscale * (t0 - t2)); o[1][e] = (_Float16)(vscale * (t1 + t2)); o[2][e] = (_Float16)(vscale * (t2 - t1));
+      o[3][e] = (_Float16)(vscale * (t1 - t3));
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<half8*>(v + ((long long)(4 * i + j) * ntile + t) * c + ch) = o[j];
@@ -95,7 +101,7 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const _Float16* __r
 }
 
 // U[p][n][c] = (G g G^T)[p], g = w[n][ky*3+kx][c]; thread = (n, c)
-__global__ void winograd_weight_kernel(const _Float16* __restrict__ wsrc, int n, int c, _Float16* __restrict__ u) {
+__global__ void winograd_weight_kernel(const _Float16* __restrict__ wsrc, int n, int c, float uscale, _Float16* __restrict__ u) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long long)n * c) return;
   const int ci = (int)(gid % c);
@@ -115,7 +121,8 @@ __global__ void winograd_weight_kernel(const _Float16* __restrict__ wsrc, int n,
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+    const float u0 = uscale * t[a][0], u1 = uscale * (0.5f * (t[a][0] + t[a][1] + t[a][2])), u2 = uscale * (0.5f * (t[a][0] - t[a][1] + t[a][2])),
+                u3 = uscale * t[a][2];
     u[((long long)(4 * a + 0) * n + ni) * c + ci] = (_Float16)u0;
     u[((long long)(4 * a + 1) * n + ni) * c + ci] = (_Float16)u1;
     u[((long long)(4 * a + 2) * n + ni) * c + ci] = (_Float16)u2;
@@ -127,7 +134,7 @@ __global__ void winograd_weight_kernel(const _Float16* __restrict__ wsrc, int n,
 __global__ void __launch_bounds__(256) winograd_output_kernel(const _Float16* __restrict__ m, int ldm, int batch, int h, int w, int n,
                                                              const _Float16* __restrict__ bias, const _Float16* __restrict__ bias_bn,
                                                              int ldbb, const _Float16* __restrict__ res, int ldr,
-                                                             _Float16* __restrict__ out, int ldo, int silu) {
+                                                             _Float16* __restrict__ out, int ldo, int silu, float mscale) {
   const int nch = n >> 3;
   const int th = h >> 1, tw = w >> 1;
   const long long ntile = (long long)batch * th * tw;
@@ -177,7 +184,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const _Float16* __
       half8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float y = (bb == 0 ? s[a][0][e] + s[a][1][e] + s[a][2][e] : s[a][1][e] - s[a][2][e] - s[a][3][e]) + add[e];
+        float y = mscale * (bb == 0 ? s[a][0][e] + s[a][1][e] + s[a][2][e] : s[a][1][e] - s[a][2][e] - s[a][3][e]) + add[e];
         if (silu) y = y / (1.0f + __expf(-y));
         o[e] = (_Float16)(y + (float)r[e]);
       }
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const _Float16* __
 __global__ void __launch_bounds__(256) winograd_output_cs_kernel(const _Float16* __restrict__ m, int ldm, int batch, int h, int n,
                                                                 const _Float16* __restrict__ bias, const _Float16* __restrict__ bias_bn,
                                                                 int ldbb, const _Float16* __restrict__ res, int ldr,
-                                                                _Float16* __restrict__ out, int ldo, int silu, float* __restrict__ cs) {
+                                                                _Float16* __restrict__ out, int ldo, int silu, float mscale, float* __restrict__ cs) {
   constexpr int w = 32, tw = 16;
   __shared__ float red[2][2][16][128];                      // [sum | sumsq][image row a][tile][channel of the block]
   const int th = h >> 1;
@@ -243,7 +250,7 @@ __global__ void __launch_bounds__(256) winograd_output_cs_kernel(const _Float16*
       half8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float y = (bb == 0 ? s[a][0][e] + s[a][1][e] + s[a][2][e] : s[a][1][e] - s[a][2][e] - s[a][3][e]) + add[e];
+        float y = mscale * (bb == 0 ? s[a][0][e] + s[a][1][e] + s[a][2][e] : s[a][1][e] - s[a][2][e] - s[a][3][e]) + add[e];
         if (silu) y = y / (1.0f + __expf(-y));
         o[e] = (_Float16)(y + (float)r[e]);
         const float f = (float)o[e];
@@ -288,6 +295,7 @@ struct GnWinoArgs {
   float eps;
   const _Float16 *gamma, *beta;
   int silu;
+  float mscale;               // mode 1: h = mscale * A^T m A + bias (the planes were stored scaled by 1 / mscale)
   _Float16* v;                // fp16 [16][batch * T][C]
 };
 
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
           hv o;
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            const float y = (xb == 0 ? sm[ya][0][e] + sm[ya][1][e] + sm[ya][2][e] : sm[ya][1][e] - sm[ya][2][e] - sm[ya][3][e]) + add[e];
+            const float y = a.mscale * (xb == 0 ? sm[ya][0][e] + sm[ya][1][e] + sm[ya][2][e] : sm[ya][1][e] - sm[ya][2][e] - sm[ya][3][e]) + add[e];
             o[e] = (_Float16)y;
             const float f = (float)o[e];            // the statistics see the fp16 tensor the unfused chain would have stored
             s += f; q += f * f;
@@ -434,45 +442,47 @@ __global__ __launch_bounds__(256) void gn_winograd_input_kernel(GnWinoArgs a) {
 extern "C" {
 
 int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, const float* gn_affine,
-                          int silu, void* v, void* stream) {
+                          int silu, float vscale, void* v, void* stream) {
   using namespace sd;
   if (plan_recording()) {
     PlanRec r{};
     r.kind = PK_WINO_IN;
     r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = v; r.p[3] = (void*)gn_affine;
-    r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = h; r.i[4] = w; r.i[5] = upsample; r.i[6] = silu;
+    r.i[0] = c0; r.i[1] = c1; r.i[2] = batch; r.i[3] = h; r.i[4] = w; r.i[5] = upsample; r.i[6] = silu; r.f[0] = vscale;
     return plan_record(r);
   }
   if (upsample != 0 && upsample != 1) return fail(COMA_E_INVALID, "sd_winograd_input_f16: upsample must be 0 or 1");
   if (!x0 || !v) return fail(COMA_E_INVALID, "sd_winograd_input_f16: null pointer");
+  if (!(vscale > 0.0f)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: vscale must be positive");
   if (c0 <= 0 || c0 % 8 || c1 < 0 || c1 % 8 || (c1 > 0 && !x1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: channel counts must be multiples of 8");
   if (batch <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_winograd_input_f16: even h, w required");
   const long long total = (long long)batch * (h / 2) * (w / 2) * ((c0 + c1) / 8);
   hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const _Float16*)x0, (const _Float16*)x1, c0, c1, batch, h, w, upsample, gn_affine, silu, (_Float16*)v);
+                     (const _Float16*)x0, (const _Float16*)x1, c0, c1, batch, h, w, upsample, gn_affine, silu, vscale, (_Float16*)v);
   return check_launch("sd_winograd_input_f16");
 }
 
-int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream) {
+int sd_winograd_weight_f16(const void* w, int n, int c, float uscale, void* u, void* stream) {
   using namespace sd;
-  if (!w || !u || n <= 0 || c <= 0) return fail(COMA_E_INVALID, "sd_winograd_weight_f16: bad arguments");
+  if (!w || !u || n <= 0 || c <= 0 || !(uscale > 0.0f)) return fail(COMA_E_INVALID, "sd_winograd_weight_f16: bad arguments");
   const long long total = (long long)n * c;
   hipLaunchKernelGGL(winograd_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const _Float16*)w, n, c, (_Float16*)u);
+                     (const _Float16*)w, n, c, uscale, (_Float16*)u);
   return check_launch("sd_winograd_weight_f16");
 }
 
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
-                           const void* res, int ldr, void* out, int ldo, int silu, float* colstats, void* stream) {
+                           const void* res, int ldr, void* out, int ldo, int silu, float mscale, float* colstats, void* stream) {
   using namespace sd;
   if (plan_recording()) {
     PlanRec r{};
     r.kind = PK_WINO_OUT;
     r.p[0] = (void*)m; r.p[1] = (void*)bias; r.p[2] = (void*)bias_bn; r.p[3] = (void*)res; r.p[4] = out; r.p[5] = colstats;
-    r.i[0] = ldm; r.i[1] = batch; r.i[2] = h; r.i[3] = w; r.i[4] = n; r.i[5] = ldbb; r.i[6] = ldr; r.i[7] = ldo; r.i[8] = silu;
+    r.i[0] = ldm; r.i[1] = batch; r.i[2] = h; r.i[3] = w; r.i[4] = n; r.i[5] = ldbb; r.i[6] = ldr; r.i[7] = ldo; r.i[8] = silu; r.f[0] = mscale;
     return plan_record(r);
   }
   if (!m || !out) return fail(COMA_E_INVALID, "sd_winograd_output_f16: null pointer");
+  if (!(mscale > 0.0f)) return fail(COMA_E_INVALID, "sd_winograd_output_f16: mscale must be positive");
   if (n <= 0 || n % 8 || ldm % 8 || batch <= 0 || (h & 1) || (w & 1)) return fail(COMA_E_INVALID, "sd_winograd_output_f16: bad shape");
   if (ldo == 0) ldo = n;
   if (ldr == 0) ldr = n;
@@ -481,29 +491,30 @@ int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int 
     if (w != 32 || n % 128) return fail(COMA_E_INVALID, "sd_winograd_output_f16: column sums need w = 32 and n %% 128 == 0 (w=%d n=%d)", w, n);
     hipLaunchKernelGGL(winograd_output_cs_kernel, dim3((unsigned)(batch * (h / 2)), (unsigned)(n / 128)), dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)m, ldm, batch, h, n, (const _Float16*)bias, (const _Float16*)bias_bn, ldbb, (const _Float16*)res, ldr,
-                       (_Float16*)out, ldo, silu, colstats);
+                       (_Float16*)out, ldo, silu, mscale, colstats);
     return check_launch("sd_winograd_output_f16");
   }
   const long long total = (long long)batch * (h / 2) * (w / 2) * (n / 8);
   hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const _Float16*)m, ldm, batch, h, w, n, (const _Float16*)bias, (const _Float16*)bias_bn, ldbb, (const _Float16*)res,
-                     ldr, (_Float16*)out, ldo, silu);
+                     ldr, (_Float16*)out, ldo, silu, mscale);
   return check_launch("sd_winograd_output_f16");
 }
 
 int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, const void* m, int ldm, const void* bias, const void* bias_bn,
-                             int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, void* v,
-                             void* stream) {
+                             int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, float mscale,
+                             void* v, void* stream) {
   using namespace sd;
   if (plan_recording()) {
     PlanRec r{};
     r.kind = PK_GN_WINO_IN;
     r.p[0] = (void*)x0; r.p[1] = (void*)x1; r.p[2] = (void*)m; r.p[3] = (void*)bias; r.p[4] = (void*)bias_bn; r.p[5] = (void*)gamma;
     r.p[6] = (void*)beta; r.p[7] = v;
-    r.i[0] = c0; r.i[1] = c1; r.i[2] = ldm; r.i[3] = ldbb; r.i[4] = batch; r.i[5] = h; r.i[6] = w; r.i[7] = groups; r.i[8] = silu; r.f[0] = eps;
+    r.i[0] = c0; r.i[1] = c1; r.i[2] = ldm; r.i[3] = ldbb; r.i[4] = batch; r.i[5] = h; r.i[6] = w; r.i[7] = groups; r.i[8] = silu; r.f[0] = eps; r.f[1] = mscale;
     return plan_record(r);
   }
   if ((!x0 && !m) || !gamma || !beta || !v) return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: null pointer");
+  if (m && !(mscale > 0.0f)) return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: mscale must be positive");
   if (m && (x0 || x1 || c1)) return fail(COMA_E_INVALID, "sd_gn_winograd_input_f16: either NHWC sources or plane products, not both");
   const int C = c0 + c1;
   if (c0 <= 0 || c0 % 4 || c1 < 0 || c1 % 4 || (c1 > 0 && !x1) || groups <= 0 || C % groups || (C / groups) % 4)
@@ -515,7 +526,7 @@ int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, con
   GnWinoArgs a;
   a.x0 = (const _Float16*)x0; a.x1 = (const _Float16*)x1; a.c0 = c0; a.c1 = c1; a.m = (const _Float16*)m; a.ldm = ldm;
   a.bias = (const _Float16*)bias; a.bias_bn = (const _Float16*)bias_bn; a.ldbb = ldbb > 0 ? ldbb : C; a.h = h; a.w = w; a.groups = groups;
-  a.eps = eps; a.gamma = (const _Float16*)gamma; a.beta = (const _Float16*)beta; a.silu = silu; a.v = (_Float16*)v;
+  a.eps = eps; a.gamma = (const _Float16*)gamma; a.beta = (const _Float16*)beta; a.silu = silu; a.mscale = mscale; a.v = (_Float16*)v;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if ((C / groups) % 8 == 0 && (!m || ldm % 8 == 0) && a.ldbb % 8 == 0 && al16(m) && al16(bias) && al16(bias_bn) && al16(gamma) && al16(beta) && al16(v))
     hipLaunchKernelGGL(gn_winograd_input_kernel<8>, dim3((unsigned)groups, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);

@@ -101,10 +101,15 @@ class LaunchGraph:
     # ---- Winograd F(2x2,3x3) for the deep ResNet levels (profiles/r04_notes.md 1, 4): input transform -> 16 plane products (the 1x1 GEMM
     # path, nbatch_z = 16) -> output transform with the epilogue.  2.25 x fewer MFMA flops; only worth it where the 4 x larger transformed
     # tensors stay in the Infinity Cache and K = C_in is long -- the 16 x 16 / 8 x 8 levels of the UNet.
+    # fp16 headroom of the STORED planes (sd_hip.h "fp16 range"): U carries 1/4, and V another 1/4 where the input is an un-normalised
+    # tensor (the Upsample2D convolutions: V alone reaches 4 max|d|); the output transforms multiply by 4 / 16 in fp32 -- exact.
+    WINO_USCALE = 0.25
+    WINO_VSCALE_RAW = 0.25
+
     def winograd_weight(self, w9, *, n, c):
-        """w9 fp16 [n][9 * c] (the direct kernel's layout) -> U fp16 [16][n][c] = G g G^T, computed once, here."""
+        """w9 fp16 [n][9 * c] (the direct kernel's layout) -> U fp16 [16][n][c] = WINO_USCALE * G g G^T, computed once, here."""
         U = torch.empty(16, n, c, dtype=torch.float16, device=self.device)        # constants: registered PERSISTENT when first recorded
-        ops.winograd_weight(w9, U, n=n, c=c)
+        ops.winograd_weight(w9, U, n=n, c=c, uscale=self.WINO_USCALE)
         return U
 
     def winograd_planes(self, V, U, *, tiles, c, n):
@@ -113,35 +118,37 @@ class LaunchGraph:
                   alg_flops=2 * 9 * (4 * tiles) * n * c, tag_note=" (winograd planes)")      # counted as the 3x3 convolution these 16 products compute
         return P
 
-    def winograd_input(self, a0, *, batch, h, w, c0, a1=None, c1=0, upsample=False):
+    def winograd_input(self, a0, *, batch, h, w, c0, a1=None, c1=0, upsample=False, vscale=1.0):
         C, T = c0 + c1, batch * (h // 2) * (w // 2)
         V = self.buf(16, T, C)
-        self.add(lambda: ops.winograd_input(a0, V, batch=batch, h=h, w=w, c0=c0, x1=a1, c1=c1, upsample=upsample),
+        self.add(lambda: ops.winograd_input(a0, V, batch=batch, h=h, w=w, c0=c0, x1=a1, c1=c1, upsample=upsample, vscale=vscale),
                  tag=f"winograd input{' (upsampled)' if upsample else ''} B={batch} {h}x{w} C={C}", nbytes=2 * 5 * batch * h * w * C)
         return V
 
     GN_WINO_MAX_SLICE = 20480
 
     def gn_winograd_input(self, gamma, beta, *, batch, h, w, c0, x0=None, x1=None, c1=0, m=None, bias=None, bias_bn=None, ldbb=0, eps, silu=True,
-                          groups=32):
+                          groups=32, vscale_of_m=1.0):
         """GroupNorm (+ SiLU) -> Winograd input transform in ONE launch (sd_gn_winograd_input_f16); the source is [x0 | x1] or the plane
         products `m` of the previous Winograd convolution (its output transform, bias and per-sample bias happen here)."""
         C, T = c0 + c1, batch * (h // 2) * (w // 2)
         assert h * w * (C // groups) <= self.GN_WINO_MAX_SLICE
         V = self.buf(16, T, C)
         self.add(lambda: ops.gn_winograd_input(V, gamma, beta, batch=batch, h=h, w=w, c0=c0, x0=x0, x1=x1, c1=c1, m=m, ldm=c0, bias=bias,
-                                               bias_bn=bias_bn, ldbb=ldbb, groups=groups, eps=eps, silu=silu),
+                                               bias_bn=bias_bn, ldbb=ldbb, groups=groups, eps=eps, silu=silu, mscale=1.0 / (self.WINO_USCALE * vscale_of_m)),
                  tag=f"groupnorm + winograd input{' (from planes)' if m is not None else ''} B={batch} {h}x{w} C={C}",
                  nbytes=2 * (5 + (16 if m is not None else 1)) * batch * h * w * C // (4 if m is not None else 1))
         return V
 
-    def winograd_output(self, P, out, *, batch, h, w, n, bias=None, bias_bn=None, ldbb=0, res=None, stats=False):
-        """stats: also leave the column sums of `out` for the consumer's GroupNorm (w = 32 only: one image row = one 32-row slot)."""
+    def winograd_output(self, P, out, *, batch, h, w, n, bias=None, bias_bn=None, ldbb=0, res=None, stats=False, vscale=1.0):
+        """stats: also leave the column sums of `out` for the consumer's GroupNorm (w = 32 only: one image row = one 32-row slot).
+        vscale: the scale the producer of V applied (the planes are WINO_USCALE * vscale times the true products)."""
+        mscale = 1.0 / (self.WINO_USCALE * vscale)
         cs, M = None, batch * h * w
         if stats and self.fuse_gn_stats and w == 32 and n % 128 == 0 and M >= 16384:
             cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
             self._colstats[out.data_ptr()] = cs
-        self.add(lambda: ops.winograd_output(P, out, batch=batch, h=h, w=w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res, colstats=cs),
+        self.add(lambda: ops.winograd_output(P, out, batch=batch, h=h, w=w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res, colstats=cs, mscale=mscale),
                  tag=f"winograd output{' (+ colstats)' if cs is not None else ''} B={batch} {h}x{w} N={n}",
                  nbytes=2 * (5 + (1 if res is not None else 0)) * batch * h * w * n)
         return out
@@ -169,9 +176,10 @@ class LaunchGraph:
         """The unfused chain: input transform -> plane products -> output transform (+ bias, per-sample bias, residual).  in_h, in_w are
         the convolution's own (= output) resolution; with upsample the sources are [in_h / 2, in_w / 2]."""
         C, T = c0 + c1, batch * (in_h // 2) * (in_w // 2)
-        V = self.winograd_input(a0, batch=batch, h=in_h, w=in_w, c0=c0, a1=a1, c1=c1, upsample=upsample)
+        vs = self.WINO_VSCALE_RAW       # the caller's tensor is not known to be normalised (the UNet's Upsample2D convolutions use this chain)
+        V = self.winograd_input(a0, batch=batch, h=in_h, w=in_w, c0=c0, a1=a1, c1=c1, upsample=upsample, vscale=vs)
         P = self.winograd_planes(V, self.winograd_weight(w9, n=n, c=C), tiles=T, c=C, n=n)
-        return self.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res, stats=stats)
+        return self.winograd_output(P, out, batch=batch, h=in_h, w=in_w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res, stats=stats, vscale=vs)
 
     def dup(self, src, dst):
         """dst = [src | src] along the batch axis (two identical CFG halves); the GroupNorm column sums of src follow."""

@@ -249,25 +249,26 @@ def groupnorm_table_cat(gamma, beta, stats, colstats0, colstats1, *, batch, hw, 
     return stats
 
 
-def winograd_input(x0, v, *, batch, h, w, c0, x1=None, c1=0, upsample=False, gn_affine=None, silu=False):
+def winograd_input(x0, v, *, batch, h, w, c0, x1=None, c1=0, upsample=False, gn_affine=None, silu=False, vscale=1.0):
     """v fp16 [16][batch*h/2*w/2][c0+c1] = B^T d B of every 4x4 patch (F(2x2,3x3), zero pad 1); upsample: [h, w] is the nearest-x2
-    upsampling of the [h/2, w/2] sources."""
+    upsampling of the [h/2, w/2] sources; vscale: power-of-two scale of the stored planes (fp16 headroom, undone by the output transform)."""
     _lib.check(_lib.lib().sd_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, batch, h, w, 1 if upsample else 0,
-                                                _p(gn_affine, "gn_affine", torch.float32), 1 if silu else 0, _p(v, "v"), _stream(v)),
+                                                _p(gn_affine, "gn_affine", torch.float32), 1 if silu else 0, vscale, _p(v, "v"), _stream(v)),
                "sd_winograd_input_f16")
     return v
 
 
-def winograd_weight(w, u, *, n, c):
-    """u fp16 [16][n][c] = G g G^T of w fp16 [n][9][c]."""
-    _lib.check(_lib.lib().sd_winograd_weight_f16(_p(w, "w"), n, c, _p(u, "u"), _stream(u)), "sd_winograd_weight_f16")
+def winograd_weight(w, u, *, n, c, uscale=1.0):
+    """u fp16 [16][n][c] = uscale * G g G^T of w fp16 [n][9][c]."""
+    _lib.check(_lib.lib().sd_winograd_weight_f16(_p(w, "w"), n, c, uscale, _p(u, "u"), _stream(u)), "sd_winograd_weight_f16")
     return u
 
 
-def winograd_output(m, out, *, batch, h, w, n, ldm=0, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, silu=False, colstats=None):
-    """out fp16 [batch*h*w, ldo] = A^T m A of m fp16 [16][T][ldm] (+ bias, per-sample bias, SiLU, residual)."""
+def winograd_output(m, out, *, batch, h, w, n, ldm=0, bias=None, bias_bn=None, ldbb=0, res=None, ldr=0, ldo=0, silu=False, colstats=None,
+                    mscale=1.0):
+    """out fp16 [batch*h*w, ldo] = mscale * A^T m A of m fp16 [16][T][ldm] (+ bias, per-sample bias, SiLU, residual)."""
     rc = _lib.lib().sd_winograd_output_f16(_p(m, "m"), ldm or n, batch, h, w, n, _p(bias, "bias"), _p(bias_bn, "bias_bn"), ldbb,
-                                           _p(res, "res"), ldr, _p(out, "out"), ldo, 1 if silu else 0, _p(colstats, "colstats", torch.float32),
+                                           _p(res, "res"), ldr, _p(out, "out"), ldo, 1 if silu else 0, mscale, _p(colstats, "colstats", torch.float32),
                                            _stream(out))
     _lib.check(rc, "sd_winograd_output_f16")
     return out
@@ -282,10 +283,10 @@ def conv3x3_small_n(x, w, out, *, batch, h, w_, c, n, bias=None, gn_affine=None,
 
 
 def gn_winograd_input(v, gamma, beta, *, batch, h, w, c0, x0=None, x1=None, c1=0, m=None, ldm=0, bias=None, bias_bn=None, ldbb=0, groups=32,
-                      eps=1e-5, silu=True):
+                      eps=1e-5, silu=True, mscale=1.0):
     """v = B^T act(GroupNorm(source)) B, source = [x0 | x1] or the output transform of the plane products m (+ bias, per-sample bias)."""
     rc = _lib.lib().sd_gn_winograd_input_f16(_p(x0, "x0"), _p(x1, "x1"), c0, c1, _p(m, "m"), ldm or c0, _p(bias, "bias"), _p(bias_bn, "bias_bn"),
-                                             ldbb, batch, h, w, groups, eps, _p(gamma), _p(beta), 1 if silu else 0, _p(v, "v"), _stream(v))
+                                             ldbb, batch, h, w, groups, eps, _p(gamma), _p(beta), 1 if silu else 0, mscale, _p(v, "v"), _stream(v))
     _lib.check(rc, "sd_gn_winograd_input_f16")
     return v
 

@@ -195,23 +195,27 @@ int sd_xattn_chain_f16(const void* attn1_out, const void* h, const void* wo1, co
  *                           colstats != NULL (w = 32, n % 128 == 0): also fp32 [batch*h*w/32][2][n], the column sums / sums of squares of
  *                           `out` per 32 rows (sd_conv_gemm_desc.colstats layout: the consumer's GroupNorm statistics)
  * h, w even; channel counts multiples of 8.  sd_winograd_input_f16 / _output_f16 are recordable (sd_winograd_weight_f16 runs at prep time).
+ * fp16 range: V and the plane products are STORED as fp16 (the direct path keeps that sum in fp32 registers), so the transforms take
+ * power-of-two scales -- v = vscale * B^T d B, u = uscale * G g G^T, out = mscale * A^T m A + bias ... with mscale = 1 / (uscale * vscale):
+ * exact in the normal range; the product uses uscale = 1/4 (and vscale = 1/4 where the input is an un-normalised residual stream, V alone
+ * reaching 4 max|d|), which keeps the stored planes 4 x / 16 x further from 65504 (tests/test_sd_ops_gpu.py: outputs peaking at 4e3 ... 3e4).
  * replaces: diffusers Conv2d(3x3) inside self.unet(...) / self.vae.decode, utils/adaptive_mask_inpainting.py:1001-1007, :1086, :1112. */
 int sd_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, int batch, int h, int w, int upsample, const float* gn_affine, int silu,
-                          void* v, void* stream);
-int sd_winograd_weight_f16(const void* w, int n, int c, void* u, void* stream);
+                          float vscale, void* v, void* stream);
+int sd_winograd_weight_f16(const void* w, int n, int c, float uscale, void* u, void* stream);
 int sd_winograd_output_f16(const void* m, int ldm, int batch, int h, int w, int n, const void* bias, const void* bias_bn, int ldbb,
-                           const void* res, int ldr, void* out, int ldo, int silu, float* colstats, void* stream);
+                           const void* res, int ldr, void* out, int ldo, int silu, float mscale, float* colstats, void* stream);
 /* GroupNorm (+ SiLU) of a SMALL feature map fused with the Winograd input transform, one workgroup per (sample, group), the group's
  * slice in LDS (h * w * C / groups <= 20480 elements: the 16 x 16 / 8 x 8 levels of the UNet):
  *   source = the channel concatenation [x0 | x1] (NHWC fp16; m == NULL), or
- *   source = A^T m A + bias + per-sample bias of the 16 plane products m fp16 [16][batch*h/2*w/2][ldm] of the PREVIOUS Winograd
+ *   source = mscale * A^T m A + bias + per-sample bias of the 16 plane products m fp16 [16][batch*h/2*w/2][ldm] of the PREVIOUS Winograd
  *            convolution (x0 == x1 == NULL, c0 = its output channels, c1 = 0), rounded to fp16 and never written;
  *   v fp16 [16][batch*h/2*w/2][c0+c1] = B^T act(GroupNorm(source)) B.
  * Replaces sd_winograd_output_f16 -> sd_groupnorm_f16 -> sd_winograd_input_f16 (conv1 -> norm2 -> SiLU -> conv2 of a ResnetBlock2D)
  * or sd_groupnorm_f16 -> sd_winograd_input_f16 (norm1 -> SiLU -> conv1) with one launch.  Recordable. */
 int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, const void* m, int ldm, const void* bias, const void* bias_bn,
-                             int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, void* v,
-                             void* stream);
+                             int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, float mscale,
+                             void* v, void* stream);
 
 /* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with FEW (n <= 4) output channels:
  *   out[m, 0:n] = conv3x3(act(x * scale + shift))[m, 0:n] + bias,   act = SiLU if silu else identity
