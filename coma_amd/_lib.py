@@ -58,6 +58,7 @@ SIGNATURES = {
     "sd_winograd_output_f16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp]),
     "sd_groupnorm_table_cat_f16": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sd_conv3x3_small_n_f16": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "sd_conv3x3_halo_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "sd_gn_winograd_input_f16": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _f, _vp, _vp]),
     "sd_im2col3x3_c3_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "sd_softmax_f16": (_i, [_vp, _i64, _i, _i, _f, _vp]),

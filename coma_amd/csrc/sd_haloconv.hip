@@ -1,0 +1,351 @@
+// sd_haloconv.hip -- GroupNorm affine + SiLU + 3x3 / stride 1 / pad 1 convolution with 128 OUTPUT channels as a halo-patch ("direct")
+// convolution on gfx950: the 128-channel layers of the VAE at 512 x 512 (decoder up_blocks.3, encoder down_blocks.0;
+// self.vae.decode / self.vae.encode, utils/adaptive_mask_inpainting.py:1086, :1112, :677-680).
+//
+// Why not the implicit GEMM (sd_gemm.hip): with N = 128 every activation row is re-staged through L2 -> LDS nine times (once per tap)
+// for only 128 output columns -- 756 TF/s isolated, 670 TF/s inside the VAE graphs -- and every such layer sits behind a GroupNorm
+// apply pass that reads and writes the 0.5 GB tensor once more (0.26 ms).  Here a workgroup (4 waves, two workgroups per CU) owns a
+// 16 x 16 pixel tile x all 128 output channels:
+//   * per 64-channel chunk the (18 x 18) halo patch is fetched ONCE, normalised (per-(sample, channel) affine table of the GroupNorm,
+//     statistics from the producer's column sums), activated, rounded to fp16 -- exactly what the GroupNorm kernel would have stored --
+//     and written to LDS in XOR-swizzled 16-byte slots; the nine taps read it at shifted positions (one conflict-free ds_read_b128 per
+//     MFMA operand); the next chunk's global loads are in flight under this chunk's MFMAs;
+//   * the weights stream through two LDS stages per (tap, chunk) slice [128][64] by LDS-DMA (`buffer_load ... lds`, source-side XOR
+//     swizzle, counted vmcnt, one raw s_barrier per slice) like the implicit GEMM's W operand;
+//   * `v_mfma_f32_16x16x32_f16`, D = W_frag . pixel_frag^T: a wave owns 4 tile rows (64 pixels) x 128 channels = 32 accumulator tiles,
+//     64 MFMAs per slice against 24 LDS fragment reads;
+//   * epilogue through LDS in two channel halves (fp32 staging): bias, residual, ONE rounding to fp16, 16-byte coalesced stores and, on
+//     request, the column sums / sums of squares of the stored tensor for the consumer's GroupNorm: a wave's 64 pixels (four tile rows)
+//     fill the first of its two 32-pixel slots, the second holds zeros -- the consumer adds a sample's slots up in any order.
+// Algorithmic bytes: the input read once (+ 27 % halo), the output written once, the residual read once.
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "sd_plan.h"
+#include "../../include/sd_hip.h"
+
+namespace sd {
+namespace hc {
+
+using coma::check_launch;
+using coma::fail;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kTile = 16, kHalo = 18, kChunk = 64, kN = 128;
+constexpr int kPatchBytes = kHalo * kHalo * 8 * 16;      // 41 472: 324 pixels x 8 octets of 8 channels
+constexpr int kWStage = kN * kChunk * 2;                 // 16 384: one (tap, chunk) weight slice [128][64]
+constexpr int kAffOff = kPatchBytes + 2 * kWStage;       // 74 240
+constexpr int kMaxC = 256;
+constexpr int kLds = kAffOff + kMaxC * 8;                // 76 288 bytes: two workgroups per CU
+constexpr int kStageRow = 64 * 4 + 16;                   // epilogue staging: 64 fp32 channels + 16 bytes of padding per pixel
+static_assert(4 * 64 * kStageRow <= kAffOff, "epilogue staging overlays the patch and the weight stages");
+
+// slot of 16-byte channel octet v (0..7) of halo pixel p: 16 consecutive pixels x one octet hit 16 distinct bank groups
+__device__ __forceinline__ int slot(int p, int v) { return p * 8 + (v ^ ((p >> 1) & 7)); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct HaloArgs {
+  const _Float16* x;          // NHWC [batch][H][W][C]
+  const float* affine;        // fp32 [batch][C][2] = (scale, shift) or nullptr
+  int silu;
+  const _Float16* w;          // [128][9][C]
+  const _Float16* bias;       // [128] or nullptr
+  const _Float16* res;        // [batch*H*W][ldr] or nullptr
+  int ldr;
+  int C, H, W;
+  _Float16* out;              // [batch*H*W][ldo]
+  int ldo;
+  float* colstats;            // fp32 [batch*H*W/32][2][128] or nullptr
+  int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kLds];
+  half8* const tile = reinterpret_cast<half8*>(lds);
+  unsigned char* const wst = lds + kPatchBytes;
+  float2* const aff = reinterpret_cast<float2*>(lds + kAffOff);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lp = lane & 15, lo = lane >> 4;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int ty0 = ty * kTile, tx0 = tx * kTile;
+  const int C = a.C, nchunk = C / kChunk;
+  const _Float16* const xb = a.x + (size_t)b * a.H * a.W * C;
+
+  // ---- weight slices by LDS-DMA: instruction j of this wave covers rows (wave * 4 + j) * 8 .. + 7 of the slice; lane -> row + lane / 8,
+  // LDS slot lane % 8, which must receive K octet slot ^ ((row >> 1) & 7)
+  auto make_rsrc = [](const void* p) {
+    const unsigned long long q = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)q), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi32 << 32) | lo32), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(a.w);
+  unsigned w_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 8 + (lane >> 3);
+    w_off[j] = (unsigned)(r * 9 * C) * 2u + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+  }
+  auto issue_w = [&](int kt) {                            // slice kt = chunk * 9 + tap into stage kt & 1
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int chunk = kt / 9, tap = kt - chunk * 9;
+    const int soff = __builtin_amdgcn_readfirstlane((tap * C + chunk * kChunk) * 2);
+    unsigned char* dst = wst + (kt & 1) * kWStage + wave * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(dst + j * 1024), 16, w_off[j], soff, 0, 0);
+#endif
+  };
+
+  // ---- halo patch: fetch = all of a chunk's global loads of this thread (11 independent 16-byte buffer loads, every wave issues all 11 so
+  // that the counted vmcnt below means the same in every wave; one 32-bit offset per load, pad pixels carry an out-of-range offset and
+  // come back as zeros), commit = normalise + activate + LDS write.  Slots and validity are recomputed at every commit from an opaque
+  // copy of the thread id: hoisted out of the chunk loop they would cost 30 registers next to the 128 accumulators (and spill).
+  constexpr int kVec = kHalo * kHalo * 8, kPer = (kVec + 255) / 256;      // 2592 vectors, 11 per thread
+  const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(xb);
+  unsigned xoff[kPer];
+#pragma unroll
+  for (int it = 0; it < kPer; ++it) {
+    const int idx = tid + it * 256;
+    const int p = idx >> 3, v = idx & 7;
+    const int r = p / kHalo, c = p - r * kHalo;
+    const int y = ty0 + r - 1, xx = tx0 + c - 1;
+    const bool ok = idx < kVec && y >= 0 && y < a.H && xx >= 0 && xx < a.W;
+    xoff[it] = ok ? (unsigned)((y * a.W + xx) * C + v * 8) * 2u : 0x80000000u;
+  }
+  half8 q[kPer];
+  auto fetch = [&](int chunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int soff = __builtin_amdgcn_readfirstlane(chunk * kChunk * 2);
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) q[it] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff[it], soff, 0));
+#endif
+  };
+  auto commit = [&](int chunk) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));                           // opaque: nothing below is loop-invariant as far as the compiler can tell
+    // idx = tid + 256 it: the channel octet v = tid & 7 is the same for all of a thread's vectors -> its 8 (scale, shift) pairs are read
+    // from LDS ONCE per chunk (read per element they were 88 LDS reads per thread and chunk: 80 us of a 745 us layer)
+    float2 sc8[8];
+    if (a.affine) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc8[e] = aff[chunk * kChunk + (t_ & 7) * 8 + e];
+    }
+#pragma unroll
+    for (int it = 0; it < kPer; ++it) {
+      const int idx = t_ + it * 256;
+      if (idx < kVec) {
+        const int p = idx >> 3, v = idx & 7;
+        half8 z = q[it];
+        if (a.affine && (int)xoff[it] >= 0) {              // zero padding applies to the ACTIVATED tensor: pad pixels stay 0
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = fmaf((float)z[e], sc8[e].x, sc8[e].y);
+            if (a.silu) f = f * __builtin_amdgcn_rcpf(1.0f + __expf(-f));
+            z[e] = (_Float16)f;
+          }
+        }
+        tile[slot(p, v)] = z;
+      }
+    }
+  };
+
+  float4v acc[4][8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  issue_w(0);
+  fetch(0);
+  if (a.affine)
+    for (int i = tid; i < C; i += 256) aff[i] = reinterpret_cast<const float2*>(a.affine)[(size_t)b * C + i];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                            // `aff` is visible
+
+  // W fragment: row = 16 j + (lane & 15), K octet = 4 kh + (lane >> 4); the swizzle term looks at row bits 1-3 only, so tile j is a
+  // constant byte offset
+  const int wrow = lp;
+  int w_fo[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) w_fo[kh] = wrow * 128 + (((kh * 4 + lo) ^ ((wrow >> 1) & 7)) * 16);
+
+  const int nkt = 9 * nchunk;
+  // epilogue read-back role (also the role in which the residual is prefetched): pixel 8 it + ps of this wave's 64, channel octet c8
+  const int ps = lane >> 3, c8 = (lane & 7) * 8;
+  const size_t m_base = ((size_t)b * a.H + ty0 + 4 * wave) * a.W + tx0;                 // pixel (t, col) of this wave = m_base + t * W + col
+#pragma unroll 1
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    if (chunk > 0) __builtin_amdgcn_s_barrier();           // every wave is done reading the previous chunk's patch
+    commit(chunk);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kt = chunk * 9 + tap;
+      // slice kt has landed (this wave's share); the next chunk's patch loads, issued during tap 0 BEHIND slice kt + 1, may stay in flight
+      // (in the LAST chunk the idle patch registers take the residual rows of the epilogue's first channel half instead: 8 loads)
+      if (tap == 1 && chunk + 1 < nchunk) wait_vmcnt<kPer>();
+      else if (tap == 1 && a.res) wait_vmcnt<8>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                        // ... everyone's share; and everyone is done with stage (kt + 1) & 1 and has committed
+      if (kt + 1 < nkt) issue_w(kt + 1);
+      asm volatile("" ::: "memory");                       // the loads below must be issued BEHIND the slice: the counted vmcnt relies on it
+      if (tap == 0 && chunk + 1 < nchunk) fetch(chunk + 1);
+      if (tap == 0 && chunk + 1 == nchunk && a.res) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int pw = it * 8 + ps;
+          q[it] = *reinterpret_cast<const half8*>(a.res + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldr + c8);
+        }
+      }
+      const unsigned char* ws = wst + (kt & 1) * kWStage;
+      const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        half8 pf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pf[t] = tile[slot((4 * wave + t + dy) * kHalo + lp + dx, kh * 4 + lo)];
+        // the W fragments come in two halves of four column tiles: 16 fewer registers live next to the 128 accumulators + the prefetched patch
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+          half8 wf[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const half8*>(ws + w_fo[kh] + (jh * 4 + j) * 2048);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], pf[t], acc[t][jh * 4 + j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();                            // every wave is done with the patch and the weight stages
+
+  // ---- epilogue.  acc[t][j][r] = output channel 16 j + 4 lo + r of pixel (tile row 4 wave + t, column lp).  Two channel halves through
+  // this wave's fp32 staging area [64 pixels][64 channels (+ pad)], read back as (pixel = 8 it + lane / 8, 8 channels = lane % 8).
+  unsigned char* const stg = lds + wave * (64 * kStageRow);
+  // residual rows: the first channel half was prefetched under the last chunk's MFMAs (into the idle patch registers), the second half
+  // is requested as soon as the first half's accumulators have been staged (their registers are free then)
+  half8 rres[2][8];
+  if (a.res) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rres[0][it] = q[it];
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4v*>(stg + (t * 16 + lp) * kStageRow + (j * 16 + lo * 4) * 4) = acc[t][hf * 4 + j];
+    if (hf == 0 && a.res) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int pw = it * 8 + ps;
+        rres[1][it] = *reinterpret_cast<const half8*>(a.res + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldr + 64 + c8);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.0f;
+    if (a.bias) {
+      const half8 bq = *reinterpret_cast<const half8*>(a.bias + hf * 64 + c8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = (float)bq[e];
+    }
+    // statistics: ONE fold per channel half over this wave's 64 pixels (= two slots of 32: the sums go to the first, zeros to the second --
+    // the consumer adds a sample's slots up in any order; folding each 32-pixel slot on its own cost twice the cross-lane traffic)
+    float cs[8], cq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int pw = it * 8 + ps;
+      const float4v v0 = *reinterpret_cast<const float4v*>(stg + pw * kStageRow + c8 * 4);
+      const float4v v1 = *reinterpret_cast<const float4v*>(stg + pw * kStageRow + c8 * 4 + 16);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = v[e] + bv[e];
+        if (a.res) f += (float)rres[hf][it][e];
+        o[e] = (_Float16)f;
+        const float g = (float)o[e];                       // statistics of the stored (fp16-rounded) tensor
+        cs[e] += g;
+        cq[e] += g * g;
+      }
+      *reinterpret_cast<half8*>(a.out + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldo + hf * 64 + c8) = o;
+    }
+    if (a.colstats) {
+      // fold the 8 pixel lanes that share a channel octet (lane bits 3-5), fixed order -> reproducible
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {                         // lane ^ 8 inside a row of 16 lanes: a DPP row rotation by 8 (VALU speed)
+        cs[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs[e]), 0x128, 0xf, 0xf, false));
+        cq[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cq[e]), 0x128, 0xf, 0xf, false));
+      }
+#pragma unroll
+      for (int mask = 16; mask < 64; mask <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          cs[e] += __shfl_xor(cs[e], mask);
+          cq[e] += __shfl_xor(cq[e], mask);
+        }
+      if (lane < 16) {                                      // lanes 0-7: the sums into slot 2 wave, lanes 8-15: zeros into slot 2 wave + 1
+        const size_t slot_id = (((size_t)b * a.tiles_y + ty) * a.tiles_x + tx) * 8 + wave * 2 + (lane >> 3);
+        const float zf = lane < 8 ? 1.0f : 0.0f;
+        float* dst = a.colstats + slot_id * 2 * kN + hf * 64 + c8;
+        *reinterpret_cast<float4v*>(dst) = float4v{zf * cs[0], zf * cs[1], zf * cs[2], zf * cs[3]};
+        *reinterpret_cast<float4v*>(dst + 4) = float4v{zf * cs[4], zf * cs[5], zf * cs[6], zf * cs[7]};
+        *reinterpret_cast<float4v*>(dst + kN) = float4v{zf * cq[0], zf * cq[1], zf * cq[2], zf * cq[3]};
+        *reinterpret_cast<float4v*>(dst + kN + 4) = float4v{zf * cq[4], zf * cq[5], zf * cq[6], zf * cq[7]};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace hc
+}  // namespace sd
+
+extern "C" int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine, int silu, const void* w, const void* bias, const void* res,
+                                   int ldr, int batch, int h, int w_, int n, void* out, int ldo, float* colstats, void* stream) {
+  using namespace sd::hc;
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_CONV_HALO;
+    r.p[0] = (void*)x; r.p[1] = (void*)gn_affine; r.p[2] = (void*)w; r.p[3] = (void*)bias; r.p[4] = (void*)res; r.p[5] = out; r.p[6] = colstats;
+    r.i[0] = c; r.i[1] = silu; r.i[2] = ldr; r.i[3] = batch; r.i[4] = h; r.i[5] = w_; r.i[6] = n; r.i[7] = ldo;
+    return sd::plan_record(r);
+  }
+  if (!x || !w || !out) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: null pointer");
+  if (n != kN) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: n = %d (built for 128 output channels)", n);
+  if (c <= 0 || c % kChunk || c > kMaxC) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: c = %d (a multiple of 64, at most %d)", c, kMaxC);
+  if (batch <= 0 || h <= 0 || w_ <= 0 || h % kTile || w_ % kTile)
+    return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: batch=%d h=%d w=%d (h, w multiples of 16)", batch, h, w_);
+  if (ldo == 0) ldo = n;
+  if (ldr == 0) ldr = n;
+  if (ldo < n || ldo % 8 || (res && (ldr < n || ldr % 8))) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: ldo = %d, ldr = %d", ldo, ldr);
+  if ((long long)n * 9 * c * 2 >= 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: weights too large");
+  const long long tiles = (long long)batch * (h / kTile) * (w_ / kTile);
+  if (tiles > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: grid too large");
+  HaloArgs a;
+  a.x = (const _Float16*)x; a.affine = gn_affine; a.silu = silu; a.w = (const _Float16*)w; a.bias = (const _Float16*)bias;
+  a.res = (const _Float16*)res; a.ldr = ldr; a.C = c; a.H = h; a.W = w_; a.out = (_Float16*)out; a.ldo = ldo; a.colstats = colstats;
+  a.tiles_x = w_ / kTile; a.tiles_y = h / kTile;
+  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("conv3x3_halo_kernel");
+}

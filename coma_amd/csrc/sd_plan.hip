@@ -130,6 +130,9 @@ static int launch(const PlanRec& r, void* st) {
     case PK_GN_TABLE_CAT:
       return sd_groupnorm_table_cat_f16((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], p[0], p[1], (float*)p[2], (const float*)p[3],
                                         (const float*)p[4], st);
+    case PK_CONV_HALO:
+      return sd_conv3x3_halo_f16(p[0], (int)i[0], (const float*)p[1], (int)i[1], p[2], p[3], p[4], (int)i[2], (int)i[3], (int)i[4], (int)i[5],
+                                 (int)i[6], p[5], (int)i[7], (float*)p[6], st);
     case PK_COPY:
       return sd_copy_d2d(p[0], p[1], (size_t)i[0], st);
     default:

@@ -262,6 +262,25 @@ class LaunchGraph:
                  flops=2 * batch * hw * n * 9 * c, tag=f"conv3x3(small n) B={batch} {h}x{w_} C={c} n={n}", nbytes=2 * batch * hw * (c + 8))
         return out
 
+    def gn_silu_conv3x3_halo(self, x, gamma, beta, w, bias, out, *, batch, h, w_, c, n, eps, silu=True, res=None, stats=False):
+        """GroupNorm (+ SiLU) -> 3x3 convolution with 128 output channels as a halo-patch convolution (sd_conv3x3_halo_f16): only the
+        per-(sample, channel) affine table is computed (statistics from the producer's column sums when it left them), the normalised
+        tensor is never written; stats: leave the column sums of `out` for the next GroupNorm."""
+        hw = h * w_
+        table = self.gn_scratch(batch, hw)
+        cs0 = self._colstats.get(x.data_ptr()) if hw % 32 == 0 else None
+        self.add(lambda: ops.groupnorm_table(x, gamma, beta, table, batch=batch, hw=hw, c0=c, eps=eps, colstats0=cs0),
+                 tag=f"groupnorm(table) B={batch} hw={hw} C={c}")
+        cs = None
+        if stats and self.fuse_gn_stats and hw % 32 == 0:
+            cs = self.buf(batch * hw // 32, 2, n, dtype=torch.float32, zero=True)
+            self._colstats[out.data_ptr()] = cs
+        self.add(lambda: ops.conv3x3_halo(x, w, out, batch=batch, h=h, w_=w_, c=c, n=n, bias=bias, res=res, gn_affine=table, silu=silu,
+                                          colstats=cs, ldo=out.shape[-1]),
+                 flops=2 * batch * hw * n * 9 * c, tag=f"conv3x3(halo) B={batch} {h}x{w_} C={c} n={n}",
+                 nbytes=2 * batch * hw * (c + n * (2 if res is not None else 1)) + 2 * n * 9 * c)
+        return out
+
     def attention_wide(self, q, k, vt, out, *, batch, heads, lq, lk, d, ldq, ldk, ldv, ldo):
         self.add(lambda: ops.attention_wide(q, k, vt, out, batch=batch, heads=heads, lq=lq, lk=lk, d=d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
                                             scale=d ** -0.5),

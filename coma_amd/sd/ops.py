@@ -282,6 +282,15 @@ def conv3x3_small_n(x, w, out, *, batch, h, w_, c, n, bias=None, gn_affine=None,
     return out
 
 
+def conv3x3_halo(x, w, out, *, batch, h, w_, c, n=128, bias=None, res=None, gn_affine=None, silu=False, colstats=None, ldo=0, ldr=0):
+    """out[:, 0:128] = conv3x3(act(x * scale + shift)) + bias (+ res): halo-patch convolution with 128 output channels (sd_haloconv.hip)."""
+    rc = _lib.lib().sd_conv3x3_halo_f16(_p(x, "x"), c, _p(gn_affine, "gn_affine", torch.float32), 1 if silu else 0, _p(w, "w"), _p(bias, "bias"),
+                                        _p(res, "res"), ldr, batch, h, w_, n, _p(out, "out"), ldo, _p(colstats, "colstats", torch.float32),
+                                        _stream(out))
+    _lib.check(rc, "sd_conv3x3_halo_f16")
+    return out
+
+
 def gn_winograd_input(v, gamma, beta, *, batch, h, w, c0, x0=None, x1=None, c1=0, m=None, ldm=0, bias=None, bias_bn=None, ldbb=0, groups=32,
                       eps=1e-5, silu=True, mscale=1.0):
     """v = B^T act(GroupNorm(source)) B, source = [x0 | x1] or the output transform of the plane products m (+ bias, per-sample bias)."""

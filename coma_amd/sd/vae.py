@@ -23,6 +23,8 @@ class _VaeBase:
     upsample_phases = True       # class-level switch (tests / A-B): False = Upsample2D convolutions as 3x3 over the upsampled tensor
     packed_conv_in = True        # class-level switch (tests / A-B): False = encoder conv_in as a K = 576 implicit GEMM over the 64-channel padded input
     fused_conv_out = True        # class-level switch (tests / A-B): False = GroupNorm kernel + 64-column implicit-GEMM tile for conv_out
+    halo_conv = True             # class-level switch (tests / A-B): False = GroupNorm kernel + implicit GEMM for the 128-channel 3x3 convolutions
+    halo_min_tiles = 512         # ... from this many 16 x 16 tiles on (two per CU)
     fused_attention = True       # class-level switch (tests / A-B): False = QK^T GEMM -> softmax -> PV GEMM through memory
 
     def __init__(self, state, batch, device, cfg, use_graph=True, plan="decode"):
@@ -33,16 +35,24 @@ class _VaeBase:
         self.s = {k: v.to(self.device, F16) for k, v in state.items()}
         self.g = LaunchGraph(self.device, plan=plan)
 
+    def _halo(self, cin, cout, H, W):
+        """GroupNorm + SiLU + conv3x3 as ONE halo-patch convolution (sd_conv3x3_halo_f16) where it was built and measured: 128 output
+        channels, at most 256 input channels, feature maps in whole 16 x 16 tiles that fill the chip (the 512 x 512 level of the VAE)."""
+        return (self.halo_conv and cout == 128 and cin % 64 == 0 and cin <= 256 and H % 16 == 0 and W % 16 == 0
+                and self.batch * (H // 16) * (W // 16) >= self.halo_min_tiles)
+
     def _resnet(self, p, x, cin, cout, H, W):
         g, s, B = self.g, self.s, self.batch
         M = B * H * W
-        n1 = g.buf(M, cin)
-        g.groupnorm(x, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=cin, eps=1e-6, silu=True)
         h = g.buf(M, cout)
-        g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9, bias=s[p + ".conv1.bias"],
-               stats=True)
-        n2 = g.buf(M, cout)
-        g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-6, silu=True)
+        if self._halo(cin, cout, H, W):
+            g.gn_silu_conv3x3_halo(x, s[p + ".norm1.weight"], s[p + ".norm1.bias"], conv_weight(s[p + ".conv1.weight"]), s[p + ".conv1.bias"], h,
+                                   batch=B, h=H, w_=W, c=cin, n=cout, eps=1e-6, stats=True)
+        else:
+            n1 = g.buf(M, cin)
+            g.groupnorm(x, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=cin, eps=1e-6, silu=True)
+            g.conv(n1, conv_weight(s[p + ".conv1.weight"]), h, batch=B, in_h=H, in_w=W, c0=cin, n=cout, taps=9, bias=s[p + ".conv1.bias"],
+                   stats=True)
         if p + ".conv_shortcut.weight" in s:
             sc = g.buf(M, cout)
             g.conv(x, conv_weight(s[p + ".conv_shortcut.weight"]), sc, batch=B, in_h=H, in_w=W, c0=cin, n=cout,
@@ -50,8 +60,14 @@ class _VaeBase:
         else:
             sc = x
         out = g.buf(M, cout)
-        g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
-               bias=s[p + ".conv2.bias"], res=sc, stats=True)
+        if self._halo(cout, cout, H, W):
+            g.gn_silu_conv3x3_halo(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], conv_weight(s[p + ".conv2.weight"]), s[p + ".conv2.bias"], out,
+                                   batch=B, h=H, w_=W, c=cout, n=cout, eps=1e-6, res=sc, stats=True)
+        else:
+            n2 = g.buf(M, cout)
+            g.groupnorm(h, s[p + ".norm2.weight"], s[p + ".norm2.bias"], n2, batch=B, hw=H * W, c0=cout, eps=1e-6, silu=True)
+            g.conv(n2, conv_weight(s[p + ".conv2.weight"]), out, batch=B, in_h=H, in_w=W, c0=cout, n=cout, taps=9,
+                   bias=s[p + ".conv2.bias"], res=sc, stats=True)
         return out
 
     def _attention(self, p, x, C, H, W):

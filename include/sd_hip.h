@@ -217,6 +217,20 @@ int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, con
                              int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, float mscale,
                              void* v, void* stream);
 
+/* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with 128 OUTPUT channels, as a halo-patch ("direct")
+ * convolution (coma_amd/csrc/sd_haloconv.hip): the 128-channel layers of the VAE at 512 x 512, where the implicit GEMM re-stages every
+ * activation nine times for only 128 columns and sits behind a GroupNorm apply pass over the 0.5 GB tensor.
+ *   x fp16 NHWC [batch][h][w][c], c in {64, 128, 192, 256}, h and w multiples of 16;
+ *   gn_affine fp32 [batch][c][2] = (scale, shift) of the GroupNorm (sd_groupnorm_table_f16), or NULL for a plain convolution;
+ *   out[m, 0:128] = conv3x3(act(x * scale + shift)) + bias (+ res[m, 0:128]), act = SiLU if silu, zero padding of the ACTIVATED tensor;
+ *   colstats != NULL: fp32 [batch*h*w/32][2][128], sums / sums of squares of the stored output per 32 pixels (sd_conv_gemm_desc.colstats
+ *   as far as a GroupNorm consumer is concerned: every pixel of a sample is counted in exactly one of the sample's h*w/32 slots; the slots
+ *   hold the sums of four rows of a 16 x 16 pixel tile alternating with zeros, not 32 consecutive rows of the matrix).  Recordable.
+ * replaces: GroupNorm -> SiLU -> Conv2d(3x3) of ResnetBlock2D inside self.vae.decode / self.vae.encode,
+ * utils/adaptive_mask_inpainting.py:1086, :1112, :677-680. */
+int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine, int silu, const void* w, const void* bias, const void* res, int ldr,
+                        int batch, int h, int w_, int n, void* out, int ldo, float* colstats, void* stream);
+
 /* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with FEW (n <= 4) output channels:
  *   out[m, 0:n] = conv3x3(act(x * scale + shift))[m, 0:n] + bias,   act = SiLU if silu else identity
  * x fp16 NHWC [batch, h, w, c] (c = 128 or 320); gn_affine fp32 [batch][c][2] = (scale, shift) per sample and channel (the table of

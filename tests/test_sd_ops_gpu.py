@@ -618,6 +618,50 @@ def test_conv3x3_small_n_with_folded_groupnorm(ops, B, H, W, n, norm, silu, C):
         ops.conv3x3_small_n(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=5)
 
 
+@pytest.mark.parametrize("B,H,W,C,norm,silu,res,stats", [(2, 32, 48, 128, True, True, False, True), (1, 16, 16, 256, True, True, True, True),
+                                                         (3, 48, 32, 128, False, False, True, False), (1, 64, 64, 64, True, False, False, True),
+                                                         (2, 16, 32, 192, True, True, True, False)])
+def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, stats):
+    """sd_conv3x3_halo_f16 (GroupNorm affine + SiLU + 3x3 convolution with 128 output channels as a halo-patch convolution: the VAE's
+    128-channel layers) against affine -> SiLU -> fp16 rounding -> conv2d (+ bias, + residual) in fp32: one to four 64-channel chunks,
+    tiles at every image border, several tiles per sample; and the column sums it leaves for the next GroupNorm against sums over the
+    stored tensor -- per slot (two rows of a 16 x 16 tile) and per sample."""
+    n, hw = 128, H * W
+    x = rnd(B * hw, C, seed=1) * 1.5 + 0.3
+    w = rnd(n, 9, C, seed=2, scale=(9 * C) ** -0.5)
+    b = rnd(n, seed=3)
+    r = rnd(B * hw, n, seed=4) if res else None
+    table = None
+    xa = x.float()
+    if norm:
+        g = torch.Generator().manual_seed(5)
+        table = torch.stack([torch.rand(B, C, generator=g) + 0.5, torch.randn(B, C, generator=g) * 0.3], -1).contiguous()     # (scale, shift)
+        xa = xa.reshape(B, hw, C) * table[:, None, :, 0] + table[:, None, :, 1]
+        if silu:
+            xa = torch.nn.functional.silu(xa)
+        xa = xa.reshape(B * hw, C).half().float()            # the kernel rounds the activated tensor to fp16, as the GroupNorm kernel would store it
+    ref = so.conv_ref(xa, w, batch=B, h=H, w_=W, taps=9, bias=b, res=r)
+    out = torch.full((B * hw, n), 7.0, dtype=F16, device=DEV)
+    cs = torch.zeros(B * hw // 32, 2, n, dtype=torch.float32, device=DEV) if stats else None
+    ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, bias=b.to(DEV), res=r.to(DEV) if res else None,
+                     gn_affine=table.to(DEV) if norm else None, silu=silu and norm, colstats=cs)
+    close(out, ref)
+    if stats:
+        o = out.float().cpu().reshape(B, H // 16, 16, W // 16, 16, n).permute(0, 1, 3, 2, 4, 5)      # [b, ty, tx, row, col, n]
+        o = o.reshape(B * (H // 16) * (W // 16) * 4, 64, n)                                         # four rows of a tile = one wave
+        c = cs.cpu().reshape(-1, 2, 2, n)                                                           # [wave][slot pair][sum | sumsq][n]: sums, zeros
+        assert torch.allclose(c[:, 0, 0], o.sum(1), rtol=1e-4, atol=4e-3) and torch.allclose(c[:, 0, 1], (o * o).sum(1), rtol=1e-4, atol=4e-3)
+        assert float(c[:, 1].abs().max()) == 0.0
+        c = cs.cpu()
+        per = hw // 32
+        tot = out.float().cpu().reshape(B, hw, n).sum(1)
+        assert torch.allclose(c[:, 0].reshape(B, per, n).sum(1), tot, rtol=1e-4, atol=2e-2)
+    with pytest.raises(Exception, match="multiples of 16"):
+        ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H - 1, w_=W, c=C)
+    with pytest.raises(Exception, match="128 output channels"):
+        ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=64)
+
+
 @pytest.mark.parametrize("B,H,W,c0,c1,n", [(2, 16, 16, 64, 0, 128), (1, 8, 12, 64, 64, 64), (3, 32, 32, 320, 0, 320)])
 def test_winograd_f2x2_3x3_chain_equals_the_direct_convolution(ops, B, H, W, c0, c1, n):
     """The measured Winograd probe (profiles/r04_notes.md 1; not part of the UNet / VAE plans): input transform -> 16 plane products
