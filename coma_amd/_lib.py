@@ -50,7 +50,7 @@ SIGNATURES = {
     "sd_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sd_attention_wide_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "sd_xattn_chain_f16": (_i, [_vp] * 15 + [_i64, _i, _i, _i, _f, _vp, _i, _vp]),
-    "sd_groupnorm_table_f16": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "sd_groupnorm_table_f16": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp]),
     "sd_xfront_f16": (_i, [_vp] * 11 + [_i64, _i, _i, _f, _vp]),
     "sd_xtail_f16": (_i, [_vp] * 11 + [_i64, _vp]),
     "sd_winograd_input_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _vp, _vp]),

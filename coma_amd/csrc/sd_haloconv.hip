@@ -15,8 +15,9 @@
 //   * `v_mfma_f32_16x16x32_f16`, D = W_frag . pixel_frag^T: a wave owns 4 tile rows (64 pixels) x 128 channels = 32 accumulator tiles,
 //     64 MFMAs per slice against 24 LDS fragment reads;
 //   * epilogue through LDS in two channel halves (fp32 staging): bias, residual, ONE rounding to fp16, 16-byte coalesced stores and, on
-//     request, the column sums / sums of squares of the stored tensor for the consumer's GroupNorm: a wave's 64 pixels (four tile rows)
-//     fill the first of its two 32-pixel slots, the second holds zeros -- the consumer adds a sample's slots up in any order.
+//     request, the column sums / sums of squares of the stored tensor for the consumer's GroupNorm, ONE slot per workgroup / tile
+//     (sd_groupnorm_table_f16 with rows_per_slot = 256: 8 x fewer slots than the GEMM epilogue's, whose 67 MB at 512 x 512 cost the
+//     consumer's table launch 84-120 us).
 // Algorithmic bytes: the input read once (+ 27 % halo), the output written once, the residual read once.
 #include <hip/hip_fp16.h>
 
@@ -43,7 +44,7 @@ constexpr int kAffOff = kPatchBytes + 2 * kWStage;       // 74 240
 constexpr int kMaxC = 256;
 constexpr int kLds = kAffOff + kMaxC * 8;                // 76 288 bytes: two workgroups per CU
 constexpr int kStageRow = 64 * 4 + 16;                   // epilogue staging: 64 fp32 channels + 16 bytes of padding per pixel
-static_assert(4 * 64 * kStageRow <= kAffOff, "epilogue staging overlays the patch and the weight stages");
+static_assert(4 * 64 * kStageRow + 4 * 2 * 2 * 64 * 4 <= kAffOff, "epilogue staging + the waves' column sums overlay the patch and the weight stages");
 
 // slot of 16-byte channel octet v (0..7) of halo pixel p: 16 consecutive pixels x one octet hit 16 distinct bank groups
 __device__ __forceinline__ int slot(int p, int v) { return p * 8 + (v ^ ((p >> 1) & 7)); }
@@ -62,7 +63,7 @@ struct HaloArgs {
   int C, H, W;
   _Float16* out;              // [batch*H*W][ldo]
   int ldo;
-  float* colstats;            // fp32 [batch*H*W/32][2][128] or nullptr
+  float* colstats;            // fp32 [batch*H*W/256][2][128] (one slot per 16 x 16 tile) or nullptr
   int tiles_x, tiles_y;
 };
 
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   // ---- epilogue.  acc[t][j][r] = output channel 16 j + 4 lo + r of pixel (tile row 4 wave + t, column lp).  Two channel halves through
   // this wave's fp32 staging area [64 pixels][64 channels (+ pad)], read back as (pixel = 8 it + lane / 8, 8 channels = lane % 8).
   unsigned char* const stg = lds + wave * (64 * kStageRow);
+  float* const wsum = reinterpret_cast<float*>(lds + 4 * 64 * kStageRow);               // [wave][half][sum | sumsq][64]: 4 KB behind the staging areas
   // residual rows: the first channel half was prefetched under the last chunk's MFMAs (into the idle patch registers), the second half
   // is requested as soon as the first half's accumulators have been staged (their registers are free then)
   half8 rres[2][8];
@@ -266,8 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) bv[e] = (float)bq[e];
     }
-    // statistics: ONE fold per channel half over this wave's 64 pixels (= two slots of 32: the sums go to the first, zeros to the second --
-    // the consumer adds a sample's slots up in any order; folding each 32-pixel slot on its own cost twice the cross-lane traffic)
+    // statistics: ONE fold per channel half over this wave's 64 pixels; the four waves' sums meet in LDS below (one slot per tile)
     float cs[8], cq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
@@ -303,18 +304,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
           cs[e] += __shfl_xor(cs[e], mask);
           cq[e] += __shfl_xor(cq[e], mask);
         }
-      if (lane < 16) {                                      // lanes 0-7: the sums into slot 2 wave, lanes 8-15: zeros into slot 2 wave + 1
-        const size_t slot_id = (((size_t)b * a.tiles_y + ty) * a.tiles_x + tx) * 8 + wave * 2 + (lane >> 3);
-        const float zf = lane < 8 ? 1.0f : 0.0f;
-        float* dst = a.colstats + slot_id * 2 * kN + hf * 64 + c8;
-        *reinterpret_cast<float4v*>(dst) = float4v{zf * cs[0], zf * cs[1], zf * cs[2], zf * cs[3]};
-        *reinterpret_cast<float4v*>(dst + 4) = float4v{zf * cs[4], zf * cs[5], zf * cs[6], zf * cs[7]};
-        *reinterpret_cast<float4v*>(dst + kN) = float4v{zf * cq[0], zf * cq[1], zf * cq[2], zf * cq[3]};
-        *reinterpret_cast<float4v*>(dst + kN + 4) = float4v{zf * cq[4], zf * cq[5], zf * cq[6], zf * cq[7]};
+      if (lane < 8) {                                       // this wave's sums of the half -> LDS (behind the four staging areas)
+        float* dst = wsum + ((wave * 2 + hf) * 2) * 64 + c8;
+        *reinterpret_cast<float4v*>(dst) = float4v{cs[0], cs[1], cs[2], cs[3]};
+        *reinterpret_cast<float4v*>(dst + 4) = float4v{cs[4], cs[5], cs[6], cs[7]};
+        *reinterpret_cast<float4v*>(dst + 64) = float4v{cq[0], cq[1], cq[2], cq[3]};
+        *reinterpret_cast<float4v*>(dst + 64 + 4) = float4v{cq[4], cq[5], cq[6], cq[7]};
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+  }
+  if (a.colstats) {
+    // one statistics slot per workgroup (= 16 x 16 pixel tile): the four waves' sums added in wave order (fixed -> reproducible)
+    __syncthreads();
+    const int hf = tid >> 7, which = (tid >> 6) & 1, c = tid & 63;               // 256 threads = [half][sum | sumsq][64 channels]
+    float r = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) r += wsum[((wv * 2 + hf) * 2 + which) * 64 + c];
+    const size_t slot_id = ((size_t)b * a.tiles_y + ty) * a.tiles_x + tx;
+    a.colstats[(slot_id * 2 + which) * kN + hf * 64 + c] = r;
   }
 }
 

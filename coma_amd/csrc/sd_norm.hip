@@ -133,11 +133,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // the same from per-32-row-block column sums [rb][2][C] of one or two producers: one 256-thread block per (b, g),
 // thread t owns channel (t % cg) of the group and every (256 / cg)-th row block; LDS fold in a fixed order
 __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* __restrict__ cs0, const float* __restrict__ cs1,
-                                                                  int c0, int c1, int hw, int groups, float eps,
+                                                                  int c0, int c1, int hw, int rbs, int groups, float eps,
                                                                   const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
                                                                   float* __restrict__ affine) {
+  // rbs = slots per sample (hw / 32 for the GEMM epilogues' 32-row slots; hw / 256 for sd_conv3x3_halo_f16's per-tile slots)
   __shared__ float rs[256], rq[256];
-  const int C = c0 + c1, cg = C / groups, rbs = hw / 32;
+  const int C = c0 + c1, cg = C / groups;
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int per = 256 / cg;                       // row-block lanes (cg <= 80 in every SD layer)
   const int tc = threadIdx.x % cg, tr = threadIdx.x / cg;
@@ -537,7 +538,7 @@ extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0,
   hipStream_t s = (hipStream_t)stream;
   const int total = batch * groups;
   if (C / groups > 256) return fail(COMA_E_INVALID, "sd_groupnorm_colstats_f16: more than 256 channels per group");
-  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(total), dim3(256), 0, s, colstats0, colstats1, c0, c1, hw, groups, eps,
+  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(total), dim3(256), 0, s, colstats0, colstats1, c0, c1, hw, hw / 32, groups, eps,
                      (const _Float16*)gamma, (const _Float16*)beta, stats);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((hw + gn_pix() - 1) / gn_pix(), batch), dim3(256), 0, s, (const _Float16*)x0,
                      (const _Float16*)x1, c0, c1, hw, stats, silu, (_Float16*)out, gn_pix());
@@ -548,23 +549,24 @@ extern "C" int sd_groupnorm_colstats_f16(const void* x0, const void* x1, int c0,
 // producer's column sums (colstats0 != NULL) or from a statistics pass over the tensor; no apply pass.  For consumers that apply the
 // affine themselves (sd_xfront_f16).
 extern "C" int sd_groupnorm_table_f16(const void* x0, int c0, int batch, int hw, int groups, float eps, const void* gamma, const void* beta,
-                                      float* stats, const float* colstats0, void* stream) {
+                                      float* stats, const float* colstats0, int rows_per_slot, void* stream) {
   if (sd::plan_recording()) {
     sd::PlanRec r{};
     r.kind = sd::PK_GN_TABLE;
     r.p[0] = (void*)x0; r.p[1] = (void*)gamma; r.p[2] = (void*)beta; r.p[3] = stats; r.p[4] = (void*)colstats0;
-    r.i[0] = c0; r.i[1] = batch; r.i[2] = hw; r.i[3] = groups; r.f[0] = eps;
+    r.i[0] = c0; r.i[1] = batch; r.i[2] = hw; r.i[3] = groups; r.i[4] = rows_per_slot; r.f[0] = eps;
     return sd::plan_record(r);
   }
   if (!x0 || !gamma || !beta || !stats) return fail(COMA_E_INVALID, "sd_groupnorm_table_f16: null pointer");
+  if (rows_per_slot == 0) rows_per_slot = 32;
   const int C = c0;
   if (batch <= 0 || hw <= 0 || groups <= 0 || groups > GN_MAX_GROUPS || C % groups || c0 % 8 || C > GN_MAX_C || C / groups > 256)
     return fail(COMA_E_INVALID, "sd_groupnorm_table_f16: bad shape C=%d groups=%d", C, groups);
   hipStream_t s = (hipStream_t)stream;
   const int total = batch * groups;
   if (colstats0) {
-    if (hw % 32) return fail(COMA_E_INVALID, "sd_groupnorm_table_f16: colstats need hw %% 32 == 0");
-    hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(total), dim3(256), 0, s, colstats0, (const float*)nullptr, c0, 0, hw, groups, eps,
+    if (rows_per_slot < 32 || hw % rows_per_slot) return fail(COMA_E_INVALID, "sd_groupnorm_table_f16: colstats need hw %% rows_per_slot == 0 (hw=%d, rows_per_slot=%d)", hw, rows_per_slot);
+    hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(total), dim3(256), 0, s, colstats0, (const float*)nullptr, c0, 0, hw, hw / rows_per_slot, groups, eps,
                        (const _Float16*)gamma, (const _Float16*)beta, stats);
   } else {
     const int nchunk = (hw + GN_PIX - 1) / GN_PIX;
@@ -594,7 +596,7 @@ extern "C" int sd_groupnorm_table_cat_f16(int c0, int c1, int batch, int hw, int
   if (batch <= 0 || hw <= 0 || hw % 32 || groups <= 0 || groups > GN_MAX_GROUPS || c0 <= 0 || c1 < 0 || C % groups || c0 % 8 || c1 % 8 || C > GN_MAX_C ||
       C / groups > 256)
     return fail(COMA_E_INVALID, "sd_groupnorm_table_cat_f16: bad shape c0=%d c1=%d groups=%d hw=%d", c0, c1, groups, hw);
-  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(batch * groups), dim3(256), 0, (hipStream_t)stream, colstats0, colstats1, c0, c1, hw, groups, eps,
+  hipLaunchKernelGGL(gn_finalize_colstats_kernel, dim3(batch * groups), dim3(256), 0, (hipStream_t)stream, colstats0, colstats1, c0, c1, hw, hw / 32, groups, eps,
                      (const _Float16*)gamma, (const _Float16*)beta, stats);
   return check_launch("gn_finalize_colstats_kernel");
 }

@@ -111,7 +111,7 @@ static int launch(const PlanRec& r, void* st) {
     case PK_XFRONT:
       return sd_xfront_f16(p[0], (const float*)p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], i[0], (int)i[1], (int)i[2], (float)f[0], st);
     case PK_GN_TABLE:
-      return sd_groupnorm_table_f16(p[0], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (float)f[0], p[1], p[2], (float*)p[3], (const float*)p[4], st);
+      return sd_groupnorm_table_f16(p[0], (int)i[0], (int)i[1], (int)i[2], (int)i[3], (float)f[0], p[1], p[2], (float*)p[3], (const float*)p[4], (int)i[4], st);
     case PK_XTAIL:
       return sd_xtail_f16(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], (float*)p[10], i[0], st);
     case PK_CONV_SMALL_N:

@@ -32,6 +32,7 @@ class LaunchGraph:
         self._gn_stats = None
         self._ws = None             # split-K workspace shared by every GEMM of the graph (launches are serial)
         self._colstats = {}         # data_ptr of a GEMM output -> its [M/32][2][N] column-sum buffer (GroupNorm statistics)
+        self._colstats_tile = {}    # data_ptr of a halo-convolution output -> its [M/256][2][N] per-tile column sums (table consumers only)
         self.fuse_gn_stats = True
 
     # ---- memory
@@ -253,28 +254,33 @@ class LaunchGraph:
         """GroupNorm (+ SiLU) -> 3x3 convolution with n <= 4 output channels in one pass over x: only the per-(sample, channel) affine
         table is computed (statistics from the producer's column sums when it left them), the normalised tensor is never written."""
         hw = h * w_
-        stats = self.gn_scratch(batch, hw)
-        cs0 = self._colstats.get(x.data_ptr()) if hw % 32 == 0 else None
-        self.add(lambda: ops.groupnorm_table(x, gamma, beta, stats, batch=batch, hw=hw, c0=c, eps=eps, colstats0=cs0),
-                 tag=f"groupnorm(table) B={batch} hw={hw} C={c}")
+        stats = self._table(x, gamma, beta, batch=batch, hw=hw, c=c, eps=eps)
         self.add(lambda: ops.conv3x3_small_n(x, w, out, batch=batch, h=h, w_=w_, c=c, n=n, bias=bias, gn_affine=stats, silu=silu,
                                              ldo=out.shape[-1]),
                  flops=2 * batch * hw * n * 9 * c, tag=f"conv3x3(small n) B={batch} {h}x{w_} C={c} n={n}", nbytes=2 * batch * hw * (c + 8))
         return out
 
+    def _table(self, x, gamma, beta, *, batch, hw, c, eps):
+        """The (scale, shift) table of a GroupNorm over x, from whatever column sums its producer left (32-row slots of a GEMM epilogue,
+        per-tile slots of a halo convolution) or from a statistics pass."""
+        table = self.gn_scratch(batch, hw)
+        cs0, rps = self._colstats_tile.get(x.data_ptr()), 256
+        if cs0 is None:
+            cs0, rps = (self._colstats.get(x.data_ptr()) if hw % 32 == 0 else None), 32
+        self.add(lambda: ops.groupnorm_table(x, gamma, beta, table, batch=batch, hw=hw, c0=c, eps=eps, colstats0=cs0, rows_per_slot=rps),
+                 tag=f"groupnorm(table) B={batch} hw={hw} C={c}")
+        return table
+
     def gn_silu_conv3x3_halo(self, x, gamma, beta, w, bias, out, *, batch, h, w_, c, n, eps, silu=True, res=None, stats=False):
         """GroupNorm (+ SiLU) -> 3x3 convolution with 128 output channels as a halo-patch convolution (sd_conv3x3_halo_f16): only the
         per-(sample, channel) affine table is computed (statistics from the producer's column sums when it left them), the normalised
-        tensor is never written; stats: leave the column sums of `out` for the next GroupNorm."""
+        tensor is never written; stats: leave the per-tile column sums of `out` for the next GroupNorm table."""
         hw = h * w_
-        table = self.gn_scratch(batch, hw)
-        cs0 = self._colstats.get(x.data_ptr()) if hw % 32 == 0 else None
-        self.add(lambda: ops.groupnorm_table(x, gamma, beta, table, batch=batch, hw=hw, c0=c, eps=eps, colstats0=cs0),
-                 tag=f"groupnorm(table) B={batch} hw={hw} C={c}")
+        table = self._table(x, gamma, beta, batch=batch, hw=hw, c=c, eps=eps)
         cs = None
-        if stats and self.fuse_gn_stats and hw % 32 == 0:
-            cs = self.buf(batch * hw // 32, 2, n, dtype=torch.float32, zero=True)
-            self._colstats[out.data_ptr()] = cs
+        if stats and self.fuse_gn_stats:
+            cs = self.buf(batch * hw // 256, 2, n, dtype=torch.float32, zero=True)
+            self._colstats_tile[out.data_ptr()] = cs
         self.add(lambda: ops.conv3x3_halo(x, w, out, batch=batch, h=h, w_=w_, c=c, n=n, bias=bias, res=res, gn_affine=table, silu=silu,
                                           colstats=cs, ldo=out.shape[-1]),
                  flops=2 * batch * hw * n * 9 * c, tag=f"conv3x3(halo) B={batch} {h}x{w_} C={c} n={n}",

@@ -141,10 +141,10 @@ def xattn_chain(a, h, wo1, bo1, g2, b2, wq, k2, vt2, wo2, bo2, g3, b3, h2, n3, *
     _lib.check(rc, "sd_xattn_chain_f16")
 
 
-def groupnorm_table(x0, gamma, beta, stats, *, batch, hw, c0, groups=32, eps=1e-5, colstats0=None):
-    """(scale, shift) per (sample, channel) -> stats[: batch * c0 * 2] (fp32), nothing applied."""
+def groupnorm_table(x0, gamma, beta, stats, *, batch, hw, c0, groups=32, eps=1e-5, colstats0=None, rows_per_slot=32):
+    """(scale, shift) per (sample, channel) -> stats[: batch * c0 * 2] (fp32), nothing applied; colstats0 fp32 [batch * hw / rows_per_slot][2][c0]."""
     rc = _lib.lib().sd_groupnorm_table_f16(_p(x0, "x0"), c0, batch, hw, groups, eps, _p(gamma), _p(beta), _p(stats, "stats", torch.float32),
-                                           _p(colstats0, "colstats0", torch.float32), _stream(x0))
+                                           _p(colstats0, "colstats0", torch.float32), rows_per_slot, _stream(x0))
     _lib.check(rc, "sd_groupnorm_table_f16")
     return stats
 

@@ -139,10 +139,11 @@ int sd_attention_wide_f16(const void* q, const void* k, const void* vt, void* ou
                           int ldq, int ldk, int ldv, int ldo, float scale, void* stream);
 
 /* Only the per-(sample, channel) affine table of a GroupNorm: fp32 [batch][c0][2] = (scale, shift) at the start of `stats` (same
- * scratch size as sd_groupnorm_f16), from the producer's column sums (colstats0 != NULL, hw % 32 == 0) or from a statistics pass over
- * x0; nothing is applied.  For consumers that apply the affine themselves (sd_xfront_f16). */
+ * scratch size as sd_groupnorm_f16), from the producer's column sums (colstats0 != NULL: fp32 [batch * hw / rows_per_slot][2][c0], rows_per_slot
+ * = 32 for sd_conv_gemm_desc.colstats -- 0 means 32 -- and 256 for sd_conv3x3_halo_f16) or from a statistics pass over x0; nothing is
+ * applied.  For consumers that apply the affine themselves (sd_xfront_f16, sd_conv3x3_halo_f16, sd_conv3x3_small_n_f16). */
 int sd_groupnorm_table_f16(const void* x0, int c0, int batch, int hw, int groups, float eps, const void* gamma, const void* beta,
-                           float* stats, const float* colstats0, void* stream);
+                           float* stats, const float* colstats0, int rows_per_slot, void* stream);
 /* The same table for a GroupNorm over the channel concatenation of two tensors, from both producers' column sums only (hw % 32 == 0). */
 int sd_groupnorm_table_cat_f16(int c0, int c1, int batch, int hw, int groups, float eps, const void* gamma, const void* beta, float* stats,
                                const float* colstats0, const float* colstats1, void* stream);
@@ -223,9 +224,9 @@ int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, con
  *   x fp16 NHWC [batch][h][w][c], c in {64, 128, 192, 256}, h and w multiples of 16;
  *   gn_affine fp32 [batch][c][2] = (scale, shift) of the GroupNorm (sd_groupnorm_table_f16), or NULL for a plain convolution;
  *   out[m, 0:128] = conv3x3(act(x * scale + shift)) + bias (+ res[m, 0:128]), act = SiLU if silu, zero padding of the ACTIVATED tensor;
- *   colstats != NULL: fp32 [batch*h*w/32][2][128], sums / sums of squares of the stored output per 32 pixels (sd_conv_gemm_desc.colstats
- *   as far as a GroupNorm consumer is concerned: every pixel of a sample is counted in exactly one of the sample's h*w/32 slots; the slots
- *   hold the sums of four rows of a 16 x 16 pixel tile alternating with zeros, not 32 consecutive rows of the matrix).  Recordable.
+ *   colstats != NULL: fp32 [batch*h*w/256][2][128], sums / sums of squares of the stored output per 16 x 16 pixel tile (one slot per
+ *   workgroup: sd_groupnorm_table_f16 with rows_per_slot = 256; 8 x fewer slots than the GEMM epilogue's 32-row slots -- at 512 x 512 the
+ *   consumer's table launch read 67 MB of them, 84-120 us).  Recordable.
  * replaces: GroupNorm -> SiLU -> Conv2d(3x3) of ResnetBlock2D inside self.vae.decode / self.vae.encode,
  * utils/adaptive_mask_inpainting.py:1086, :1112, :677-680. */
 int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine, int silu, const void* w, const void* bias, const void* res, int ldr,

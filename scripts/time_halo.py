@@ -25,7 +25,7 @@ del xf
 stats = torch.empty(1 << 20, dtype=torch.float32, device=dev)
 norm = torch.empty(M, C, dtype=torch.float16, device=dev)
 out_a, out_b = torch.empty(M, n, dtype=torch.float16, device=dev), torch.empty(M, n, dtype=torch.float16, device=dev)
-cs_a, cs_b = torch.zeros(M // 32, 2, n, dtype=torch.float32, device=dev), torch.zeros(M // 32, 2, n, dtype=torch.float32, device=dev)
+cs_a, cs_b = torch.zeros(M // 32, 2, n, dtype=torch.float32, device=dev), torch.zeros(M // 256, 2, n, dtype=torch.float32, device=dev)
 ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)
 
 
