@@ -63,8 +63,9 @@ struct HaloArgs {
   int C, H, W;
   _Float16* out;              // [batch*H*W][ldo]
   int ldo;
-  float* colstats;            // fp32 [batch*H*W/256][2][128] (one slot per 16 x 16 tile) or nullptr
+  float* colstats;            // fp32 [batch*H*W/256][2][ntot] (one slot per 16 x 16 tile) or nullptr
   int tiles_x, tiles_y;
+  int ntot;                   // output channels of the layer (128 or 256): block id % (ntot / 128) selects this workgroup's 128
 };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
@@ -76,6 +77,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lp = lane & 15, lo = lane >> 4;
   int bid = blockIdx.x;
+  // n > 128: the tile is computed by n / 128 workgroups, consecutive in dispatch order (the later ones find the patch in the Infinity
+  // Cache), each with its own 128 output channels -- the patch is staged (and activated) once per workgroup
+  const int nsplit = a.ntot / kN;
+  const int n_off = __builtin_amdgcn_readfirstlane((bid % nsplit) * kN);
+  bid /= nsplit;
+  a.w += (size_t)n_off * 9 * a.C;
+  a.out += n_off;
+  if (a.bias) a.bias += n_off;
+  if (a.res) a.res += n_off;
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) r += wsum[((wv * 2 + hf) * 2 + which) * 64 + c];
     const size_t slot_id = ((size_t)b * a.tiles_y + ty) * a.tiles_x + tx;
-    a.colstats[(slot_id * 2 + which) * kN + hf * 64 + c] = r;
+    a.colstats[(slot_id * 2 + which) * a.ntot + n_off + hf * 64 + c] = r;
   }
 }
 
@@ -341,7 +351,7 @@ extern "C" int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine,
     return sd::plan_record(r);
   }
   if (!x || !w || !out) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: null pointer");
-  if (n != kN) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: n = %d (built for 128 output channels)", n);
+  if (n != kN && n != 2 * kN) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: n = %d (built for 128 and 256 output channels)", n);
   if (c <= 0 || c % kChunk || c > kMaxC) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: c = %d (a multiple of 64, at most %d)", c, kMaxC);
   if (batch <= 0 || h <= 0 || w_ <= 0 || h % kTile || w_ % kTile)
     return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: batch=%d h=%d w=%d (h, w multiples of 16)", batch, h, w_);
@@ -354,7 +364,7 @@ extern "C" int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine,
   HaloArgs a;
   a.x = (const _Float16*)x; a.affine = gn_affine; a.silu = silu; a.w = (const _Float16*)w; a.bias = (const _Float16*)bias;
   a.res = (const _Float16*)res; a.ldr = ldr; a.C = c; a.H = h; a.W = w_; a.out = (_Float16*)out; a.ldo = ldo; a.colstats = colstats;
-  a.tiles_x = w_ / kTile; a.tiles_y = h / kTile;
-  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+  a.tiles_x = w_ / kTile; a.tiles_y = h / kTile; a.ntot = n;
+  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)(tiles * (n / kN))), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("conv3x3_halo_kernel");
 }

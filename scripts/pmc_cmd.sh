@@ -19,4 +19,4 @@ cd $REPO
 python scripts/summarize_pmc.py $OUT > $OUT/summary.txt
 for f in $OUT/g*.log; do grep -iE "error|invalid|not found|unsupported" $f | head -3; done
 rm -rf $OUT/g[0-9]
-cat $OUT/summary.txt | grep -v "^==" | grep -E "attention|conv_gemm" | head -80
+cat $OUT/summary.txt | grep -v "^==" | grep -E "${PMC_FILTER:-attention|conv_gemm}" | head -80

@@ -10,6 +10,10 @@ if "--unfused" in sys.argv:
     vae_mod._VaeBase.fused_attention = False          # A/B: QK^T GEMM -> softmax -> PV GEMM through memory
 if "--gemm-conv-out" in sys.argv:
     vae_mod._VaeBase.fused_conv_out = False           # A/B: GroupNorm kernel + 64-column implicit-GEMM tile for the decoder's conv_out
+if "--halo128" in sys.argv:
+    vae_mod._VaeBase.halo_widths = (128,)             # A/B: halo convolutions only for 128 output channels
+if "--no-halo" in sys.argv:
+    vae_mod._VaeBase.halo_conv = False
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = "cuda:0"
 vae = HipAutoencoderKL(weights.random_state(weights.vae_shapes(), seed=1), batch=B, device=dev)

@@ -618,15 +618,16 @@ def test_conv3x3_small_n_with_folded_groupnorm(ops, B, H, W, n, norm, silu, C):
         ops.conv3x3_small_n(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=5)
 
 
-@pytest.mark.parametrize("B,H,W,C,norm,silu,res,stats", [(2, 32, 48, 128, True, True, False, True), (1, 16, 16, 256, True, True, True, True),
-                                                         (3, 48, 32, 128, False, False, True, False), (1, 64, 64, 64, True, False, False, True),
-                                                         (2, 16, 32, 192, True, True, True, False)])
-def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, stats):
+@pytest.mark.parametrize("B,H,W,C,norm,silu,res,stats,n", [(2, 32, 48, 128, True, True, False, True, 128), (1, 16, 16, 256, True, True, True, True, 128),
+                                                           (3, 48, 32, 128, False, False, True, False, 128), (1, 64, 64, 64, True, False, False, True, 128),
+                                                           (2, 16, 32, 192, True, True, True, False, 128), (2, 32, 32, 256, True, True, True, True, 256),
+                                                           (1, 48, 16, 128, True, True, False, True, 256)])
+def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, stats, n):
     """sd_conv3x3_halo_f16 (GroupNorm affine + SiLU + 3x3 convolution with 128 output channels as a halo-patch convolution: the VAE's
     128-channel layers) against affine -> SiLU -> fp16 rounding -> conv2d (+ bias, + residual) in fp32: one to four 64-channel chunks,
-    tiles at every image border, several tiles per sample; and the column sums it leaves for the next GroupNorm against sums over the
-    stored tensor -- per slot (two rows of a 16 x 16 tile) and per sample."""
-    n, hw = 128, H * W
+    tiles at every image border, several tiles per sample, 128 and 256 output channels (two workgroups per tile); and the column sums it
+    leaves for the next GroupNorm against sums over the stored tensor -- per slot (one per 16 x 16 tile) and per sample."""
+    hw = H * W
     x = rnd(B * hw, C, seed=1) * 1.5 + 0.3
     w = rnd(n, 9, C, seed=2, scale=(9 * C) ** -0.5)
     b = rnd(n, seed=3)
@@ -643,7 +644,7 @@ def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, st
     ref = so.conv_ref(xa, w, batch=B, h=H, w_=W, taps=9, bias=b, res=r)
     out = torch.full((B * hw, n), 7.0, dtype=F16, device=DEV)
     cs = torch.zeros(B * hw // 256, 2, n, dtype=torch.float32, device=DEV) if stats else None
-    ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, bias=b.to(DEV), res=r.to(DEV) if res else None,
+    ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=n, bias=b.to(DEV), res=r.to(DEV) if res else None,
                      gn_affine=table.to(DEV) if norm else None, silu=silu and norm, colstats=cs)
     close(out, ref)
     if stats:
@@ -660,7 +661,7 @@ def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, st
         assert torch.allclose(t1[:B * n * 2], t2[:B * n * 2], rtol=2e-4, atol=2e-4)
     with pytest.raises(Exception, match="multiples of 16"):
         ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H - 1, w_=W, c=C)
-    with pytest.raises(Exception, match="128 output channels"):
+    with pytest.raises(Exception, match="128 and 256 output channels"):
         ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=64)
 
 
