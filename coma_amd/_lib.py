@@ -13,7 +13,9 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoma_hip.so")
+# COMA_HIP_LIB=<path>: tuning aid -- load another BUILD of the library (A/B of two builds inside one GPU call: box-to-box spread is larger
+# than most of the effects being measured); the product and the tests use the in-tree library
+LIB_PATH = os.environ.get("COMA_HIP_LIB") or os.path.join(_HERE, "libcoma_hip.so")
 
 _lib = None
 

@@ -46,8 +46,10 @@ constexpr int kLds = kAffOff + kMaxC * 8;                // 76 288 bytes: two wo
 constexpr int kStageRow = 64 * 4 + 16;                   // epilogue staging: 64 fp32 channels + 16 bytes of padding per pixel
 static_assert(4 * 64 * kStageRow + 4 * 2 * 2 * 64 * 4 <= kAffOff, "epilogue staging + the waves' column sums overlay the patch and the weight stages");
 
-// slot of 16-byte channel octet v (0..7) of halo pixel p: 16 consecutive pixels x one octet hit 16 distinct bank groups
-__device__ __forceinline__ int slot(int p, int v) { return p * 8 + (v ^ ((p >> 1) & 7)); }
+// slot of 16-byte channel octet v (0..7) of halo pixel (row r, column c): 16 consecutive pixels of a row x one octet hit 16 distinct bank
+// groups (18 is even, so pixel parity = column parity; (c >> 1) & 7 takes 8 values over 16 consecutive columns, each at both parities).
+// The swizzle depends on the COLUMN only, so a tap's row shift is a constant byte offset of the fragment address.
+__device__ __forceinline__ int pslot(int r, int c, int v) { return (r * kHalo + c) * 8 + (v ^ ((c >> 1) & 7)); }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -68,6 +70,18 @@ struct HaloArgs {
   int ntot;                   // output channels of the layer (128 or 256): block id % (ntot / 128) selects this workgroup's 128
 };
 
+#ifdef HALO_DBG
+// tuning build (-DHALO_DBG, loaded through COMA_HIP_LIB): per workgroup, wave 0 records shader-clock stamps -- entry, first commit done,
+// end of the K loop, end of the epilogue -- and the cycles it spent in the per-slice wait + barrier and in the commits; sd_halo_debug()
+constexpr int kDbgBlocks = 8192;
+__device__ unsigned long long g_halo_dbg[kDbgBlocks * 8];
+#define HALO_STAMP(k) do { if (dbg_on) g_halo_dbg[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define HALO_ACC(k, t0) do { if (dbg_on) g_halo_dbg[blockIdx.x * 8 + (k)] += __builtin_readcyclecounter() - (t0); } while (0)
+#else
+#define HALO_STAMP(k) do {} while (0)
+#define HALO_ACC(k, t0) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[kLds];
   half8* const tile = reinterpret_cast<half8*>(lds);
@@ -75,78 +89,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
   float2* const aff = reinterpret_cast<float2*>(lds + kAffOff);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef HALO_DBG
+  const bool dbg_on = tid == 0 && blockIdx.x < kDbgBlocks;
+  if (dbg_on) { g_halo_dbg[blockIdx.x * 8 + 4] = 0; g_halo_dbg[blockIdx.x * 8 + 5] = 0; }
+  unsigned long long tdbg = 0;
+#endif
+  HALO_STAMP(0);
   const int lp = lane & 15, lo = lane >> 4;
-  int bid = blockIdx.x;
-  // n > 128: the tile is computed by n / 128 workgroups, consecutive in dispatch order (the later ones find the patch in the Infinity
-  // Cache), each with its own 128 output channels -- the patch is staged (and activated) once per workgroup
+  const int C = a.C, nchunk = C / kChunk, nkt = 9 * nchunk;
   const int nsplit = a.ntot / kN;
-  const int n_off = __builtin_amdgcn_readfirstlane((bid % nsplit) * kN);
-  bid /= nsplit;
-  a.w += (size_t)n_off * 9 * a.C;
-  a.out += n_off;
-  if (a.bias) a.bias += n_off;
-  if (a.res) a.res += n_off;
-  const int tx = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int b = bid / a.tiles_y;
-  const int ty0 = ty * kTile, tx0 = tx * kTile;
-  const int C = a.C, nchunk = C / kChunk;
-  const _Float16* const xb = a.x + (size_t)b * a.H * a.W * C;
 
-  // ---- weight slices by LDS-DMA: instruction j of this wave covers rows (wave * 4 + j) * 8 .. + 7 of the slice; lane -> row + lane / 8,
-  // LDS slot lane % 8, which must receive K octet slot ^ ((row >> 1) & 7)
   auto make_rsrc = [](const void* p) {
     const unsigned long long q = reinterpret_cast<unsigned long long>(p);
     const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)q), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(q >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi32 << 32) | lo32), 0, 0x7fffffff, 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(a.w);
-  unsigned w_off[4];
+  // ---- weight slices by LDS-DMA: instruction j of this wave covers rows (wave * 4 + j) * 8 .. + 7 of the slice; lane -> row + lane / 8,
+  // LDS slot lane % 8, which must receive K octet slot ^ ((row >> 1) & 7)
+  // (row r + 8 j: the swizzle term (r >> 1) & 7 only flips bit 2 for odd j -> two lane registers serve the four instructions)
+  unsigned w_off2[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < 2; ++j) {
     const int r = (wave * 4 + j) * 8 + (lane >> 3);
-    w_off[j] = (unsigned)(r * 9 * C) * 2u + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    w_off2[j] = (unsigned)(r * 9 * C) * 2u + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
   }
-  auto issue_w = [&](int kt) {                            // slice kt = chunk * 9 + tap into stage kt & 1
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int chunk = kt / 9, tap = kt - chunk * 9;
-    const int soff = __builtin_amdgcn_readfirstlane((tap * C + chunk * kChunk) * 2);
-    unsigned char* dst = wst + (kt & 1) * kWStage + wave * 4096;
+  const int w_jstep = __builtin_amdgcn_readfirstlane(16 * 9 * C * 2);       // two instructions further = 16 rows further
+  // W fragment: row = 16 j + (lane & 15), K octet = 4 kh + (lane >> 4); the swizzle term looks at row bits 1-3 only, so tile j is a
+  // constant byte offset
+  int w_fo[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(dst + j * 1024), 16, w_off[j], soff, 0, 0);
-#endif
-  };
+  for (int kh = 0; kh < 2; ++kh) w_fo[kh] = lp * 128 + (((kh * 4 + lo) ^ ((lp >> 1) & 7)) * 16);
+  // pixel fragment of tap (dy, dx), tile row t, K half kh: patch pixel (4 wave + t + dy, lp + dx), octet 4 kh + lo.  The swizzle looks at
+  // the patch COLUMN only (pslot), so per (dx, kh) the lane part of the address is one register and rows are constant offsets.
+  int pf_lane[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) pf_lane[dx][kh] = (pslot(0, lp + dx, kh * 4 + lo) + wave * 4 * kHalo * 8) * 16;
+  // epilogue read-back role (also the role in which the residual is prefetched): pixel 8 it + ps of this wave's 64, channel octet c8
+  const int ps = lane >> 3, c8 = (lane & 7) * 8;
+  unsigned char* const stg = lds + wave * (64 * kStageRow);
+  float* const wsum = reinterpret_cast<float*>(lds + 4 * 64 * kStageRow);               // [wave][half][sum | sumsq][64]: 4 KB behind the staging areas
 
   // ---- halo patch: fetch = all of a chunk's global loads of this thread (11 independent 16-byte buffer loads, every wave issues all 11 so
   // that the counted vmcnt below means the same in every wave; one 32-bit offset per load, pad pixels carry an out-of-range offset and
-  // come back as zeros), commit = normalise + activate + LDS write.  Slots and validity are recomputed at every commit from an opaque
-  // copy of the thread id: hoisted out of the chunk loop they would cost 30 registers next to the 128 accumulators (and spill).
+  // come back as zeros), commit = normalise + activate + LDS write.
   constexpr int kVec = kHalo * kHalo * 8, kPer = (kVec + 255) / 256;      // 2592 vectors, 11 per thread
-  const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(xb);
-  unsigned xoff[kPer];
-#pragma unroll
-  for (int it = 0; it < kPer; ++it) {
-    const int idx = tid + it * 256;
-    const int p = idx >> 3, v = idx & 7;
-    const int r = p / kHalo, c = p - r * kHalo;
-    const int y = ty0 + r - 1, xx = tx0 + c - 1;
-    const bool ok = idx < kVec && y >= 0 && y < a.H && xx >= 0 && xx < a.W;
-    xoff[it] = ok ? (unsigned)((y * a.W + xx) * C + v * 8) * 2u : 0x80000000u;
-  }
+  // Offsets, slots and validity are recomputed at every fetch / commit from an opaque copy of the thread id: kept live across the K loop
+  // they would cost 20-30 registers next to the 128 accumulators + the 44 patch registers (and spill).
   half8 q[kPer];
-  auto fetch = [&](int chunk) {
+  auto fetch = [&](__amdgpu_buffer_rsrc_t x_rsrc, int ty0, int tx0, int chunk) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
     const int soff = __builtin_amdgcn_readfirstlane(chunk * kChunk * 2);
 #pragma unroll
-    for (int it = 0; it < kPer; ++it) q[it] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xoff[it], soff, 0));
+    for (int it = 0; it < kPer; ++it) {
+      const int idx = t_ + it * 256;
+      const int p = idx >> 3, v = idx & 7;
+      const int r = p / kHalo, c = p - r * kHalo;
+      const int y = ty0 + r - 1, xx = tx0 + c - 1;
+      const bool ok = idx < kVec && y >= 0 && y < a.H && xx >= 0 && xx < a.W;
+      const unsigned xo = ok ? (unsigned)((y * a.W + xx) * C + v * 8) * 2u : 0x80000000u;
+      q[it] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, xo, soff, 0));
+    }
 #endif
   };
-  auto commit = [&](int chunk) {
+  auto commit = [&](int ty0, int tx0, int chunk) {
     int t_ = tid;
     asm volatile("" : "+v"(t_));                           // opaque: nothing below is loop-invariant as far as the compiler can tell
     // idx = tid + 256 it: the channel octet v = tid & 7 is the same for all of a thread's vectors -> its 8 (scale, shift) pairs are read
-    // from LDS ONCE per chunk (read per element they were 88 LDS reads per thread and chunk: 80 us of a 745 us layer)
+    // from LDS ONCE per chunk
     float2 sc8[8];
     if (a.affine) {
 #pragma unroll
@@ -157,8 +170,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
       const int idx = t_ + it * 256;
       if (idx < kVec) {
         const int p = idx >> 3, v = idx & 7;
+        const int r = p / kHalo, c = p - r * kHalo;
+        const int y = ty0 + r - 1, xx = tx0 + c - 1;
         half8 z = q[it];
-        if (a.affine && (int)xoff[it] >= 0) {              // zero padding applies to the ACTIVATED tensor: pad pixels stay 0
+        if (a.affine && y >= 0 && y < a.H && xx >= 0 && xx < a.W) {     // zero padding applies to the ACTIVATED tensor: pad pixels stay 0
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float f = fmaf((float)z[e], sc8[e].x, sc8[e].y);
@@ -166,174 +181,212 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
             z[e] = (_Float16)f;
           }
         }
-        tile[slot(p, v)] = z;
+        tile[pslot(r, c, v)] = z;
       }
     }
   };
 
-  float4v acc[4][8];
+  // ---- one workgroup per (tile, 128-channel slice).  n > 128: the slices of a tile are consecutive in dispatch order (the later ones find
+  // the patch in the Infinity Cache); the patch is staged (and activated) once per workgroup.
+  // (A PERSISTENT form -- two workgroups per CU walking the tile list, the next tile's first patch requested in the middle of the epilogue
+  // -- was written and measured to be worth having: the phase stamps show a CU slot empty for ~ 30 % of the kernel between workgroups and
+  // 4 us of first-patch latency per tile.  It does not fit: the loop-carried state costs ~ 35 registers more than the 256 a wave has at
+  // two workgroups per CU, and the library refuses kernels that touch scratch; profiles/r05_notes.md.)
+  int id = blockIdx.x;
+  const int n_off = __builtin_amdgcn_readfirstlane((id % nsplit) * kN);
+  id /= nsplit;
+  const int tx = __builtin_amdgcn_readfirstlane(id % a.tiles_x);
+  id /= a.tiles_x;
+  const int ty = __builtin_amdgcn_readfirstlane(id % a.tiles_y);
+  const int b = __builtin_amdgcn_readfirstlane(id / a.tiles_y);
+  const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(a.x + (size_t)b * a.H * a.W * C);
+  fetch(x_rsrc, ty * kTile, tx * kTile, 0);
+  {
+    const int ty0 = ty * kTile, tx0 = tx * kTile;
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(a.w + (size_t)n_off * 9 * C);
+    auto issue_w = [&](int kt) {                          // slice kt = chunk * 9 + tap into stage kt & 1
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int chunk = kt / 9, tap = kt - chunk * 9;
+      const int soff = __builtin_amdgcn_readfirstlane((tap * C + chunk * kChunk) * 2);
+      unsigned char* dst = wst + (kt & 1) * kWStage + wave * 4096;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[t][j] = float4v{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(dst + j * 1024), 16, w_off2[j & 1], soff + (j >> 1) * w_jstep, 0, 0);
+#endif
+    };
+    const size_t m_base = ((size_t)b * a.H + ty0 + 4 * wave) * a.W + tx0;               // pixel (t, col) of this wave = m_base + t * W + col
+    const _Float16* const resp = a.res ? a.res + n_off : nullptr;
 
-  issue_w(0);
-  fetch(0);
-  if (a.affine)
-    for (int i = tid; i < C; i += 256) aff[i] = reinterpret_cast<const float2*>(a.affine)[(size_t)b * C + i];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                            // `aff` is visible
-
-  // W fragment: row = 16 j + (lane & 15), K octet = 4 kh + (lane >> 4); the swizzle term looks at row bits 1-3 only, so tile j is a
-  // constant byte offset
-  const int wrow = lp;
-  int w_fo[2];
-#pragma unroll
-  for (int kh = 0; kh < 2; ++kh) w_fo[kh] = wrow * 128 + (((kh * 4 + lo) ^ ((wrow >> 1) & 7)) * 16);
-
-  const int nkt = 9 * nchunk;
-  // epilogue read-back role (also the role in which the residual is prefetched): pixel 8 it + ps of this wave's 64, channel octet c8
-  const int ps = lane >> 3, c8 = (lane & 7) * 8;
-  const size_t m_base = ((size_t)b * a.H + ty0 + 4 * wave) * a.W + tx0;                 // pixel (t, col) of this wave = m_base + t * W + col
-#pragma unroll 1
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    if (chunk > 0) __builtin_amdgcn_s_barrier();           // every wave is done reading the previous chunk's patch
-    commit(chunk);
+    issue_w(0);
+    if (a.affine)
+      for (int i = tid; i < C; i += 256) aff[i] = reinterpret_cast<const float2*>(a.affine)[(size_t)b * C + i];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kt = chunk * 9 + tap;
-      // slice kt has landed (this wave's share); the next chunk's patch loads, issued during tap 0 BEHIND slice kt + 1, may stay in flight
-      // (in the LAST chunk the idle patch registers take the residual rows of the epilogue's first channel half instead: 8 loads)
-      if (tap == 1 && chunk + 1 < nchunk) wait_vmcnt<kPer>();
-      else if (tap == 1 && a.res) wait_vmcnt<8>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();                        // ... everyone's share; and everyone is done with stage (kt + 1) & 1 and has committed
-      if (kt + 1 < nkt) issue_w(kt + 1);
-      asm volatile("" ::: "memory");                       // the loads below must be issued BEHIND the slice: the counted vmcnt relies on it
-      if (tap == 0 && chunk + 1 < nchunk) fetch(chunk + 1);
-      if (tap == 0 && chunk + 1 == nchunk && a.res) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int pw = it * 8 + ps;
-          q[it] = *reinterpret_cast<const half8*>(a.res + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldr + c8);
-        }
-      }
-      const unsigned char* ws = wst + (kt & 1) * kWStage;
-      const int dy = tap / 3, dx = tap - dy * 3;
-#pragma unroll
-      for (int kh = 0; kh < 2; ++kh) {
-        half8 pf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pf[t] = tile[slot((4 * wave + t + dy) * kHalo + lp + dx, kh * 4 + lo)];
-        // the W fragments come in two halves of four column tiles: 16 fewer registers live next to the 128 accumulators + the prefetched patch
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-          half8 wf[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const half8*>(ws + w_fo[kh] + (jh * 4 + j) * 2048);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], pf[t], acc[t][jh * 4 + j], 0, 0, 0);
-        }
-      }
-    }
-  }
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();                            // every wave is done with the patch and the weight stages
+    __builtin_amdgcn_s_barrier();                          // `aff` is visible
 
-  // ---- epilogue.  acc[t][j][r] = output channel 16 j + 4 lo + r of pixel (tile row 4 wave + t, column lp).  Two channel halves through
-  // this wave's fp32 staging area [64 pixels][64 channels (+ pad)], read back as (pixel = 8 it + lane / 8, 8 channels = lane % 8).
-  unsigned char* const stg = lds + wave * (64 * kStageRow);
-  float* const wsum = reinterpret_cast<float*>(lds + 4 * 64 * kStageRow);               // [wave][half][sum | sumsq][64]: 4 KB behind the staging areas
-  // residual rows: the first channel half was prefetched under the last chunk's MFMAs (into the idle patch registers), the second half
-  // is requested as soon as the first half's accumulators have been staged (their registers are free then)
-  half8 rres[2][8];
-  if (a.res) {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) rres[0][it] = q[it];
-  }
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
+    float4v acc[4][8];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<float4v*>(stg + (t * 16 + lp) * kStageRow + (j * 16 + lo * 4) * 4) = acc[t][hf * 4 + j];
-    if (hf == 0 && a.res) {
+      for (int j = 0; j < 8; ++j) acc[t][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      if (chunk > 0) __builtin_amdgcn_s_barrier();         // every wave is done reading the previous chunk's patch
+#ifdef HALO_DBG
+      tdbg = __builtin_readcyclecounter();
+#endif
+      commit(ty0, tx0, chunk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      HALO_ACC(5, tdbg);
+      if (chunk == 0) HALO_STAMP(1);
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kt = chunk * 9 + tap;
+        // slice kt has landed (this wave's share); the next chunk's patch loads, issued during tap 0 BEHIND slice kt + 1, may stay in flight
+        // (in the LAST chunk the idle patch registers take the residual rows of the epilogue's first channel half instead: 8 loads)
+#ifdef HALO_DBG
+        tdbg = __builtin_readcyclecounter();
+#endif
+        if (tap == 1 && chunk + 1 < nchunk) wait_vmcnt<kPer>();
+        else if (tap == 1 && resp) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                      // ... everyone's share; and everyone is done with stage (kt + 1) & 1 and has committed
+        HALO_ACC(4, tdbg);
+        if (kt + 1 < nkt) issue_w(kt + 1);
+        asm volatile("" ::: "memory");                     // the loads below must be issued BEHIND the slice: the counted vmcnt relies on it
+        if (tap == 0 && chunk + 1 < nchunk) fetch(x_rsrc, ty0, tx0, chunk + 1);
+        if (tap == 0 && chunk + 1 == nchunk && resp) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int pw = it * 8 + ps;
+            q[it] = *reinterpret_cast<const half8*>(resp + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldr + c8);
+          }
+        }
+        const unsigned char* ws = wst + (kt & 1) * kWStage;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int prow = __builtin_amdgcn_readfirstlane(dy * kHalo * 128);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          const unsigned char* pb = lds + (dx == 0 ? pf_lane[0][kh] : (dx == 1 ? pf_lane[1][kh] : pf_lane[2][kh])) + prow;
+          half8 pf[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) pf[t] = *reinterpret_cast<const half8*>(pb + t * (kHalo * 128));
+          // the W fragments come in two halves of four column tiles: 16 fewer registers live next to the 128 accumulators + the prefetched patch
+#pragma unroll
+          for (int jh = 0; jh < 2; ++jh) {
+            half8 wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const half8*>(ws + w_fo[kh] + (jh * 4 + j) * 2048);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[t][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], pf[t], acc[t][jh * 4 + j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                          // every wave is done with the patch and the weight stages
+    HALO_STAMP(2);
+
+    // ---- epilogue.  acc[t][j][r] = output channel 16 j + 4 lo + r of pixel (tile row 4 wave + t, column lp).  Two channel halves through
+    // this wave's fp32 staging area [64 pixels][64 channels (+ pad)], read back as (pixel = 8 it + lane / 8, 8 channels = lane % 8).
+    // residual rows: the first channel half was prefetched under the last chunk's MFMAs (into the idle patch registers), the second half
+    // is requested as soon as the first half's accumulators have been staged (their registers are free then)
+    // (opaque copies of the lane roles: hoisted out of the persistent loop, the epilogue's ~40 lane-dependent addresses would stay live
+    // across the K loop next to the accumulators -- and spill)
+    int lp_e = lp, lo_e = lo, ps_e = ps, c8_e = c8;
+    asm volatile("" : "+v"(lp_e), "+v"(lo_e), "+v"(ps_e), "+v"(c8_e));
+    _Float16* const outp = a.out + n_off;
+    const _Float16* const biasp = a.bias ? a.bias + n_off : nullptr;
+    const size_t slot_id = ((size_t)b * a.tiles_y + ty) * a.tiles_x + tx;
+    half8 rres[2][8];
+    if (resp) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) rres[0][it] = q[it];
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4v*>(stg + (t * 16 + lp_e) * kStageRow + (j * 16 + lo_e * 4) * 4) = acc[t][hf * 4 + j];
+      asm volatile("" ::: "memory");                       // the loads below must not be scheduled above the staging writes (accumulators still live there)
+      if (hf == 0 && resp) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int pw = it * 8 + ps_e;
+          rres[1][it] = *reinterpret_cast<const half8*>(resp + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldr + 64 + c8_e);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bv[e] = 0.0f;
+      if (biasp) {
+        const half8 bq = *reinterpret_cast<const half8*>(biasp + hf * 64 + c8_e);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (float)bq[e];
+      }
+      // statistics: ONE fold per channel half over this wave's 64 pixels; the four waves' sums meet in LDS below (one slot per tile)
+      float cs[8], cq[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int pw = it * 8 + ps;
-        rres[1][it] = *reinterpret_cast<const half8*>(a.res + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldr + 64 + c8);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = 0.0f;
-    if (a.bias) {
-      const half8 bq = *reinterpret_cast<const half8*>(a.bias + hf * 64 + c8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bv[e] = (float)bq[e];
-    }
-    // statistics: ONE fold per channel half over this wave's 64 pixels; the four waves' sums meet in LDS below (one slot per tile)
-    float cs[8], cq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.0f;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int pw = it * 8 + ps;
-      const float4v v0 = *reinterpret_cast<const float4v*>(stg + pw * kStageRow + c8 * 4);
-      const float4v v1 = *reinterpret_cast<const float4v*>(stg + pw * kStageRow + c8 * 4 + 16);
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      half8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = v[e] + bv[e];
-        if (a.res) f += (float)rres[hf][it][e];
-        o[e] = (_Float16)f;
-        const float g = (float)o[e];                       // statistics of the stored (fp16-rounded) tensor
-        cs[e] += g;
-        cq[e] += g * g;
-      }
-      *reinterpret_cast<half8*>(a.out + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldo + hf * 64 + c8) = o;
-    }
-    if (a.colstats) {
-      // fold the 8 pixel lanes that share a channel octet (lane bits 3-5), fixed order -> reproducible
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {                         // lane ^ 8 inside a row of 16 lanes: a DPP row rotation by 8 (VALU speed)
-        cs[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs[e]), 0x128, 0xf, 0xf, false));
-        cq[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cq[e]), 0x128, 0xf, 0xf, false));
-      }
-#pragma unroll
-      for (int mask = 16; mask < 64; mask <<= 1)
+        const int pw = it * 8 + ps_e;
+        const float4v v0 = *reinterpret_cast<const float4v*>(stg + pw * kStageRow + c8_e * 4);
+        const float4v v1 = *reinterpret_cast<const float4v*>(stg + pw * kStageRow + c8_e * 4 + 16);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          cs[e] += __shfl_xor(cs[e], mask);
-          cq[e] += __shfl_xor(cq[e], mask);
+          float f = v[e] + bv[e];
+          if (resp) f += (float)rres[hf][it][e];
+          o[e] = (_Float16)f;
+          const float g = (float)o[e];                     // statistics of the stored (fp16-rounded) tensor
+          cs[e] += g;
+          cq[e] += g * g;
         }
-      if (lane < 8) {                                       // this wave's sums of the half -> LDS (behind the four staging areas)
-        float* dst = wsum + ((wave * 2 + hf) * 2) * 64 + c8;
-        *reinterpret_cast<float4v*>(dst) = float4v{cs[0], cs[1], cs[2], cs[3]};
-        *reinterpret_cast<float4v*>(dst + 4) = float4v{cs[4], cs[5], cs[6], cs[7]};
-        *reinterpret_cast<float4v*>(dst + 64) = float4v{cq[0], cq[1], cq[2], cq[3]};
-        *reinterpret_cast<float4v*>(dst + 64 + 4) = float4v{cq[4], cq[5], cq[6], cq[7]};
+        *reinterpret_cast<half8*>(outp + (m_base + (size_t)(pw >> 4) * a.W + (pw & 15)) * a.ldo + hf * 64 + c8_e) = o;
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (a.colstats) {
-    // one statistics slot per workgroup (= 16 x 16 pixel tile): the four waves' sums added in wave order (fixed -> reproducible)
-    __syncthreads();
-    const int hf = tid >> 7, which = (tid >> 6) & 1, c = tid & 63;               // 256 threads = [half][sum | sumsq][64 channels]
-    float r = 0.0f;
+      if (a.colstats) {
+        // fold the 8 pixel lanes that share a channel octet (lane bits 3-5), fixed order -> reproducible
 #pragma unroll
-    for (int wv = 0; wv < 4; ++wv) r += wsum[((wv * 2 + hf) * 2 + which) * 64 + c];
-    const size_t slot_id = ((size_t)b * a.tiles_y + ty) * a.tiles_x + tx;
-    a.colstats[(slot_id * 2 + which) * a.ntot + n_off + hf * 64 + c] = r;
+        for (int e = 0; e < 8; ++e) {                       // lane ^ 8 inside a row of 16 lanes: a DPP row rotation by 8 (VALU speed)
+          cs[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cs[e]), 0x128, 0xf, 0xf, false));
+          cq[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, cq[e]), 0x128, 0xf, 0xf, false));
+        }
+#pragma unroll
+        for (int mask = 16; mask < 64; mask <<= 1)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            cs[e] += __shfl_xor(cs[e], mask);
+            cq[e] += __shfl_xor(cq[e], mask);
+          }
+        if (lane < 8) {                                     // this wave's sums of the half -> LDS (behind the four staging areas)
+          float* dst = wsum + ((wave * 2 + hf) * 2) * 64 + c8_e;
+          *reinterpret_cast<float4v*>(dst) = float4v{cs[0], cs[1], cs[2], cs[3]};
+          *reinterpret_cast<float4v*>(dst + 4) = float4v{cs[4], cs[5], cs[6], cs[7]};
+          *reinterpret_cast<float4v*>(dst + 64) = float4v{cq[0], cq[1], cq[2], cq[3]};
+          *reinterpret_cast<float4v*>(dst + 64 + 4) = float4v{cq[4], cq[5], cq[6], cq[7]};
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    HALO_STAMP(3);
+    if (a.colstats) {
+      __syncthreads();
+      // one statistics slot per workgroup (= 16 x 16 pixel tile): the four waves' sums added in wave order (fixed -> reproducible)
+      const int hf = tid >> 7, which = (tid >> 6) & 1, c = tid & 63;             // 256 threads = [half][sum | sumsq][64 channels]
+      float r = 0.0f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) r += wsum[((wv * 2 + hf) * 2 + which) * 64 + c];
+      a.colstats[(slot_id * 2 + which) * a.ntot + n_off + hf * 64 + c] = r;
+    }
   }
 }
 
@@ -365,6 +418,14 @@ extern "C" int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine,
   a.x = (const _Float16*)x; a.affine = gn_affine; a.silu = silu; a.w = (const _Float16*)w; a.bias = (const _Float16*)bias;
   a.res = (const _Float16*)res; a.ldr = ldr; a.C = c; a.H = h; a.W = w_; a.out = (_Float16*)out; a.ldo = ldo; a.colstats = colstats;
   a.tiles_x = w_ / kTile; a.tiles_y = h / kTile; a.ntot = n;
+  if (tiles * (n / kN) > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: grid too large");
   hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)(tiles * (n / kN))), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("conv3x3_halo_kernel");
 }
+
+#ifdef HALO_DBG
+extern "C" int sd_halo_debug(unsigned long long* host_dst, int n_blocks) {
+  if (!host_dst || n_blocks <= 0 || n_blocks > sd::hc::kDbgBlocks) return -1;
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(sd::hc::g_halo_dbg), (size_t)n_blocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -147,20 +147,26 @@ __global__ __launch_bounds__(256) void gn_finalize_colstats_kernel(const float* 
     const int c = g * cg + tc;
     const float* base = c < c0 ? cs0 + c : cs1 + (c - c0);
     const int cw = c < c0 ? c0 : c1;
-    // four row blocks per trip: eight independent loads in flight (one per trip left this launch latency-bound: 12 us on average
-    // next to a 20 us apply pass); the sums are still taken in row-block order
-    int rb = tr;
-    for (; rb + 3 * per < rbs; rb += 4 * per) {
+    // eight row blocks per trip, all sixteen loads independent and the tail predicated (index clamped, weight 0) instead of a serial
+    // remainder loop: at the UNet's shapes (128 row blocks, 25 row lanes) the whole sum is ONE round of memory latency where the
+    // four-per-trip loop + remainder took three (11.5 us per launch, 31 launches per forward); sums still in row-block order
+    const long long st = (long long)per * 2 * cw;
+    for (int rb = tr; rb < rbs; rb += 8 * per) {
       const float* p = base + ((long long)(b * rbs + rb) * 2) * cw;
-      const long long st = (long long)per * 2 * cw;
-      const float a0 = p[0], b0 = p[cw], a1 = p[st], b1 = p[st + cw], a2 = p[2 * st], b2 = p[2 * st + cw], a3 = p[3 * st], b3 = p[3 * st + cw];
-      s = (((s + a0) + a1) + a2) + a3;
-      q = (((q + b0) + b1) + b2) + b3;
-    }
-    for (; rb < rbs; rb += per) {
-      const float* p = base + ((long long)(b * rbs + rb) * 2) * cw;
-      s += p[0];
-      q += p[cw];
+      float av[8], bv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool ok = rb + k * per < rbs;
+        const float* pk = ok ? p + k * st : p;
+        av[k] = pk[0];
+        bv[k] = pk[cw];
+        if (!ok) av[k] = bv[k] = 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s += av[k];
+        q += bv[k];
+      }
     }
   }
   rs[threadIdx.x] = s;

@@ -30,5 +30,5 @@ for name, m, run in (("decoder", vae.dec, vae.dec.decode_static), ("encoder", va
         acc = collections.defaultdict(lambda: [0.0, 0, 0.0])
         for tag, fl, ms in m.g.profile(reps=2):
             acc[tag][0] += ms; acc[tag][1] += 1; acc[tag][2] += fl
-        for tag, (ms, n, fl) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]:
+        for tag, (ms, n, fl) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:(40 if "--all" in sys.argv else 12)]:
             print(f"   {ms:8.3f} ms n={n:3d} {fl/ms/1e9 if ms else 0:7.1f} TF/s  {tag}")
