@@ -41,7 +41,7 @@ constexpr int kTile = 16, kHalo = 18, kChunk = 64, kN = 128;
 constexpr int kPatchBytes = kHalo * kHalo * 8 * 16;      // 41 472: 324 pixels x 8 octets of 8 channels
 constexpr int kWStage = kN * kChunk * 2;                 // 16 384: one (tap, chunk) weight slice [128][64]
 constexpr int kAffOff = kPatchBytes + 2 * kWStage;       // 74 240
-constexpr int kMaxC = 256;
+constexpr int kMaxC = 512;
 constexpr int kLds = kAffOff + kMaxC * 8;                // 76 288 bytes: two workgroups per CU
 constexpr int kStageRow = 64 * 4 + 16;                   // epilogue staging: 64 fp32 channels + 16 bytes of padding per pixel
 static_assert(4 * 64 * kStageRow + 4 * 2 * 2 * 64 * 4 <= kAffOff, "epilogue staging + the waves' column sums overlay the patch and the weight stages");
@@ -404,7 +404,7 @@ extern "C" int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine,
     return sd::plan_record(r);
   }
   if (!x || !w || !out) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: null pointer");
-  if (n != kN && n != 2 * kN) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: n = %d (built for 128 and 256 output channels)", n);
+  if (n <= 0 || n % kN || n > 4 * kN) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: n = %d (built for 128, 256, 384 and 512 output channels)", n);
   if (c <= 0 || c % kChunk || c > kMaxC) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: c = %d (a multiple of 64, at most %d)", c, kMaxC);
   if (batch <= 0 || h <= 0 || w_ <= 0 || h % kTile || w_ % kTile)
     return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: batch=%d h=%d w=%d (h, w multiples of 16)", batch, h, w_);

@@ -25,7 +25,7 @@ class _VaeBase:
     fused_conv_out = True        # class-level switch (tests / A-B): False = GroupNorm kernel + 64-column implicit-GEMM tile for conv_out
     halo_conv = True             # class-level switch (tests / A-B): False = GroupNorm kernel + implicit GEMM for the 128-channel 3x3 convolutions
     halo_min_tiles = 512         # ... from this many 16 x 16 tiles on (two per CU)
-    halo_widths = (128, 256)     # ... for these output widths (256 = two workgroups per tile, 128 channels each)
+    halo_widths = (128, 256, 512)     # ... for these output widths (n / 128 workgroups per tile, 128 channels each)
     fused_attention = True       # class-level switch (tests / A-B): False = QK^T GEMM -> softmax -> PV GEMM through memory
 
     def __init__(self, state, batch, device, cfg, use_graph=True, plan="decode"):
@@ -39,7 +39,7 @@ class _VaeBase:
     def _halo(self, cin, cout, H, W):
         """GroupNorm + SiLU + conv3x3 as ONE halo-patch convolution (sd_conv3x3_halo_f16) where it was built and measured: 128 output
         channels, at most 256 input channels, feature maps in whole 16 x 16 tiles that fill the chip (the 512 x 512 level of the VAE)."""
-        return (self.halo_conv and cout in self.halo_widths and cin % 64 == 0 and cin <= 256 and H % 16 == 0 and W % 16 == 0
+        return (self.halo_conv and cout in self.halo_widths and cin % 64 == 0 and cin <= 512 and H % 16 == 0 and W % 16 == 0
                 and self.batch * (H // 16) * (W // 16) * (cout // 128) >= self.halo_min_tiles)
 
     def _resnet(self, p, x, cin, cout, H, W):

@@ -218,13 +218,14 @@ int sd_gn_winograd_input_f16(const void* x0, const void* x1, int c0, int c1, con
                              int ldbb, int batch, int h, int w, int groups, float eps, const void* gamma, const void* beta, int silu, float mscale,
                              void* v, void* stream);
 
-/* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with 128 OUTPUT channels, as a halo-patch ("direct")
- * convolution (coma_amd/csrc/sd_haloconv.hip): the 128-channel layers of the VAE at 512 x 512, where the implicit GEMM re-stages every
- * activation nine times for only 128 columns and sits behind a GroupNorm apply pass over the 0.5 GB tensor.
- *   x fp16 NHWC [batch][h][w][c], c in {64, 128, 192, 256}, h and w multiples of 16;
+/* GroupNorm affine + SiLU folded into a 3x3 / stride 1 / pad 1 convolution with n = 128 ... 512 OUTPUT channels, as a halo-patch ("direct")
+ * convolution (coma_amd/csrc/sd_haloconv.hip): the ResNet convolutions of the VAE.  At n = 128 (512 x 512) the implicit GEMM re-stages every
+ * activation nine times for only 128 columns; at every width it sits behind a GroupNorm apply pass over the whole tensor.  A 16 x 16 pixel
+ * tile is computed by n / 128 workgroups, 128 output channels each.
+ *   x fp16 NHWC [batch][h][w][c], c a multiple of 64 up to 512, h and w multiples of 16;
  *   gn_affine fp32 [batch][c][2] = (scale, shift) of the GroupNorm (sd_groupnorm_table_f16), or NULL for a plain convolution;
- *   out[m, 0:128] = conv3x3(act(x * scale + shift)) + bias (+ res[m, 0:128]), act = SiLU if silu, zero padding of the ACTIVATED tensor;
- *   colstats != NULL: fp32 [batch*h*w/256][2][128], sums / sums of squares of the stored output per 16 x 16 pixel tile (one slot per
+ *   out[m, 0:n] = conv3x3(act(x * scale + shift)) + bias (+ res[m, 0:n]), act = SiLU if silu, zero padding of the ACTIVATED tensor;
+ *   colstats != NULL: fp32 [batch*h*w/256][2][n], sums / sums of squares of the stored output per 16 x 16 pixel tile (one slot per
  *   workgroup: sd_groupnorm_table_f16 with rows_per_slot = 256; 8 x fewer slots than the GEMM epilogue's 32-row slots -- at 512 x 512 the
  *   consumer's table launch read 67 MB of them, 84-120 us).  Recordable.
  * replaces: GroupNorm -> SiLU -> Conv2d(3x3) of ResnetBlock2D inside self.vae.decode / self.vae.encode,

@@ -12,6 +12,8 @@ if "--gemm-conv-out" in sys.argv:
     vae_mod._VaeBase.fused_conv_out = False           # A/B: GroupNorm kernel + 64-column implicit-GEMM tile for the decoder's conv_out
 if "--halo128" in sys.argv:
     vae_mod._VaeBase.halo_widths = (128,)             # A/B: halo convolutions only for 128 output channels
+if "--halo256" in sys.argv:
+    vae_mod._VaeBase.halo_widths = (128, 256)
 if "--no-halo" in sys.argv:
     vae_mod._VaeBase.halo_conv = False
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8

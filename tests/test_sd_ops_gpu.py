@@ -621,7 +621,8 @@ def test_conv3x3_small_n_with_folded_groupnorm(ops, B, H, W, n, norm, silu, C):
 @pytest.mark.parametrize("B,H,W,C,norm,silu,res,stats,n", [(2, 32, 48, 128, True, True, False, True, 128), (1, 16, 16, 256, True, True, True, True, 128),
                                                            (3, 48, 32, 128, False, False, True, False, 128), (1, 64, 64, 64, True, False, False, True, 128),
                                                            (2, 16, 32, 192, True, True, True, False, 128), (2, 32, 32, 256, True, True, True, True, 256),
-                                                           (1, 48, 16, 128, True, True, False, True, 256)])
+                                                           (1, 48, 16, 128, True, True, False, True, 256), (1, 32, 16, 512, True, True, True, True, 512),
+                                                           (2, 16, 16, 320, True, True, False, False, 384)])
 def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, stats, n):
     """sd_conv3x3_halo_f16 (GroupNorm affine + SiLU + 3x3 convolution with 128 output channels as a halo-patch convolution: the VAE's
     128-channel layers) against affine -> SiLU -> fp16 rounding -> conv2d (+ bias, + residual) in fp32: one to four 64-channel chunks,
@@ -661,7 +662,7 @@ def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, st
         assert torch.allclose(t1[:B * n * 2], t2[:B * n * 2], rtol=2e-4, atol=2e-4)
     with pytest.raises(Exception, match="multiples of 16"):
         ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H - 1, w_=W, c=C)
-    with pytest.raises(Exception, match="128 and 256 output channels"):
+    with pytest.raises(Exception, match="128, 256, 384 and 512 output channels"):
         ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=64)
 
 
