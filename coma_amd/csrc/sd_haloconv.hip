@@ -76,7 +76,11 @@ struct HaloArgs {
 constexpr int kDbgBlocks = 8192;
 __device__ unsigned long long g_halo_dbg[kDbgBlocks * 8];
 #define HALO_STAMP(k) do { if (dbg_on) g_halo_dbg[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#ifdef HALO_DBG_LIGHT                                      // stamps only (the accumulating counters cost a global read-modify-write per slice)
+#define HALO_ACC(k, t0) do {} while (0)
+#else
 #define HALO_ACC(k, t0) do { if (dbg_on) g_halo_dbg[blockIdx.x * 8 + (k)] += __builtin_readcyclecounter() - (t0); } while (0)
+#endif
 #else
 #define HALO_STAMP(k) do {} while (0)
 #define HALO_ACC(k, t0) do {} while (0)

@@ -31,9 +31,11 @@ lib = _lib.lib()
 lib.sd_halo_debug.restype = C.c_int
 assert lib.sd_halo_debug(st.ctypes.data_as(C.c_void_p), nb) == 0
 st = st.astype(np.int64)
-span = st[:, 3].max() - st[:, 0].min()
+span = int(st[:, 3].max() - st[:, 0].min())
 tot = st[:, 3] - st[:, 0]
 print(f"C={Cc}: {us:.1f} us, span {span / 1e3:.0f} kcyc -> {span / us / 1e3:.2f} GHz; per workgroup (median, kcyc): total {np.median(tot) / 1e3:.1f}  "
       f"entry->first commit {np.median(st[:, 1] - st[:, 0]) / 1e3:.1f}  K loop {np.median(st[:, 2] - st[:, 1]) / 1e3:.1f}  "
       f"epilogue {np.median(st[:, 3] - st[:, 2]) / 1e3:.1f} | parked in slice wait+barrier {np.median(st[:, 4]) / 1e3:.1f}  commits {np.median(st[:, 5]) / 1e3:.1f}")
+# occupancy of the two slots per CU: sum of workgroup lifetimes / (512 slots x kernel span)
+print(f"  slot occupancy: sum of workgroup lifetimes / (2 x 256 CUs x span) = {tot.sum() / (512.0 * span):.2f}; first entry -> last exit {span / 1e3:.0f} kcyc")
 print(f"  MFMA issue floor per workgroup-wave: {9 * (Cc // 64) * 64 * 16 / 1e3:.1f} kcyc; workgroups resident per CU: 2; rounds {nb / 512:.0f}")
