@@ -149,6 +149,19 @@ def bench_inpaint(args, dev, world, rank):
         g_fl, g_ms = sum(f for f, _ in gemm), sum(m for _, m in gemm)
         flops_img = (pipe.unet.g.flops * 50 + pipe.vae.dec.g.flops + pipe.vae.enc.g.flops) / B
         vendor = vendor_gemm_reference(dev)
+        # the two VAE graphs on their own (outside the timed region): 1 + 1 of them per image in this workload, 21 + 21 per image in the
+        # adaptive loop, where they are ~ 43 % of the time
+        vae_ms = {}
+        for name, run in (("decode_ms", pipe.vae.dec.decode_static), ("encode_ms", pipe.vae.enc.encode_static)):
+            run()
+            torch.cuda.synchronize()
+            a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                run()
+            e.record()
+            torch.cuda.synchronize()
+            vae_ms[name] = a.elapsed_time(e) / 3
         value = world * B * args.steps / dt
         res = {
             "metric": "HOI images/sec (50-step SD-1.5 inpaint, 512x512, fixed mask, CFG; BASELINE metric part 1)",
@@ -165,18 +178,21 @@ def bench_inpaint(args, dev, world, rank):
                          "frac": g_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS, "launches": n_gemm,
                          "avg_launch_ms": g_ms / n_gemm, "flops_per_forward": g_fl,
                          "executed_tflops": exec_fl / g_ms / 1e9, "executed_flops_per_forward": exec_fl,
+                         "executed_frac": exec_fl / g_ms / 1e9 / MFMA_F16_PEAK_TFLOPS,      # what the MFMAs issued against the same peak
                          "flops_what": "algorithmic: 2*M*N*K of every conv3x3 / 1x1 / linear operator of a UNet forward; the 24 ResNet convolutions of "
                                        "the 16x16 / 8x8 levels run as Winograd F(2x2,3x3) (16 plane products = 4/9 of the multiplies) and are timed "
                                        "with their transform launches; executed_* counts the MFMA flops actually issued",
                          "algorithmic_bytes": alg_bytes / n_gemm, "algorithmic_bytes_what": "per launch, mean over the launch list: every input "
                          "activation, weight, bias / residual tile read once + the output written once (fp16)",
                          "traffic": UNET_GEMM_PMC_TRAFFIC_BYTES if B == 8 else None,
-                         "traffic_source": "profiles/r04_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
+                         "traffic_source": "profiles/r05_unet_gemm_traffic.txt: (2*FETCH_SIZE + WRITE_SIZE) per conv_gemm launch, mean over "
                                            "the launches of eager UNet forwards at batch 16 (fabric-side requests of the 8 L2s: "
                                            "weights are pulled once per XCD and mostly hit the Infinity Cache)",
                          "unet_forward_ms_eager_sum": tot_ms,
                          "vendor_gemm": vendor,
                          "attention": {"achieved": sum(f for f, _ in attn) / sum(m for _, m in attn) / 1e9, "unit": "TFLOP/s"}},
+            "vae": dict(vae_ms, batch=B, what="VAE decoder / encoder hipGraph at 512 x 512, HIP events, mean of 3 replays "
+                                              "(every ResNet convolution = halo-patch convolution with the GroupNorm + SiLU folded in)"),
         }
     del pipe
     torch.cuda.empty_cache()
@@ -269,7 +285,7 @@ def bench_contact(args, dev, world, rank):
                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS,
                      "kernel_ms": kern_ms, "flop_per_pair": flop_per_pair(N), "algorithmic_hbm_bytes": alg_bytes,
                      "traffic": CONTACT_PMC_TRAFFIC_BYTES if (S, H, O, N) == (64, 10475, 180, 250) else None,
-                     "traffic_source": "profiles/r04_inpaint_pmc.txt (contact_accumulate_kernel): (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
+                     "traffic_source": "profiles/r05_inpaint_pmc.txt (contact_accumulate_kernel): (2*FETCH_SIZE + WRITE_SIZE) KiB per launch"},
     }
 
 
@@ -399,16 +415,16 @@ def bench_occupancy(args, dev, world, rank):
 
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
-#   profiles/r04_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
-#   profiles/r04_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91545e6 KiB, WRITE_SIZE 3.71199e6 KiB per launch
-#   profiles/r04_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.12 GB, rowprep 2 * 0.21 + 0.23 GB,
-#                                        groupmax 0.06 GB
-UNET_GEMM_PMC_TRAFFIC_BYTES = int(157.19e6)
+#   profiles/r05_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
+#   profiles/r05_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91584e6 KiB, WRITE_SIZE 3.71089e6 KiB per launch
+#   profiles/r05_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.124 GB, rowprep 2 * 0.209 + 0.232 GB,
+#                                        groupmax 0.04 GB
+UNET_GEMM_PMC_TRAFFIC_BYTES = int(158.17e6)
 OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.96e9)   # fused 11.02 + 0.25, rowprep 0.42 + 0.23, groupmax 0.04 GB
-OCCUPANCY_PMC_SOURCE = ("profiles/r04_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
+OCCUPANCY_PMC_SOURCE = ("profiles/r05_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
                         "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "
                         "the grid written once + the incidences; the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
-CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91545e6 + 3.71199e6) * 1024)
+CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91584e6 + 3.71089e6) * 1024)
 
 
 def main():

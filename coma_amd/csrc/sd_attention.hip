@@ -871,6 +871,7 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   else if (d == 40) SD_ATTN_LAUNCH(3, 2, 1, 40);
   else if (d <= 48) SD_ATTN_LAUNCH(3, 2, 1, -1);
   else if (d <= 64) SD_ATTN_LAUNCH(4, 2, 1, -1);
+  else if (d == 80) SD_ATTN_LAUNCH(5, 3, 1, 80);     // r5: V^T rows 80-95 are padding at d = 80 too -> the ones row gives the denominator (C = 640 level)
   else if (d <= 80) SD_ATTN_LAUNCH(5, 3, 1, -1);
   else if (d <= 96) SD_ATTN_LAUNCH(6, 3, 1, -1);
   else if (d <= 128) SD_ATTN_LAUNCH(8, 4, 1, -1);
