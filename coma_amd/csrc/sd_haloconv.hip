@@ -19,6 +19,10 @@
 //     (sd_groupnorm_table_f16 with rows_per_slot = 256: 8 x fewer slots than the GEMM epilogue's, whose 67 MB at 512 x 512 cost the
 //     consumer's table launch 84-120 us).
 // Algorithmic bytes: the input read once (+ 27 % halo), the output written once, the residual read once.
+// Measured alternatives that were NOT kept (profiles/r05_notes.md 1): persistent workgroups with the next tile's patch prefetched inside
+// the epilogue (spills: ~ 35 registers short), the four waves splitting the output channels with their weight fragments loaded straight
+// from L2 into registers (no weight staging, no barrier per slice: 739 vs 736 us), and that form on 16 x 8 tiles with three workgroups
+// per CU (146 registers, 37 KB of LDS: 808-823 vs 730-737 us).
 #include <hip/hip_fp16.h>
 
 #include "common.h"
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(HaloArgs a) {
     }
   }
 }
+
 
 }  // namespace hc
 }  // namespace sd
