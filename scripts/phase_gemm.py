@@ -61,6 +61,9 @@ SH = [(65536, 320, 320, 1, None, 0), (65536, 320, 1280, 1, None, 0), (65536, 320
       (16384, 640, 640, 1, None, 0), (16384, 640, 5760, 9, 1024, 0), (16384, 1280, 11520, 9, 1024, 0),
       (4096, 1280, 1280, 1, None, 0), (4096, 1280, 11520, 9, 256, 0), (1024, 1280, 11520, 9, 64, 0),
       (65536, 2560, 320, 1, None, 1), (16384, 5120, 640, 1, None, 1), (4096, 10240, 1280, 1, None, 1)]
+if os.environ.get("TAIL"):      # the short-K launches of the C = 640 / 1280 transformer blocks
+    SH = [(16384, 640, 640, 1, None, 0), (4096, 1280, 1280, 1, None, 0), (16384, 1920, 640, 1, None, 0), (4096, 3840, 1280, 1, None, 0),
+          (16384, 640, 2560, 1, None, 0), (4096, 1280, 5120, 1, None, 0), (16384, 5120, 640, 1, None, 1), (4096, 10240, 1280, 1, None, 1)]
 knob = sum(1 << int(b) for b in sys.argv[1].split("+")) if len(sys.argv) > 1 else 0
 for sh in SH:
     if os.environ.get("GEGLU_ONLY") and not sh[5]:

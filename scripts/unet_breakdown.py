@@ -6,7 +6,7 @@ import torch
 from coma_amd.sd import weights
 from coma_amd.sd.unet import HipUNet2DConditionModel
 dev = "cuda:0"
-B = 16
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 state = weights.random_state(weights.unet_shapes(), seed=0, device=dev)
 unet = HipUNet2DConditionModel(state, batch=B, height=64, width=64, device=dev, use_graph=True)
 g = torch.Generator(device=dev).manual_seed(0)
