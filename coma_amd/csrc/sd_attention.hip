@@ -849,7 +849,8 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   // it process-wide.
   static const int sp_mode = [] { const char* e = getenv("SD_ATTN_V"); return e ? atoi(e) : 2; }();
   const bool sp_legal = d == 40 && (vt_perm16 & 1) && lk % BKV == 0 && lk >= 2 * BKV;
-  const bool sp_auto = sp_mode >= 2 && !(vt_perm16 & 4) && (long long)batch * heads * ((lq + 255) / 256) >= 512;
+  // (r5: from ONE block per CU on -- UNet batch 2, one image per pipeline call: 75 us against 97 us for the r2 kernel; it was two per CU)
+  const bool sp_auto = sp_mode >= 2 && !(vt_perm16 & 4) && (long long)batch * heads * ((lq + 255) / 256) >= 256;
   if (sp_legal && ((vt_perm16 & 2) || sp_auto)) {
     // (HQ = 2, 128 queries per wave, measured slower -- 585 vs 487 us -- and is not instantiated: it needs 460 registers)
     dim3 g2((unsigned)((lq + 255) / 256), (unsigned)heads, (unsigned)batch);
