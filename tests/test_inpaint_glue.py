@@ -244,3 +244,21 @@ def test_per_item_state_inherits_from_the_previous_item():
     assert p.initial_human_bbox == ("box", "new")
     w.select(1, inherit_from=0)                      # the live slot can be overwritten too
     assert p.initial_human_bbox == ("box", 2)
+
+
+def test_synthetic_plug_in_batched_form_equals_the_per_image_form():
+    """SyntheticHumanMaskPredictor.predict_batch (one plug-in call per mask re-estimation of a batched pipeline call) returns, image by image,
+    the bits of __call__ on a tensor and of __call__ on the reference-contract NumPy array."""
+    from coma_amd.sd.pipeline import SyntheticHumanMaskPredictor
+    p = SyntheticHumanMaskPredictor()
+    g = torch.Generator().manual_seed(3)
+    imgs = (torch.rand(5, 64, 48, 3, generator=g) * 255).to(torch.uint8)
+    imgs[2] = 255
+    imgs[3] = 0
+    batch = p.predict_batch(imgs)["mask"]
+    assert batch.dtype == torch.uint8 and tuple(batch.shape) == (5, 64, 48)
+    for b in range(5):
+        one_t = p(imgs[b])["mask"]
+        one_n = p(imgs[b].numpy())["mask"]
+        assert torch.equal(batch[b], one_t) and np.array_equal(batch[b].numpy(), one_n)
+    assert 0 < int(batch[0].sum()) < 64 * 48
