@@ -417,6 +417,7 @@ extern "C" int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine,
   if (c <= 0 || c % kChunk || c > kMaxC) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: c = %d (a multiple of 64, at most %d)", c, kMaxC);
   if (batch <= 0 || h <= 0 || w_ <= 0 || h % kTile || w_ % kTile)
     return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: batch=%d h=%d w=%d (h, w multiples of 16)", batch, h, w_);
+  if (silu && !gn_affine) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: silu is applied with the GroupNorm affine (gn_affine is NULL)");
   if (ldo == 0) ldo = n;
   if (ldr == 0) ldr = n;
   if (ldo < n || ldo % 8 || (res && (ldr < n || ldr % 8))) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: ldo = %d, ldr = %d", ldo, ldr);

@@ -206,7 +206,7 @@ def test_model_file_is_verified_before_it_is_trusted(tmp_path, hip_lib):
 
 
 def test_winograd_and_small_n_records_survive_save_and_load(tmp_path, hip_lib):
-    """The r4 entry points are recordable: a plan of [GroupNorm + Winograd input transform] -> 16 plane products -> output transform ->
+    """The r4 / r5 entry points are recordable: a plan of [GroupNorm + Winograd input transform] -> 16 plane products -> output transform ->
     [GroupNorm table + SiLU + 3x3 convolution with 3 output channels] is saved with its constants (the transformed weights U = G g G^T are
     computed outside the plan and must be registered as persistent when first recorded), loaded into a fresh model and replayed there:
     same bits."""
@@ -215,7 +215,7 @@ def test_winograd_and_small_n_records_survive_save_and_load(tmp_path, hip_lib):
     from coma_amd.sd.graph import LaunchGraph
     from coma_amd.sd.model import SdModel
     g = LaunchGraph(DEV, plan="p")
-    B, H, W, C, n = 2, 8, 8, 128, 128
+    B, H, W, C, n = 2, 16, 16, 128, 128
     gen = torch.Generator().manual_seed(4)
     r = lambda *s, k=1.0: (torch.randn(*s, generator=gen) * k).half().to(DEV)
     x, out, img = g.buf(B * H * W, C), g.buf(B * H * W, n), g.buf(B * H * W, 64, zero=True)
@@ -225,7 +225,11 @@ def test_winograd_and_small_n_records_survive_save_and_load(tmp_path, hip_lib):
     V = g.gn_winograd_input(ga, be, batch=B, h=H, w=W, c0=C, x0=x, eps=1e-5)
     P = g.winograd_planes(V, g.winograd_weight(w9, n=n, c=C), tiles=B * (H // 2) * (W // 2), c=C, n=n)
     g.winograd_output(P, out, batch=B, h=H, w=W, n=n, bias=b9)
-    g.gn_silu_conv3x3_small_n(out, ga2, be2, w3, b3, img, batch=B, h=H, w_=W, c=n, n=3, eps=1e-6)
+    # r5: [GroupNorm table + halo-patch convolution with residual, leaving per-tile column sums] -> [table from them (rows_per_slot = 256) + ...]
+    out2 = g.buf(B * H * W, n)
+    wh, bh = r(n, 9 * n, k=(9 * n) ** -0.5), r(n)
+    g.gn_silu_conv3x3_halo(out, ga2, be2, wh, bh, out2, batch=B, h=H, w_=W, c=n, n=n, eps=1e-6, res=out, stats=True)
+    g.gn_silu_conv3x3_small_n(out2, ga2, be2, w3, b3, img, batch=B, h=H, w_=W, c=n, n=3, eps=1e-6)
     g.model.bind("x", x)
     g.model.bind("img", img)
     xin = r(B * H * W, C)
@@ -238,7 +242,7 @@ def test_winograd_and_small_n_records_survive_save_and_load(tmp_path, hip_lib):
     path = tmp_path / "w.sdm"
     g.model.save(path)
     m2 = SdModel.load(path, DEV)
-    assert m2.num_launches("p") == g.model.num_launches("p") >= 5
+    assert m2.num_launches("p") == g.model.num_launches("p") >= 7
     px, nx = m2.binding("x")
     pi, ni = m2.binding("img")
     _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(px), ctypes.c_void_p(xin.data_ptr()), nx, _lib.stream_ptr(xin.device)), "copy")
