@@ -666,6 +666,46 @@ def test_conv3x3_halo_with_folded_groupnorm(ops, B, H, W, C, norm, silu, res, st
         ops.conv3x3_halo(x.to(DEV), w.reshape(n, -1).to(DEV), out, batch=B, h=H, w_=W, c=C, n=64)
 
 
+@pytest.mark.parametrize("C,n", [(128, 128), (256, 256)])
+def test_conv3x3_halo_at_the_benchmark_size_equals_groupnorm_plus_implicit_gemm(ops, C, n):
+    """BASELINE configs 2 / 3 at full size (batch 8; 512 x 512 x 128 -> 128 and 256 x 256 x 256 -> 256: 8192 / 4096 workgroups, every border
+    case of a real feature map): [table from the producer's 32-row column sums + halo convolution with residual] against
+    [sd_groupnorm_colstats_f16 + implicit GEMM with residual], the path the 512 x 512 fp32-restatement tests of r1-r4 pinned.  Same products,
+    same fp16 storage points, other accumulation order: <= 2e-3 max|ref| (measured 4.5e-4); and the per-sample column sums the two leave
+    for the next GroupNorm (256-row tile slots vs 32-row slots) agree."""
+    B = 8
+    H = W = 512 if C == 128 else 256
+    M, hw = B * H * W, H * W
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(M, C, generator=g, device=DEV).half()
+    w = (torch.randn(n, 9 * C, generator=g, device=DEV) * (9 * C) ** -0.5).half()
+    bias, res = torch.randn(n, generator=g, device=DEV).half(), torch.randn(M, n, generator=g, device=DEV).half()
+    ga, be = (torch.rand(C, generator=g, device=DEV) + 0.5).half(), (torch.randn(C, generator=g, device=DEV) * 0.1).half()
+    cs_in = torch.zeros(M // 32, 2, C, dtype=torch.float32, device=DEV)
+    for b in range(B):                                                   # per sample: keeps the fp32 temporaries small
+        xf = x[b * hw:(b + 1) * hw].float().reshape(hw // 32, 32, C)
+        cs_in[b * hw // 32:(b + 1) * hw // 32, 0], cs_in[b * hw // 32:(b + 1) * hw // 32, 1] = xf.sum(1), (xf * xf).sum(1)
+    del xf
+    stats = torch.empty(1 << 20, dtype=torch.float32, device=DEV)
+    norm = torch.empty(M, C, dtype=F16, device=DEV)
+    out_a, out_b = torch.empty(M, n, dtype=F16, device=DEV), torch.empty(M, n, dtype=F16, device=DEV)
+    cs_a = torch.zeros(M // 32, 2, n, dtype=torch.float32, device=DEV)
+    cs_b = torch.zeros(M // 256, 2, n, dtype=torch.float32, device=DEV)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.groupnorm_colstats(x, ga, be, norm, stats, cs_in, batch=B, hw=hw, c0=C, eps=1e-6, silu=True)
+    ops.conv_gemm(norm, w, out_a, batch=B, in_h=H, in_w=W, c0=C, n=n, taps=9, bias=bias, res=res, colstats=cs_a, workspace=ws)
+    ops.groupnorm_table(x, ga, be, stats, batch=B, hw=hw, c0=C, eps=1e-6, colstats0=cs_in)
+    ops.conv3x3_halo(x, w, out_b, batch=B, h=H, w_=W, c=C, n=n, bias=bias, res=res, gn_affine=stats, silu=True, colstats=cs_b)
+    torch.cuda.synchronize()
+    scale = float(out_a.float().abs().max())
+    err = float((out_a.float() - out_b.float()).abs().max())
+    print(f"METRIC halo vs gemm at full size C={C} n={n}: max|diff| / max|ref| = {err / scale:.2e}")
+    assert bool(torch.isfinite(out_b.float()).all()) and err <= 2e-3 * scale
+    sa, sb = cs_a[:, 0].reshape(B, -1, n).sum(1), cs_b[:, 0].reshape(B, -1, n).sum(1)
+    qa, qb = cs_a[:, 1].reshape(B, -1, n).sum(1), cs_b[:, 1].reshape(B, -1, n).sum(1)
+    assert torch.allclose(sa, sb, rtol=1e-3, atol=2e-3 * scale * hw ** 0.5) and torch.allclose(qa, qb, rtol=2e-3)
+
+
 @pytest.mark.parametrize("B,H,W,c0,c1,n", [(2, 16, 16, 64, 0, 128), (1, 8, 12, 64, 64, 64), (3, 32, 32, 320, 0, 320)])
 def test_winograd_f2x2_3x3_chain_equals_the_direct_convolution(ops, B, H, W, c0, c1, n):
     """The measured Winograd probe (profiles/r04_notes.md 1; not part of the UNet / VAE plans): input transform -> 16 plane products
