@@ -861,7 +861,9 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   // 64 queries per wave once there are enough blocks to fill the chip -- unless there are only a few key tiles (the 77-token cross
   // attention): then a block is all prologue / epilogue latency and more resident blocks (QT = 1: ~100 registers) hide it better
   static const int xqt1 = [] { const char* e = getenv("SD_ATTN_XQT1"); return e ? atoi(e) : 1; }();   // 38.5 -> 34.9 us at lq = 4096, lk = 77
-  const bool two = lq >= 1024 && d == 40 && !(xqt1 && lk <= 128);
+  // r5: ... and at d = 80 (the 32 x 32 level: 73.4 -> 64.4 us; 254 registers) once 256-query blocks fill the chip twice
+  const bool two80 = d == 80 && lq >= 1024 && lk >= 256 && (long long)batch * heads * ((lq + 255) / 256) >= 512;
+  const bool two = (lq >= 1024 && d == 40 && !(xqt1 && lk <= 128)) || two80;
   dim3 grid((unsigned)((lq + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)heads, (unsigned)batch);
 #define SD_ATTN_LAUNCH(KS, DVT, QT, ONES)                                                                       \
   do {                                                                                                          \
@@ -872,6 +874,7 @@ extern "C" int sd_attention_f16(const void* q, const void* k, const void* vt, vo
   else if (d == 40) SD_ATTN_LAUNCH(3, 2, 1, 40);
   else if (d <= 48) SD_ATTN_LAUNCH(3, 2, 1, -1);
   else if (d <= 64) SD_ATTN_LAUNCH(4, 2, 1, -1);
+  else if (two80) SD_ATTN_LAUNCH(5, 3, 2, 80);
   else if (d == 80) SD_ATTN_LAUNCH(5, 3, 1, 80);     // r5: V^T rows 80-95 are padding at d = 80 too -> the ones row gives the denominator (C = 640 level)
   else if (d <= 80) SD_ATTN_LAUNCH(5, 3, 1, -1);
   else if (d <= 96) SD_ATTN_LAUNCH(6, 3, 1, -1);

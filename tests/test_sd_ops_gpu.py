@@ -180,6 +180,21 @@ def test_attention(ops, heads, d, lq, lk):
     close(out2, ref, tol=4e-3)
 
 
+def test_attention_d80_with_64_queries_per_wave(ops):
+    """d = 80 at the UNet's 32 x 32 level (batch 16 x 8 heads x 1024 queries = 512 blocks of 256 queries: the QT = 2 instantiation with the
+    ones-row denominator, r5), ragged last key tile, against the fp32 reference on the first two and the last sample."""
+    B, H, lq, lk, d = 16, 8, 1024, 328, 80
+    C = H * d
+    g = torch.Generator().manual_seed(9)
+    q, k, v = (torch.randn(B, n_, C, generator=g).half() for n_ in (lq, lk, lk))
+    vt = ops.perm16_columns(v.transpose(1, 2).contiguous().to(DEV))
+    out = torch.empty(B, lq, C, dtype=F16, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), vt, out, batch=B, heads=H, lq=lq, lk=lk, d=d, ldq=C, ldk=C, ldv=vt.shape[-1], ldo=C, scale=d ** -0.5,
+                  vt_perm16=True)
+    for b in (0, 1, B - 1):
+        close(out[b:b + 1], so.attention_ref(q[b:b + 1].float(), k[b:b + 1].float(), v[b:b + 1].float(), H, d ** -0.5))
+
+
 @pytest.mark.parametrize("L,C", [(200, 320), (77, 320), (64, 1280)])
 def test_v_transposed_projection_in_the_permuted_layout(ops, L, C):
     """SD_EPI_PERM16_N: the batched V^T projection writes every group of 16 keys in the order (0-3, 8-11, 4-7, 12-15), rounded up
