@@ -660,8 +660,10 @@ __global__ __launch_bounds__(256, 1) void attention_sp_kernel(AttnArgs a) {
 // in two single-buffered LDS regions and alternate -- the next K tile streams in (LDS-DMA) while P.V runs, the next V^T tile
 // while Q.K^T runs.  128 MFMAs (2048 cycles) against 16 exp2 per lane and tile: matrix-bound; every fragment feeds one MFMA,
 // so the LDS read port (128 B / clk / CU) is the practical limit.
-template <int DT>
-__global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
+// NW = 8 waves (128 queries per workgroup, two waves per SIMD) when that still fills the chip: a wave's fragment reads and its four barrier waits per
+// key tile run under its partner's MFMAs, and a K / V^T tile is fetched once per 128 queries (profiles/r05_notes.md 9).
+template <int DT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attention_wide_kernel(AttnArgs a) {
   constexpr int D = 32 * DT;                       // head dim
   constexpr int KROW = D;                          // halves per K row in LDS (16-byte chunks: D / 8, swizzled with the key index)
   extern __shared__ __attribute__((aligned(1024))) _Float16 wide_smem[];
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = blockIdx.x * (NW * 16) + wave * 16;
   const int n = lane & 15, g = lane >> 4;
 
   // Q fragments (B operand): lane (query n, chunk g) holds dd = 32 j + 8 g .. + 7
@@ -709,16 +711,19 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
   const __amdgpu_buffer_rsrc_t k_rsrc = make_rsrc(kbase, (unsigned)(((long long)(a.lk - 1) * a.ldk + D) * 2));
   const __amdgpu_buffer_rsrc_t v_rsrc = make_rsrc(vbase, (unsigned)((long long)D * a.ldv * 2));
   constexpr int KPI = D / 512 > 0 ? D / 512 : 1;   // K instructions per key row (D = 512: 1); smaller D: several rows per instruction
-  constexpr int K_INSTR = BKV * D * 2 / 1024 / 4;  // per wave and tile
-  constexpr int V_INSTR = D * 128 / 1024 / 4;
+  constexpr int K_INSTR = BKV * D * 2 / 1024 / NW;  // per wave and tile
+  constexpr int V_INSTR = D * 128 / 1024 / NW;
+  static_assert(K_INSTR >= 1 && V_INSTR >= 1 && K_INSTR * NW * 1024 == BKV * D * 2 && V_INSTR * NW * 1024 == D * 128, "DMA pieces per wave");
   static_assert(D % 64 == 0 || D == 32, "row pitch");
   const unsigned k_step = (unsigned)(BKV * a.ldk * 2), v_step = BKV * 2;
   auto issue_k = [&](int tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                   // the piece offsets are recomputed per tile, not carried through the loop (registers)
 #pragma unroll
     for (int i = 0; i < K_INSTR; ++i) {
       const int idx = wave * K_INSTR + i;          // 1 KiB piece of the tile
-      const int e16 = idx * 64 + lane;             // 16-byte element of the tile
+      const int e16 = idx * 64 + ln;               // 16-byte element of the tile
       const int row = e16 / (D / 8), slot = e16 % (D / 8);
       const int chunk = (slot & ~15) | ((slot ^ row) & 15);
       const unsigned off = (unsigned)(row * a.ldk * 2 + chunk * 16) + tile * k_step;
@@ -728,10 +733,12 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
   };
   auto issue_v = [&](int tile) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
 #pragma unroll
     for (int i = 0; i < V_INSTR; ++i) {
       const int idx = wave * V_INSTR + i;
-      const int row = idx * 8 + (lane >> 3), slot = lane & 7;
+      const int row = idx * 8 + (ln >> 3), slot = ln & 7;
       const unsigned off = (unsigned)(row * a.ldv * 2 + swz64(row, slot) * 16) + tile * v_step;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(Vbuf + idx * 512), 16, off, 0, 0, 0);
     }
@@ -739,24 +746,29 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
   };
   (void)KPI;
 
+  int koff[4], voff[2];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) koff[jj] = n * KROW + (((4 * jj + g) ^ n) & 15) * 8;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) voff[ks] = n * 64 + swz64(n, 4 * ks + g) * 8;      // (swz64 looks at the low row bits only: 16 db drops out)
   const int ntiles = a.lk / BKV;
   issue_k(0);
   issue_v(0);
   for (int t = 0; t < ntiles; ++t) {
     // K(t) was issued before V^T(t): all but the youngest V_INSTR pieces of this wave have landed
-    if (V_INSTR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V_INSTR) : "memory");
     __builtin_amdgcn_s_barrier();
     // ---- S^T = K Q^T, 4 key blocks of 16
     float4v s[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) s[kb] = float4v{0.f, 0.f, 0.f, 0.f};
+    // fragment (key block kb, dd step j) of lane (n, g): row 16 kb + n, chunk c = 4 j + g in slot (c & ~15) | ((c ^ row) & 15); the swizzled
+    // part only depends on j & 3, so FOUR lane offsets serve all 64 reads of a tile (the rest is an immediate)
 #pragma unroll
     for (int j = 0; j < DT; ++j)
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        const int row = kb * 16 + n, c = 4 * j + g;
-        const half8 kf = *reinterpret_cast<const half8*>(&Kbuf[row * KROW + ((c & ~15) | ((c ^ row) & 15)) * 8]);
+        const half8 kf = *reinterpret_cast<const half8*>(Kbuf + koff[j & 3] + kb * 16 * KROW + (j >> 2) * 128);
         s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[j], s[kb], 0, 0, 0);
       }
     __builtin_amdgcn_s_barrier();                    // every wave is done with K(t)
@@ -784,7 +796,7 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
         pf[kb >> 1][(kb & 1) * 4 + i] = (_Float16)p;
       }
     // V^T(t) has landed (the K(t+1) pieces issued above may still be in flight)
-    if (t + 1 < ntiles && K_INSTR == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K_INSTR) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // ---- O^T += V^T P^T: 2 key steps of 32, 2 DT blocks of 16 head dims
@@ -792,8 +804,7 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(AttnArgs a) {
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int db = 0; db < 2 * DT; ++db) {
-        const int row = db * 16 + n;
-        const half8 vf = *reinterpret_cast<const half8*>(&Vbuf[row * 64 + swz64(row, 4 * ks + g) * 8]);
+        const half8 vf = *reinterpret_cast<const half8*>(Vbuf + voff[ks] + db * 16 * 64);
         o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ks], o[db], 0, 0, 0);
       }
     __builtin_amdgcn_s_barrier();                    // every wave is done with V^T(t)
@@ -908,17 +919,21 @@ extern "C" int sd_attention_wide_f16(const void* q, const void* k, const void* v
   a.scale_log2 = scale * 1.4426950408889634f;
   a.no_spec = 0;
   const size_t lds = (size_t)2 * BKV * d * sizeof(_Float16);          // K tile + V^T tile
-  dim3 grid((unsigned)((lq + 63) / 64), (unsigned)heads, (unsigned)batch);
   hipStream_t s = (hipStream_t)stream;
-#define SD_WIDE_LAUNCH(DT)                                                                                                    \
+  // 128 queries per workgroup (8 waves) from one full round of such workgroups on (VAE batch 8: 470 -> 300 us; half a round -- batch 4 -- is a tie,
+  // below it the 64-query form wins by 8 - 10 %); SD_WIDE_NW = 4 / 8 forces either (A/B timing)
+  static const int nw_env = [] { const char* e = getenv("SD_WIDE_NW"); return e ? atoi(e) : 0; }();
+  const bool eight = nw_env ? nw_env == 8 : (long long)batch * heads * ((lq + 127) / 128) >= 256;
+#define SD_WIDE_LAUNCH(DT, NW)                                                                                                \
   do {                                                                                                                        \
     static coma::LdsOptIn lds_opt;                                                                                            \
-    if (int rc = coma::opt_in_lds(lds_opt, reinterpret_cast<const void*>(attention_wide_kernel<DT>), lds, "sd_attention_wide_f16")) return rc; \
-    hipLaunchKernelGGL((attention_wide_kernel<DT>), grid, dim3(256), lds, s, a);                                              \
+    if (int rc = coma::opt_in_lds(lds_opt, reinterpret_cast<const void*>(attention_wide_kernel<DT, NW>), lds, "sd_attention_wide_f16")) return rc; \
+    dim3 grid((unsigned)((lq + NW * 16 - 1) / (NW * 16)), (unsigned)heads, (unsigned)batch);                                  \
+    hipLaunchKernelGGL((attention_wide_kernel<DT, NW>), grid, dim3(NW * 64), lds, s, a);                                      \
   } while (0)
-  if (d == 512) SD_WIDE_LAUNCH(16);
-  else if (d == 256) SD_WIDE_LAUNCH(8);
-  else SD_WIDE_LAUNCH(4);
+  if (d == 512) { if (eight) SD_WIDE_LAUNCH(16, 8); else SD_WIDE_LAUNCH(16, 4); }
+  else if (d == 256) { if (eight) SD_WIDE_LAUNCH(8, 8); else SD_WIDE_LAUNCH(8, 4); }
+  else { if (eight) SD_WIDE_LAUNCH(4, 8); else SD_WIDE_LAUNCH(4, 4); }
 #undef SD_WIDE_LAUNCH
   return check_launch("attention_wide_kernel");
 }

@@ -253,9 +253,11 @@ def test_attention_pipelined_rescale_and_low_scores(ops):
         close(out, so.attention_ref(q2, kk, v, heads, d**-0.5), tol=8e-3)
 
 
-@pytest.mark.parametrize("d,L,heads,B", [(512, 256, 1, 2), (512, 4096, 1, 1), (256, 128, 2, 1), (128, 192, 3, 2)])
+@pytest.mark.parametrize("d,L,heads,B", [(512, 256, 1, 2), (512, 4096, 1, 1), (256, 128, 2, 1), (128, 192, 3, 2),
+                                         (512, 4096, 1, 8), (256, 1024, 8, 4), (128, 2240, 5, 3)])
 def test_attention_wide_heads(ops, d, L, heads, B):
-    """sd_attention_wide_f16 (the VAE mid-block: one head of 512 over 4096 tokens) vs torch fp32, V^T in the PERM32 key order."""
+    """sd_attention_wide_f16 (the VAE mid-block: one head of 512 over 4096 tokens) vs torch fp32, V^T in the PERM32 key order.  The last three
+    cases have >= 256 blocks of 128 queries and take the 8-wave form (the last one with a ragged final block)."""
     C = heads * d
     q, k, v = rnd(B, L, C, seed=1, scale=0.5), rnd(B, L, C, seed=2, scale=0.5), rnd(B, L, C, seed=3)
     if d == 512 and L == 256:
