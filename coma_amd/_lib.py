@@ -63,6 +63,7 @@ SIGNATURES = {
     "sd_conv3x3_halo_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "sd_gn_winograd_input_f16": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i, _f, _vp, _vp]),
     "sd_im2col3x3_c3_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "sd_conv3x3_c3_f16": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "sd_softmax_f16": (_i, [_vp, _i64, _i, _i, _f, _vp]),
     "sd_cfg_ddim_step": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp]),
     "sd_timestep_embedding_f16": (_i, [_vp, _i, _i, _vp, _vp]),

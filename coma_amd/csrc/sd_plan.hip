@@ -133,6 +133,8 @@ static int launch(const PlanRec& r, void* st) {
     case PK_CONV_HALO:
       return sd_conv3x3_halo_f16(p[0], (int)i[0], (const float*)p[1], (int)i[1], p[2], p[3], p[4], (int)i[2], (int)i[3], (int)i[4], (int)i[5],
                                  (int)i[6], p[5], (int)i[7], (float*)p[6], st);
+    case PK_CONV_C3:
+      return sd_conv3x3_c3_f16(p[0], (int)i[0], p[1], p[2], (int)i[1], (int)i[2], (int)i[3], (int)i[4], p[3], (int)i[5], (float*)p[4], st);
     case PK_COPY:
       return sd_copy_d2d(p[0], p[1], (size_t)i[0], st);
     default:

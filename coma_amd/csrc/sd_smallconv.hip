@@ -183,6 +183,123 @@ __global__ __launch_bounds__(256) void im2col3x3_c3_kernel(const _Float16* __res
   }
 }
 
+
+// ---- the same convolution (3 input channels -> 128, conv_in of the VAE encoder at 512 x 512) WITHOUT the packed copy: a workgroup owns a 16 x 16
+// pixel tile, keeps the (18 x 18) x 3 halo patch in LDS as [row][3 col + channel] (a tap row's 9 values are then contiguous), and every wave builds the
+// K = 32 operand of 16 pixels (k = 9 ky + 3 kx + channel = 3 tap + channel, 5 zeros) with eight 2-byte LDS reads per lane -- the im2col matrix
+// (134 MB per 8 images, written and read back) never exists.  D = W . X^T on `v_mfma_f32_16x16x32_f16`: the weights are eight register operands, a lane
+// owns pixel (lane & 15) and channels 16 nb + 4 (lane >> 4) + i.  The output leaves through a per-wave LDS staging tile as full 256-byte rows, and the
+// tile's column sums / sums of squares of the STORED fp16 values go to one statistics slot per tile (the layout sd_conv3x3_halo_f16 writes and
+// sd_groupnorm_table_f16(rows_per_slot = 256) reads): the first ResNet's GroupNorm no longer re-reads the 0.5 GB tensor for its statistics.
+// Bound: HBM -- the output written once (537 MB per 8 images).
+constexpr int kC3Row = 56;                                 // halves per patch row (18 x 3 = 54, padded)
+constexpr int kC3Zero = kHalo * kC3Row;                    // one zero half behind the patch: the source of k = 27 .. 31
+constexpr int kC3Stage = 136;                              // halves per staged pixel row (128 + 8: the 8-byte writes of 16 pixels x 4 groups spread over all banks)
+
+// sum over the 16 lanes of a DPP row, in every lane (row rotations by 8, 4, 2, 1: a fixed order)
+template <int CTRL>
+__device__ __forceinline__ float dpp_ror_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) { return dpp_ror_add<0x121>(dpp_ror_add<0x122>(dpp_ror_add<0x124>(dpp_ror_add<0x128>(v)))); }
+
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(const _Float16* __restrict__ x, int ldx, const _Float16* __restrict__ w32,
+                                                        const _Float16* __restrict__ bias, int H, int W, _Float16* __restrict__ out, int ldo,
+                                                        float* __restrict__ colstats) {
+  __shared__ _Float16 patch[kHalo * kC3Row + 8];
+  __shared__ __attribute__((aligned(16))) _Float16 stage[4][16 * kC3Stage];
+  __shared__ float wsum[4][2][128];
+  const int b = blockIdx.z, ty0 = blockIdx.y * kTile, tx0 = blockIdx.x * kTile;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+
+  // weights: operand nb of lane (n = lane & 15, g) = w32[16 nb + n][8 g .. 8 g + 7]; bias of this lane's output channels 16 nb + 4 g + i
+  half8 wf[8];
+  float bv[8][4];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    wf[nb] = *reinterpret_cast<const half8*>(w32 + (nb * 16 + px) * 32 + g * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[nb][i] = bias ? (float)bias[nb * 16 + 4 * g + i] : 0.0f;
+  }
+  // halo patch: 324 pixels, 3 halves each (zero outside the image)
+  for (int p = tid; p < kHalo * kHalo; p += 256) {
+    const int r = p / kHalo, c = p - r * kHalo;
+    const int yy = ty0 + r - 1, xx = tx0 + c - 1;
+    half4s q = {0, 0, 0, 0};
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) q = *reinterpret_cast<const half4s*>(x + (((long long)b * H + yy) * W + xx) * ldx);
+    _Float16* d = patch + r * kC3Row + c * 3;
+    d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+  }
+  if (tid < 8) patch[kC3Zero + tid] = (_Float16)0.0f;
+  // where element e of this lane's operand (k = 8 g + e) sits relative to the patch row of the output pixel's row
+  int koff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * g + e, ky = k / 9, j = k - 9 * ky;
+    koff[e] = k < 27 ? ky * kC3Row + px * 3 + j : -1;
+  }
+  __syncthreads();
+
+  float cs[8][4], cq[8][4];
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[nb][i] = cq[nb][i] = 0.0f;
+  _Float16* const stg = stage[wave];
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+    const int y = wave * 4 + r;                            // tile row = the 16 pixels of this MFMA
+    half8 xf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xf[e] = patch[koff[e] >= 0 ? koff[e] + y * kC3Row : kC3Zero];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const float4v acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nb], xf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+      half4v o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = (_Float16)(acc[i] + bv[nb][i]);
+        const float f = (float)o[i];                       // statistics of the stored (fp16-rounded) tensor
+        cs[nb][i] += f;
+        cq[nb][i] += f * f;
+      }
+      *reinterpret_cast<half4v*>(stg + px * kC3Stage + nb * 16 + 4 * g) = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // 16 pixels x 256 bytes: lane -> (pixel 4 it + (lane >> 4), 16-byte chunk lane & 15): every store instruction covers four full rows
+    _Float16* const orow = out + (((long long)b * H + ty0 + y) * W + tx0) * ldo;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int pr = it * 4 + g;
+      *reinterpret_cast<half8*>(orow + (long long)pr * ldo + px * 8) = *reinterpret_cast<const half8*>(stg + pr * kC3Stage + px * 8);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (colstats) {
+    // fold the 16 pixel lanes of a row group (DPP row rotations inside 16 lanes, fixed order), then the four waves through LDS
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cs[nb][i] = row_sum16(cs[nb][i]);
+        cq[nb][i] = row_sum16(cq[nb][i]);
+        if (px == 0) {
+          wsum[wave][0][nb * 16 + 4 * g + i] = cs[nb][i];
+          wsum[wave][1][nb * 16 + 4 * g + i] = cq[nb][i];
+        }
+      }
+    __syncthreads();
+    const int which = tid >> 7, c = tid & 127;             // 256 threads = [sum | sumsq][128 channels], waves added in wave order
+    const float rsum = ((wsum[0][which][c] + wsum[1][which][c]) + wsum[2][which][c]) + wsum[3][which][c];
+    const long long slot_id = ((long long)b * (H / kTile) + blockIdx.y) * (W / kTile) + blockIdx.x;
+    colstats[(slot_id * 2 + which) * 128 + c] = rsum;
+  }
+}
+
 }  // namespace sc
 }  // namespace sd
 
@@ -226,4 +343,24 @@ extern "C" int sd_im2col3x3_c3_f16(const void* x, int ldx, int batch, int h, int
   hipLaunchKernelGGL(im2col3x3_c3_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, ldx, batch, h, w_,
                      (_Float16*)out);
   return check_launch("im2col3x3_c3_kernel");
+}
+
+extern "C" int sd_conv3x3_c3_f16(const void* x, int ldx, const void* w32, const void* bias, int batch, int h, int w_, int n, void* out, int ldo,
+                                 float* colstats, void* stream) {
+  using namespace sd::sc;
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_CONV_C3;
+    r.p[0] = (void*)x; r.p[1] = (void*)w32; r.p[2] = (void*)bias; r.p[3] = out; r.p[4] = colstats;
+    r.i[0] = ldx; r.i[1] = batch; r.i[2] = h; r.i[3] = w_; r.i[4] = n; r.i[5] = ldo;
+    return sd::plan_record(r);
+  }
+  if (!x || !w32 || !out) return fail(COMA_E_INVALID, "sd_conv3x3_c3_f16: null pointer");
+  if (n != 128) return fail(COMA_E_INVALID, "sd_conv3x3_c3_f16: n = %d (built for 128 output channels)", n);
+  if (ldx < 4 || ldx % 4 || batch <= 0 || batch > 65535 || h <= 0 || w_ <= 0 || h % kTile || w_ % kTile || ldo < n || ldo % 8)
+    return fail(COMA_E_INVALID, "sd_conv3x3_c3_f16: bad shape ldx=%d batch=%d h=%d w=%d ldo=%d (h, w multiples of 16; ldx %% 4 == 0; ldo %% 8 == 0)", ldx, batch, h, w_, ldo);
+  dim3 grid((unsigned)(w_ / kTile), (unsigned)(h / kTile), (unsigned)batch);
+  hipLaunchKernelGGL(conv3x3_c3_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, ldx, (const _Float16*)w32, (const _Float16*)bias, h, w_,
+                     (_Float16*)out, ldo, colstats);
+  return check_launch("conv3x3_c3_kernel");
 }

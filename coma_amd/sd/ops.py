@@ -304,3 +304,12 @@ def im2col3x3_c3(x, out, *, batch, h, w, ldx):
     """out[m][3 * tap + ch] = the 3x3x3 neighbourhood of pixel m of a 3-channel NHWC image (zero pad; columns 27..31 zero)."""
     _lib.check(_lib.lib().sd_im2col3x3_c3_f16(_p(x, "x"), ldx, batch, h, w, _p(out, "out"), _stream(out)), "sd_im2col3x3_c3_f16")
     return out
+
+
+def conv3x3_c3(x, w32, out, *, batch, h, w, ldx, n=128, bias=None, colstats=None, ldo=0):
+    """3x3 / pad 1 convolution of a 3-channel NHWC image into n = 128 channels in one launch (w32 = [n][ky][kx][c] padded to 32 halfs);
+    colstats fp32 [batch*h*w/256][2][n]: per-tile column sums of the stored output (rows_per_slot = 256 for sd_groupnorm_table_f16)."""
+    rc = _lib.lib().sd_conv3x3_c3_f16(_p(x, "x"), ldx, _p(w32), _p(bias), batch, h, w, n, _p(out, "out"), ldo or out.shape[-1],
+                                      _p(colstats, "colstats", torch.float32), _stream(out))
+    _lib.check(rc, "sd_conv3x3_c3_f16")
+    return out

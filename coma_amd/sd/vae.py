@@ -21,6 +21,7 @@ class _Cfg(dict):
 
 class _VaeBase:
     upsample_phases = True       # class-level switch (tests / A-B): False = Upsample2D convolutions as 3x3 over the upsampled tensor
+    direct_conv_in = True        # class-level switch (tests / A-B): False = im2col pass + K = 32 product (packed_conv_in) for the encoder's conv_in
     packed_conv_in = True        # class-level switch (tests / A-B): False = encoder conv_in as a K = 576 implicit GEMM over the 64-channel padded input
     fused_conv_out = True        # class-level switch (tests / A-B): False = GroupNorm kernel + 64-column implicit-GEMM tile for conv_out
     halo_conv = True             # class-level switch (tests / A-B): False = GroupNorm kernel + implicit GEMM for the 128-channel 3x3 convolutions
@@ -177,7 +178,16 @@ class HipVaeEncoder(_VaeBase):
         H, W = height, width
         self.x = g.buf(B, H * W, 64, zero=True)
         x = g.buf(B * H * W, ch[0])
-        if self.packed_conv_in and s["encoder.conv_in.weight"].shape[1] == 3:
+        if self.direct_conv_in and s["encoder.conv_in.weight"].shape[1] == 3 and ch[0] == 128 and H % 16 == 0 and W % 16 == 0:
+            # 3 -> 128 channels in one launch: the halo patch of a 16 x 16 tile in LDS, K = 32 operands built there, per-tile column sums for the
+            # first ResNet's GroupNorm table (sd_conv3x3_c3_f16)
+            w27 = torch.nn.functional.pad(conv_weight(s["encoder.conv_in.weight"]), (0, 5)).contiguous()       # [n][ky][kx][c] -> [n][32]
+            cs = g.buf(B * H * W // 256, 2, ch[0], dtype=torch.float32, zero=True)
+            g._colstats_tile[x.data_ptr()] = cs
+            g.add(lambda h0=H, w0=W, xo=x: ops.conv3x3_c3(self.x, w27, xo, batch=B, h=h0, w=w0, ldx=64, n=ch[0], bias=s["encoder.conv_in.bias"], colstats=cs),     # (x, H, W are rebound below)
+                  flops=2 * B * H * W * ch[0] * 32, alg_flops=2 * B * H * W * ch[0] * 27, tag=f"conv3x3(c3) B={B} {H}x{W} n={ch[0]}",
+                  nbytes=2 * B * H * W * (4 + ch[0]))
+        elif self.packed_conv_in and s["encoder.conv_in.weight"].shape[1] == 3:
             # 3 input channels: one elementwise pass packs every pixel's 3x3x3 neighbourhood into 32 halfs and conv_in is a plain K = 32 product
             # (the implicit GEMM multiplied a 64-channel padded input: K = 576 for 27 real products)
             xp = g.buf(B * H * W, 32)

@@ -252,6 +252,17 @@ int sd_conv3x3_small_n_f16(const void* x, const float* gn_affine, int silu, cons
  * replaces: the im2col half of encoder.conv_in of AutoencoderKL (self.vae.encode, utils/adaptive_mask_inpainting.py:677-680). */
 int sd_im2col3x3_c3_f16(const void* x, int ldx, int batch, int h, int w_, void* out, void* stream);
 
+/* The whole 3-input-channel convolution in one launch (r5): out[m][n] = bias[n] + sum_k w32[n][k] * x[pixel m shifted by tap][ch], k = 3 * tap + ch, for
+ * n = 128 output channels, h and w multiples of 16.  x fp16 NHWC [batch, h, w, ldx] (channels 0..2 read, ldx % 4 == 0); w32 fp16 [128][32] =
+ * [n][ky][kx][c] padded with 5 zeros (the layout the K = 32 product above takes); bias fp16 [128] or NULL; out fp16 [batch*h*w][ldo], ldo % 8 == 0.
+ * colstats (or NULL): fp32 [batch*h*w/256][2][128], the column sums / sums of squares of the stored output per 16 x 16 pixel tile -- the slot layout
+ * of sd_conv3x3_halo_f16, read by sd_groupnorm_table_f16 with rows_per_slot = 256.  Same products as im2col + K = 32 GEMM (fp32 accumulation in the
+ * MFMA, another summation order); the packed [batch*h*w][32] matrix is never written.  Recordable.
+ * replaces: encoder.conv_in of AutoencoderKL (self.vae.encode, utils/adaptive_mask_inpainting.py:677-680) + the statistics pass of the first
+ *           ResNet block's GroupNorm. */
+int sd_conv3x3_c3_f16(const void* x, int ldx, const void* w32, const void* bias, int batch, int h, int w_, int n, void* out, int ldo,
+                      float* colstats, void* stream);
+
 /* Row softmax in place over fp16 [rows, n] with scale (VAE mid-block attention, un-fused). */
 int sd_softmax_f16(void* x, int64_t rows, int n, int ld, float scale, void* stream);
 

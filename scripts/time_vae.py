@@ -14,6 +14,8 @@ if "--halo128" in sys.argv:
     vae_mod._VaeBase.halo_widths = (128,)             # A/B: halo convolutions only for 128 output channels
 if "--halo256" in sys.argv:
     vae_mod._VaeBase.halo_widths = (128, 256)
+if "--packed-conv-in" in sys.argv:
+    vae_mod._VaeBase.direct_conv_in = False           # A/B: im2col pass + K = 32 product for the encoder's conv_in
 if "--no-halo" in sys.argv:
     vae_mod._VaeBase.halo_conv = False
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8

@@ -914,6 +914,39 @@ def test_conv3x3_with_three_input_channels_as_a_packed_k32_product(ops, B, H, W,
     close(out, ref)
 
 
+@pytest.mark.parametrize("B,H,W,ldx,ldo", [(2, 16, 48, 64, 128), (1, 64, 32, 4, 136), (3, 16, 16, 8, 128)])
+def test_conv3x3_with_three_input_channels_in_one_launch(ops, B, H, W, ldx, ldo):
+    """sd_conv3x3_c3_f16 (halo patch in LDS, K = 32 operands built there, no packed copy) against conv2d in fp32 and against the im2col + K = 32
+    product it replaces (same products, another fp32 summation order: a few fp16 ulps); its per-tile column sums are the sums of the STORED
+    values, slot = 16 x 16 tile in (sample, tile row, tile column) order.  Image edges on every side, ldx / ldo strides, channels >= 3 ignored."""
+    M, n = B * H * W, 128
+    x = torch.zeros(M, ldx, dtype=F16)
+    x[:, :3] = rnd(M, 3, seed=1)
+    x[:, 3:] = 9.0
+    w = rnd(n, 3, 3, 3, seed=2, scale=27 ** -0.5)
+    b = rnd(n, seed=3)
+    w27 = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(n, 27), (0, 5)).contiguous().to(DEV)
+    out = torch.full((M, ldo), 7.0, dtype=F16, device=DEV)
+    cs = torch.zeros(M // 256, 2, n, dtype=torch.float32, device=DEV)
+    ops.conv3x3_c3(x.to(DEV), w27, out, batch=B, h=H, w=W, ldx=ldx, bias=b.to(DEV), colstats=cs, ldo=ldo)
+    img = x[:, :3].float().reshape(B, H, W, 3)
+    ref = torch.nn.functional.conv2d(img.permute(0, 3, 1, 2), w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(M, n)
+    close(out[:, :n], ref)
+    assert float((out[:, n:].float() - 7.0).abs().max().item() if ldo > n else 0.0) == 0.0         # nothing written past n
+    xs = torch.zeros(M, 64, dtype=F16); xs[:, :3] = x[:, :3]
+    xp = torch.empty(M, 32, dtype=F16, device=DEV)
+    ops.im2col3x3_c3(xs.to(DEV), xp, batch=B, h=H, w=W, ldx=64)
+    out2 = torch.empty(M, n, dtype=F16, device=DEV)
+    ops.conv_gemm(xp, w27, out2, batch=M, in_h=1, in_w=1, c0=32, n=n, bias=b.to(DEV))
+    d = (out[:, :n].float() - out2.float()).abs().max().item()
+    assert d <= 4e-3 * ref.abs().max().item(), d
+    st = out[:, :n].float().cpu().reshape(B, H // 16, 16, W // 16, 16, n).permute(0, 1, 3, 2, 4, 5).reshape(-1, 256, n)
+    got = cs.cpu()
+    assert torch.allclose(got[:, 0], st.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(got[:, 1], (st * st).sum(1), rtol=1e-5, atol=1e-3)
+    with pytest.raises(Exception, match="multiples of 16"):
+        ops.conv3x3_c3(x.to(DEV), w27, out, batch=B, h=H - 8, w=W, ldx=ldx, bias=b.to(DEV), ldo=ldo)
+
+
 @pytest.mark.parametrize("B,H,W,C,n,stats", [(2, 8, 8, 64, 64, False), (2, 16, 32, 128, 320, True), (1, 32, 16, 64, 128, True), (3, 4, 4, 64, 64, False),
                                              (16, 32, 32, 640, 640, True)])
 def test_upsample_conv_as_four_subpixel_phases(ops, B, H, W, C, n, stats):

@@ -68,6 +68,7 @@ def test_decoder_512_matches_fp32_reference(vae512):
     # the 128-channel layers of the 512 x 512 level run as halo-patch convolutions with the GroupNorm folded in (sd_conv3x3_halo_f16)
     # (and the 256-channel ones of the 256 x 256 level, two workgroups per tile)
     assert sum("conv3x3(halo)" in tag for tag, _ in vae.dec.g.tags) == 12 and sum("conv3x3(halo)" in tag for tag, _ in vae.enc.g.tags) == 8
+    assert sum("conv3x3(c3)" in tag for tag, _ in vae.enc.g.tags) == 1 and not any("im2col" in tag for tag, _ in vae.enc.g.tags)    # conv_in: one launch
     z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(5)).half().float()
     out = vae.decode(z.to(DEV), return_dict=False)[0]
     assert tuple(out.shape) == (1, 3, 512, 512)
