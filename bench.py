@@ -416,7 +416,7 @@ def bench_occupancy(args, dev, world, rank):
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
 #   profiles/r05_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
-#   profiles/r05_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91584e6 KiB, WRITE_SIZE 3.71089e6 KiB per launch
+#   profiles/r05_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91569e6 KiB, WRITE_SIZE 3.71278e6 KiB per launch
 #   profiles/r05_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.124 GB, rowprep 2 * 0.209 + 0.232 GB,
 #                                        groupmax 0.04 GB
 UNET_GEMM_PMC_TRAFFIC_BYTES = int(158.17e6)
@@ -424,7 +424,7 @@ OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.96e9)   # fused 11.02 + 0.25, rowprep 0.42 
 OCCUPANCY_PMC_SOURCE = ("profiles/r05_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
                         "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "
                         "the grid written once + the incidences; the 4 GB 'samples re-read per slab' term of the structure-B formula never reaches HBM")
-CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91584e6 + 3.71089e6) * 1024)
+CONTACT_PMC_TRAFFIC_BYTES = int((2 * 1.91569e6 + 3.71278e6) * 1024)
 
 
 def main():
