@@ -230,24 +230,38 @@ def test_winograd_and_small_n_records_survive_save_and_load(tmp_path, hip_lib):
     wh, bh = r(n, 9 * n, k=(9 * n) ** -0.5), r(n)
     g.gn_silu_conv3x3_halo(out, ga2, be2, wh, bh, out2, batch=B, h=H, w_=W, c=n, n=n, eps=1e-6, res=out, stats=True)
     g.gn_silu_conv3x3_small_n(out2, ga2, be2, w3, b3, img, batch=B, h=H, w_=W, c=n, n=3, eps=1e-6)
+    # r5: ... -> [3 -> 128 channel convolution in one launch, leaving per-tile column sums] (sd_conv3x3_c3_f16)
+    from coma_amd.sd import ops
+    w27, bc = r(128, 32, k=27 ** -0.5), r(128)
+    w27[:, 27:] = 0
+    y, csy = g.buf(B * H * W, 128), g.buf(B * H * W // 256, 2, 128, dtype=torch.float32, zero=True)
+    g.add(lambda: ops.conv3x3_c3(img, w27, y, batch=B, h=H, w=W, ldx=64, bias=bc, colstats=csy), tag="conv3x3(c3)")
     g.model.bind("x", x)
     g.model.bind("img", img)
+    g.model.bind("y", y)
+    g.model.bind("csy", csy)
     xin = r(B * H * W, C)
     x.copy_(xin)
     g.replay()                                               # records, runs eagerly, builds the hipGraph
     g.replay()                                               # graph launch
     torch.cuda.synchronize()
-    want = img.clone()
+    want, want_y, want_cs = img.clone(), y.clone(), csy.clone()
     assert float(want[:, :3].float().abs().max()) > 0 and float(want[:, 3:].float().abs().max()) == 0.0
+    assert float(want_y.float().abs().max()) > 0 and float(want_cs.abs().max()) > 0
     path = tmp_path / "w.sdm"
     g.model.save(path)
     m2 = SdModel.load(path, DEV)
-    assert m2.num_launches("p") == g.model.num_launches("p") >= 7
+    assert m2.num_launches("p") == g.model.num_launches("p") >= 8
     px, nx = m2.binding("x")
     pi, ni = m2.binding("img")
     _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(px), ctypes.c_void_p(xin.data_ptr()), nx, _lib.stream_ptr(xin.device)), "copy")
     m2.replay("p")
     got = torch.empty_like(want)
     _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(got.data_ptr()), ctypes.c_void_p(pi), ni, _lib.stream_ptr(got.device)), "copy")
+    got_y, got_cs = torch.empty_like(want_y), torch.empty_like(want_cs)
+    for name, dst in (("y", got_y), ("csy", got_cs)):
+        pp, nn = m2.binding(name)
+        assert nn == dst.numel() * dst.element_size()
+        _lib.check(_lib.lib().sd_copy_d2d(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(pp), nn, _lib.stream_ptr(dst.device)), "copy")
     torch.cuda.synchronize()
-    assert torch.equal(got, want)
+    assert torch.equal(got, want) and torch.equal(got_y, want_y) and torch.equal(got_cs, want_cs)
