@@ -1,5 +1,8 @@
-// sd_haloconv.hip -- GroupNorm affine + SiLU + 3x3 / stride 1 / pad 1 convolution with 128 OUTPUT channels as a halo-patch ("direct")
-// convolution on gfx950: the 128-channel layers of the VAE at 512 x 512 (decoder up_blocks.3, encoder down_blocks.0;
+// sd_haloconv.hip -- GroupNorm affine + SiLU + 3x3 / stride 1 / pad 1 convolution as a halo-patch ("direct") convolution on gfx950, in
+// slices of 128 OUTPUT channels.  Shipped envelope: n in {128, 256, 384, 512} as n / 128 workgroups per 16 x 16 tile (each re-fetches the
+// patch, which stays in L2), c a multiple of 64 up to 512, h and w multiples of 16, one input sample below 2 GiB (32-bit byte offsets
+// against a 0x7fffffff-byte buffer resource; refused otherwise -- the callers fall back to the implicit GEMM).  The description below is
+// of one 128-channel slice.  First users: the ResNet layers of the VAE at 512 x 512 (decoder up_blocks.3, encoder down_blocks.0;
 // self.vae.decode / self.vae.encode, utils/adaptive_mask_inpainting.py:1086, :1112, :677-680).
 //
 // Why not the implicit GEMM (sd_gemm.hip): with N = 128 every activation row is re-staged through L2 -> LDS nine times (once per tap)
@@ -422,6 +425,9 @@ extern "C" int sd_conv3x3_halo_f16(const void* x, int c, const float* gn_affine,
   if (ldr == 0) ldr = n;
   if (ldo < n || ldo % 8 || (res && (ldr < n || ldr % 8))) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: ldo = %d, ldr = %d", ldo, ldr);
   if ((long long)n * 9 * c * 2 >= 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: weights too large");
+  // the kernel addresses one sample of x with a 32-bit byte offset against a 0x7fffffff-byte buffer resource: refuse what it cannot reach
+  if ((long long)h * w_ * c * 2 >= 0x7fffffffLL)
+    return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: one input sample is %lld bytes (must stay below 2 GiB)", (long long)h * w_ * c * 2);
   const long long tiles = (long long)batch * (h / kTile) * (w_ / kTile);
   if (tiles > 0x7fffffffLL) return fail(COMA_E_INVALID, "sd_conv3x3_halo_f16: grid too large");
   HaloArgs a;

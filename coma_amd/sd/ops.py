@@ -283,7 +283,8 @@ def conv3x3_small_n(x, w, out, *, batch, h, w_, c, n, bias=None, gn_affine=None,
 
 
 def conv3x3_halo(x, w, out, *, batch, h, w_, c, n=128, bias=None, res=None, gn_affine=None, silu=False, colstats=None, ldo=0, ldr=0):
-    """out[:, 0:128] = conv3x3(act(x * scale + shift)) + bias (+ res): halo-patch convolution with 128 output channels (sd_haloconv.hip)."""
+    """out[:, 0:n] = conv3x3(act(x * scale + shift)) + bias (+ res): halo-patch convolution (sd_haloconv.hip); n in {128, 256, 384, 512},
+    c % 64 == 0 and c <= 512, h and w multiples of 16, one input sample below 2 GiB (refused otherwise)."""
     rc = _lib.lib().sd_conv3x3_halo_f16(_p(x, "x"), c, _p(gn_affine, "gn_affine", torch.float32), 1 if silu else 0, _p(w, "w"), _p(bias, "bias"),
                                         _p(res, "res"), ldr, batch, h, w_, n, _p(out, "out"), ldo, _p(colstats, "colstats", torch.float32),
                                         _stream(out))

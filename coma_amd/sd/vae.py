@@ -38,10 +38,11 @@ class _VaeBase:
         self.g = LaunchGraph(self.device, plan=plan)
 
     def _halo(self, cin, cout, H, W):
-        """GroupNorm + SiLU + conv3x3 as ONE halo-patch convolution (sd_conv3x3_halo_f16) where it was built and measured: 128 output
-        channels, at most 256 input channels, feature maps in whole 16 x 16 tiles that fill the chip (the 512 x 512 level of the VAE)."""
+        """GroupNorm + SiLU + conv3x3 as ONE halo-patch convolution (sd_conv3x3_halo_f16) where it was built and measured: 128 / 256 /
+        512 output channels (n / 128 workgroups per tile), input channels a multiple of 64 up to 512, one input sample below 2 GiB (the
+        kernel's 32-bit offsets), feature maps in whole 16 x 16 tiles, at least halo_min_tiles workgroups (two per CU)."""
         return (self.halo_conv and cout in self.halo_widths and cin % 64 == 0 and cin <= 512 and H % 16 == 0 and W % 16 == 0
-                and self.batch * (H // 16) * (W // 16) * (cout // 128) >= self.halo_min_tiles)
+                and H * W * cin * 2 < 0x7fffffff and self.batch * (H // 16) * (W // 16) * (cout // 128) >= self.halo_min_tiles)
 
     def _resnet(self, p, x, cin, cout, H, W):
         g, s, B = self.g, self.s, self.batch

@@ -59,6 +59,57 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
+def g20_dilation():
+    """G20: the mask-dilation branch of adapt_mask (utils/adaptive_mask_inpainting.py:1123-1157) -- `cv2.dilate(mask, ones((3,3)),
+    iterations=k)` AND default mask, or the default mask when `mask.sum() < 512 * 512 * thres`.  cv2 is absent from this image, so the
+    expected masks come from an implementation INDEPENDENT of the build's own restatement (oracle/sd_oracle.py uses grey_dilation):
+    scipy.ndimage.binary_dilation(structure=ones((3,3)), iterations=k, border_value=0), cross-checked here against a shifted-OR in
+    plain NumPy.  Still not cv2: what cv2.dilate does with a 3x3 all-ones kernel, default anchor and default border (the border value
+    never wins a max) is restated, not run.  Masks are stored bit-packed."""
+    from scipy.ndimage import binary_dilation
+
+    def shifted_or(m, k):
+        m = m.astype(bool)
+        for _ in range(k):
+            p = np.pad(m, 1)
+            acc = np.zeros_like(m)
+            for dy in range(3):
+                for dx in range(3):
+                    acc |= p[dy:dy + m.shape[0], dx:dx + m.shape[1]]
+            m = acc
+        return m
+
+    rng = np.random.default_rng(20)
+    H = W = 512
+    yy, xx = np.mgrid[0:H, 0:W]
+    segs = []
+    s = np.zeros((H, W), bool)                                   # 0: blobs touching all four borders and a corner + an interior ellipse
+    s[0:3, 100:140] = s[H - 2:H, 300:360] = s[200:260, 0:2] = s[50:90, W - 1:W] = s[H - 1, W - 1] = s[0, 0] = True
+    s |= ((yy - 256) / 90.0) ** 2 + ((xx - 250) / 40.0) ** 2 <= 1.0
+    segs.append(s)
+    segs.append(rng.random((H, W)) > 0.995)                      # 1: salt noise (every pixel grows its own square)
+    s = np.zeros((H, W), bool)                                   # 2: a small blob: area 600 < 512 * 512 * 0.005 -> the default-mask branch
+    s[300:320, 100:130] = True
+    segs.append(s)
+    s = (((yy - 200) / 120.0) ** 2 + ((xx - 300) / 70.0) ** 2 <= 1.0) & (rng.random((H, W)) > 0.3)      # 3: a ragged person-sized blob
+    segs.append(s)
+    segs = np.stack(segs)
+    default = np.zeros((H, W), bool)                             # the candidate-box default mask of the harness, off-centre, touching one border
+    default[96:512, 140:420] = True
+    ks, thres = [0, 1, 5, 20], 0.005
+    out = {"g20_segs": np.packbits(segs, axis=-1), "g20_default": np.packbits(default, axis=-1), "g20_ks": np.array(ks), "g20_thres": np.array(thres)}
+    exp, dil = [], []
+    for s in segs:
+        for k in ks:
+            d = binary_dilation(s, structure=np.ones((3, 3), bool), iterations=k, border_value=0) if k > 0 else s.copy()
+            assert np.array_equal(d, shifted_or(s, k)), "scipy.ndimage.binary_dilation and the shifted-OR disagree"
+            dil.append(d)
+            exp.append(default.copy() if s.sum() < 512 * 512 * thres else (d & default))
+    out["g20_dilated"] = np.packbits(np.stack(dil).reshape(len(segs), len(ks), H, W), axis=-1)
+    out["g20_adapted"] = np.packbits(np.stack(exp).reshape(len(segs), len(ks), H, W), axis=-1)
+    return out
+
+
 def main():
     sys.meta_path.insert(0, _Finder())
     root = os.path.dirname(os.path.dirname(HERE))
@@ -161,6 +212,7 @@ def main():
         out[f"g19_{tag}_masks"], out[f"g19_{tag}_assets"], out[f"g19_{tag}_kinds"] = np.stack(masks), np.stack(assets), np.array(kinds)
         if hasattr(pred, "initial_human_bbox") and pred.initial_human_bbox is not None:
             out[f"g19_{tag}_final_bbox"] = np.asarray(pred.initial_human_bbox)
+    out.update(g20_dilation())
     np.savez_compressed(os.path.join(HERE, "inpaint_golden.npz"), **out)
     print("wrote inpaint_golden.npz", {k: getattr(v, "shape", None) for k, v in out.items()}, errs)
 

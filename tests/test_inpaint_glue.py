@@ -262,3 +262,25 @@ def test_synthetic_plug_in_batched_form_equals_the_per_image_form():
         one_n = p(imgs[b].numpy())["mask"]
         assert torch.equal(batch[b], one_t) and np.array_equal(batch[b].numpy(), one_n)
     assert 0 < int(batch[0].sum()) < 64 * 48
+
+
+def _g20(gi):
+    unpack = lambda a: np.unpackbits(a, axis=-1).astype(bool)
+    return unpack(gi["g20_segs"]), unpack(gi["g20_default"]), [int(k) for k in gi["g20_ks"]], float(gi["g20_thres"]), unpack(gi["g20_dilated"]), \
+        unpack(gi["g20_adapted"])
+
+
+def test_mask_dilation_restatement_matches_independent_implementation(gi):
+    """G20: the oracle's restatement of `cv2.dilate(mask, ones((3,3)), iterations=k)` AND default mask / area fallback
+    (utils/adaptive_mask_inpainting.py:1123-1157) against masks produced by scipy.ndimage.binary_dilation (cross-checked with a plain NumPy
+    shifted-OR by the generator): blobs on every border and corner, salt noise, the area-below-threshold branch, k in {0, 1, 5, 20} at
+    512 x 512.  Checked against scipy, still not against cv2 (absent)."""
+    from oracle import sd_oracle as so
+    segs, default, ks, thres, dilated, adapted = _g20(gi)
+    assert segs.shape == (4, 512, 512) and segs[2].sum() < 512 * 512 * thres <= segs[3].sum()       # both branches of :1132 are present
+    for s in range(len(segs)):
+        for j, k in enumerate(ks):
+            assert np.array_equal(so.dilate_ref(segs[s].astype(np.uint8), k).astype(bool), dilated[s, j]), (s, k)
+            got = so.adapt_mask_ref(segs[s].astype(np.uint8), default.astype(np.uint8), k, False, thres)
+            assert np.array_equal(got.astype(bool), adapted[s, j]), (s, k)
+    assert np.array_equal(adapted[2, 3], default) and not np.array_equal(adapted[0, 3], default)

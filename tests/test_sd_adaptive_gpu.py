@@ -169,3 +169,31 @@ def test_batched_mask_adapt_matches_numpy(hip_lib):
             exp = np.where(ref[None] > 0, 0.0, img[b]).transpose(1, 2, 0)
             assert np.array_equal(m[:, :, :3], exp.astype(np.float16).astype(np.float32))
             assert float(np.abs(m[:, :, 3:8]).max()) == 0.0 and (m[:, :, 8:] == 7.0).all()     # write_pad=0 leaves channels >= 8 alone
+
+
+def test_batched_mask_adapt_matches_g20(hip_lib):
+    """sd_mask_adapt_batched at 512 x 512 against G20 (tests/golden/make_golden_inpaint.py: scipy.ndimage.binary_dilation, independent of
+    the oracle's own dilation): the four segmentations as one batch of 4, k in {0, 1, 5, 20}, area threshold 512 * 512 * 0.005 decided on
+    the device -- full-resolution masks bit-equal, latent masks = their nearest 8 x down-sampling."""
+    import os
+    from coma_amd.sd import ops
+    gi = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inpaint_golden.npz"))
+    unpack = lambda a: np.unpackbits(a, axis=-1)
+    segs, default, ks, thres = unpack(gi["g20_segs"]), unpack(gi["g20_default"]), [int(k) for k in gi["g20_ks"]], float(gi["g20_thres"])
+    adapted = unpack(gi["g20_adapted"])
+    B, H, W = segs.shape
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    img = torch.zeros(B, 3, H, W, dtype=torch.float32, device=DEV)
+    dflt = d(np.broadcast_to(default, (B, H, W)))
+    for j, k in enumerate(ks):
+        mask_full = torch.empty(B, H, W, dtype=torch.uint8, device=DEV)
+        mask_lat = torch.empty(B, H // 8 * W // 8, dtype=torch.float16, device=DEV)
+        masked = torch.zeros(B * H * W, 64, dtype=torch.float16, device=DEV)
+        area = torch.empty(B, dtype=torch.int32, device=DEV)
+        scratch = torch.empty(B, H, W, dtype=torch.uint8, device=DEV)
+        ops.mask_adapt_batched(d(segs), dflt, img, mask_full, mask_lat, masked, area, scratch, batch=B, H=H, W=W, dilate_iters=k,
+                               force_default=False, area_thres=512 * 512 * thres, cpad=64)
+        assert area.tolist() == segs.reshape(B, -1).sum(-1).tolist()
+        for b in range(B):
+            assert np.array_equal(mask_full[b].cpu().numpy(), adapted[b, j]), (b, k)
+            assert np.array_equal(mask_lat[b].float().cpu().numpy().reshape(H // 8, W // 8), adapted[b, j][::8, ::8].astype(np.float32)), (b, k)

@@ -85,8 +85,41 @@ def test_encoder_512_matches_fp32_reference(vae512):
     assert rel <= REL_L2 and cos >= COS, (rel, cos)
 
 
+@pytest.fixture(scope="module")
+def fp32_strict():
+    old = torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cudnn.allow_tf32 = torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+    torch.backends.cudnn.allow_tf32, torch.backends.cuda.matmul.allow_tf32 = old
+
+
+def test_batch_8_decoder_and_encoder_match_fp32_reference(hip_lib, fp32_strict):
+    """The BENCHMARKED dispatch (batch 8 at 512 x 512: the 8-wave wide-head mid-block attention with 128 queries per workgroup, n / 128 halo
+    workgroups per tile at every level that fills the chip, the 256 x 256 GEMM tiles) at model level: images 0 and 7 of a batch of 8 distinct
+    inputs against vae_decode_ref / vae_encode_ref (utils/adaptive_mask_inpainting.py:1111-1115, :675-684), the restatement evaluated by
+    torch's fp32 device kernels one image at a time (the images of a batch are independent).  Same bars as batch 1."""
+    from coma_amd.sd import weights
+    from coma_amd.sd.vae import HipAutoencoderKL
+    state = weights.random_state(weights.vae_shapes(), seed=3)
+    cfg = weights.VAE_CFG
+    vae = HipAutoencoderKL(state, batch=8, height=512, width=512, device=DEV)
+    assert any("attention(wide)" in tag for tag, _ in vae.dec.g.tags) and sum("conv3x3(halo)" in tag for tag, _ in vae.dec.g.tags) >= 12
+    dstate = {k: v.to(DEV) for k, v in state.items()}
+    z = torch.randn(8, 4, 64, 64, generator=torch.Generator().manual_seed(15)).half().float()
+    out = vae.decode(z.to(DEV), return_dict=False)[0].clone()
+    assert tuple(out.shape) == (8, 3, 512, 512)
+    img = (torch.rand(8, 3, 512, 512, generator=torch.Generator().manual_seed(16)) * 2 - 1).half().float()
+    mode = vae.encode(img.to(DEV)).latent_dist.mode().clone()
+    for b in (0, 7):
+        rel, cos = _metrics(out[b:b + 1], so.vae_decode_ref(dstate, z[b:b + 1].to(DEV), cfg))
+        assert rel <= REL_L2 and cos >= COS, ("decode", b, rel, cos)
+        rel, cos = _metrics(mode[b:b + 1], so.vae_encode_ref(dstate, img[b:b + 1].to(DEV), cfg)[:, :4])
+        assert rel <= REL_L2 and cos >= COS, ("encode", b, rel, cos)
+    assert float((out[0] - out[7]).abs().max()) > 0.1                 # distinct images came out distinct
+
+
 def test_halo_convolutions_agree_with_the_groupnorm_plus_gemm_graph(vae512):
-    """The r5 decoder / encoder (every ResNet convolution a halo-patch convolution with the GroupNorm + SiLU applied on the way into LDS) against
+    """The r5 decoder / encoder (every ResNet convolution that fills the chip a halo-patch convolution with the GroupNorm + SiLU applied on the way into LDS) against
     the SAME networks built the r4 way (GroupNorm kernel -> implicit GEMM): two launch lists computing the same products with the same
     fp16 storage points up to accumulation order: each is 1.3e-3 ... 1.5e-3 from the fp32 restatement, and they are 0.8e-3 (decoder) / 1.7e-3
     (encoder moments) from each other -- bar at 2 x that."""
