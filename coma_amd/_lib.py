@@ -92,6 +92,23 @@ SIGNATURES = {
     "sd_vae_decode": (_i, [_vp, _vp, _vp, _vp]),
     "sd_vae_encode": (_i, [_vp, _vp, _vp, _vp]),
     "sd_mask_adapt_batched": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    # include/seg_hip.h
+    "seg_conv_gemm_f32": (_i, [_vp, _vp]),
+    "seg_resize_normalize_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "seg_maxpool3x3s2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "seg_subsample2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "seg_memset": (_i, [_vp, _i, C.c_size_t, _vp]),
+    "seg_rpn_select": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    "seg_sort_candidates": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "seg_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "seg_roi_align_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "seg_box_predict": (_i, [_vp, _i, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "seg_finalize_detections": (_i, [_vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
+    "seg_point_sample_f32": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, C.c_longlong, _vp]),
+    "seg_upsample2x_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "seg_topk_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "seg_point_logit_scatter": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "seg_paste_masks": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 

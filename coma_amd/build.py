@@ -41,6 +41,7 @@ def build_lib(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "coma_hip.h"))
     headers.append(os.path.join(os.path.dirname(HERE), "include", "sd_hip.h"))
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "seg_hip.h"))
     jobs = []
     for src in _sources():
         s = os.path.join(CSRC, src)

@@ -137,6 +137,8 @@ static int launch(const PlanRec& r, void* st) {
       return sd_conv3x3_c3_f16(p[0], (int)i[0], p[1], p[2], (int)i[1], (int)i[2], (int)i[3], (int)i[4], p[3], (int)i[5], (float*)p[4], st);
     case PK_COPY:
       return sd_copy_d2d(p[0], p[1], (size_t)i[0], st);
+    case PK_SEG:
+      return seg_replay(r, st);
     default:
       return fail(COMA_E_INVALID, "sd plan: unknown launch kind %d", r.kind);
   }

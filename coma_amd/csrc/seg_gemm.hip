@@ -1,0 +1,245 @@
+// seg_gemm.hip -- fp32 implicit-GEMM convolution / linear layer on the fp32 MFMA of gfx950 (v_mfma_f32_32x32x2_f32): every
+// convolution and fully connected layer of the person-segmentation network behind PointRendPredictor.__call__
+// (utils/adaptive_mask_inpainting.py:1225-1236 -> detectron2 DefaultPredictor; src/generation/segment_human.py:24-169), which the
+// reference runs in fp32 -- so this path computes in fp32 too: exact-f32 MFMA (a k-ordered fmaf chain, one rounding
+// per product), roofline = the 157.3 TFLOP/s fp32 matrix peak, not the fp16 one.
+//
+//   out[m, n] = act( sum_k A[m, k] * W[n, k] + bias[n] (+ res) ),  m = (b, oy, ox),  k = (ky, kx, c)
+//
+// * A is gathered on the fly from an NHWC fp32 tensor (kh x kw window, stride, zero padding); a linear layer is the 1 x 1 case.
+// * FrozenBatchNorm is folded into W / bias by the host (coma_amd/seg/weights.py), ReLU is an epilogue flag, the bottleneck shortcut
+//   is the residual operand, and FPN's top-down pathway (`lateral + F.interpolate(coarser, 2, "nearest")`) is the residual read at
+//   (oy >> 1, ox >> 1) -- no upsampled tensor is ever written.
+// * rows can be limited by counts that live on the device: the M rows form units of `unit_rows` rows (one per image), and of unit u only
+//   the first m_dev[u] * rows_per_item rows are computed -- the mask heads run on however many detections each image produced without the
+//   host ever learning the number; workgroups with no valid row exit, invalid rows are neither gathered nor stored.
+// Workgroup = 4 waves, tile 128 x 128 (2 x 2 waves, 2 x 2 MFMA tiles each), 128 x 64 or 128 x 32 (4 x 1 waves); K in chunks of 32 through
+// two LDS stages (one barrier per chunk), the next chunk's global loads in flight under this chunk's MFMAs.  Per 8 k values a wave reads
+// ONE ds_read_b128 per operand tile: lanes 0-31 take k = 8g .. 8g+3, lanes 32-63 take k = 8g+4 .. 8g+7, and MFMA step e consumes element e
+// of both (the k order inside a sum is free as long as A and W agree) -- 16 MFMAs (1024 cycles) per 4 LDS reads.
+// Algorithmic bytes per launch: A read once (x taps when the window overlaps is NOT counted: the re-reads hit L2), W once, out once.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "sd_plan.h"
+#include "../../include/seg_hip.h"
+
+namespace seg {
+
+using coma::check_launch;
+using coma::fail;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 32, kLd = kBK + 4;      // LDS row stride in floats (144 B: 16-byte aligned, rows spread over the banks)
+
+struct GemmArgs {
+  const float* x; const float* w; const float* bias; const float* res; float* out; const int* m_dev;
+  int B, H, W, C, ldx, N, Kpad, kh, kw, stride, pad, OH, OW, ldr, res_mode, ldo, relu, rows_per_item, unit_rows;
+  long long M;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int NA = BM / 32, NB = (BN + 31) / 32;       // float4 loads per thread and chunk (A rows / W rows in steps of 32)
+  extern __shared__ float lds[];
+  float* As = lds;                                       // [2][BM][kLd]
+  float* Bs = lds + 2 * BM * kLd;                        // [2][BN][kLd]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const long long Mv = a.M;
+  if (m0 >= Mv) return;
+  auto row_ok = [&](long long m) {
+    if (m >= Mv) return false;
+    if (!a.m_dev) return true;
+    const long long u = m / a.unit_rows;
+    return m - u * a.unit_rows < (long long)a.m_dev[u] * a.rows_per_item;
+  };
+  if (a.m_dev) {                                         // valid rows are a prefix of every unit: does any unit this tile touches have one here?
+    const long long last = (m0 + BM - 1 < Mv ? m0 + BM - 1 : Mv - 1);
+    bool any = false;
+    for (long long u = m0 / a.unit_rows; u <= last / a.unit_rows; ++u) {
+      const long long lo = u * a.unit_rows > m0 ? u * a.unit_rows : m0;
+      any = any || row_ok(lo);
+    }
+    if (!any) return;
+  }
+
+  // ---- per-thread gather geometry: rows r = tid / 8 + 32 j, k offset (tid % 8) * 4 inside a chunk
+  const int lr = tid >> 3, lk = (tid & 7) * 4;
+  long long rbase[NA];                                   // element offset of (b, iy0, ix0) -- may point outside; bounds are checked per tap
+  int riy[NA], rix[NA];
+  const int ohw = a.OH * a.OW;
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const long long m = m0 + lr + 32 * j;
+    if (row_ok(m)) {
+      const int b = (int)(m / ohw), rem = (int)(m - (long long)b * ohw);
+      const int oy = rem / a.OW, ox = rem - oy * a.OW;
+      riy[j] = oy * a.stride - a.pad;
+      rix[j] = ox * a.stride - a.pad;
+      rbase[j] = (long long)b * a.H * a.W;
+    } else {
+      riy[j] = -(1 << 28); rix[j] = 0; rbase[j] = 0;     // never in bounds
+    }
+  }
+  const int ntaps = a.kh * a.kw;
+  const int nk = a.Kpad / kBK;
+
+  float4 ra[NA], rb[NB];
+  auto gload = [&](int kc) {
+    const int k = kc * kBK + lk;
+    const int tap = k / a.C, c = k - tap * a.C;
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    const bool tv = tap < ntaps;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int iy = riy[j] + ky, ix = rix[j] + kx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        v = *reinterpret_cast<const float4*>(a.x + (rbase[j] + (long long)iy * a.W + ix) * a.ldx + c);
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int n = n0 + lr + 32 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lr + 32 * j < BN && n < a.N) v = *reinterpret_cast<const float4*>(a.w + (long long)n * a.Kpad + k);
+      rb[j] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<float4*>(As + (buf * BM + lr + 32 * j) * kLd + lk) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (lr + 32 * j < BN) *reinterpret_cast<float4*>(Bs + (buf * BN + lr + 32 * j) * kLd + lk) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    if (kc + 1 < nk) gload(kc + 1);
+    const float* Ab = As + (buf * BM + wm * TM * 32 + li) * kLd + lh * 4;
+    const float* Bb = Bs + (buf * BN + wn * TN * 32 + li) * kLd + lh * 4;
+#pragma unroll
+    for (int g = 0; g < kBK / 8; ++g) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * kLd + g * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * kLd + g * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kc + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32]
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+      if (col >= a.N) continue;
+      const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + (wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+        if (!row_ok(m)) continue;
+        float v = acc[i][j][r] + bv;
+        if (a.res_mode == 1) {
+          v += a.res[m * a.ldr + col];
+        } else if (a.res_mode == 2) {                    // nearest x2 up-sampling of a [B, OH / 2, OW / 2] tensor
+          const int b = (int)(m / ohw), rem = (int)(m - (long long)b * ohw);
+          const int oy = rem / a.OW, ox = rem - oy * a.OW;
+          v += a.res[(((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + col];
+        }
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        a.out[m * a.ldo + col] = v;
+      }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * kLd * sizeof(float);
+  static coma::LdsOptIn opt;
+  if (lds > 65536)
+    if (int rc = coma::opt_in_lds(opt, (const void*)conv_gemm_f32_kernel<WM, WN, TM, TN>, lds, "seg_conv_gemm_f32")) return rc;
+  const long long gx = (a.M + BM - 1) / BM;
+  const int gy = (a.N + BN - 1) / BN;
+  if (gx > 0x7fffffffLL || gy > 65535) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: grid too large");
+  hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN>), dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, st, a);
+  return check_launch("seg::conv_gemm_f32_kernel");
+}
+
+}  // namespace seg
+
+extern "C" int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream) {
+  using namespace seg;
+  if (!d) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: null descriptor");
+  if (sd::plan_recording()) {
+    sd::PlanRec r{};
+    r.kind = sd::PK_SEG;
+    r.i[0] = SEG_OP_CONV;
+    r.p[0] = (void*)d->x; r.p[1] = (void*)d->w; r.p[2] = (void*)d->bias; r.p[3] = (void*)d->res; r.p[4] = d->out; r.p[5] = (void*)d->m_dev;
+    r.i[1] = d->batch; r.i[2] = d->in_h; r.i[3] = d->in_w; r.i[4] = d->c; r.i[5] = d->ldx; r.i[6] = d->n; r.i[7] = d->kpad; r.i[8] = d->kh;
+    r.i[9] = d->kw; r.i[10] = d->stride; r.i[11] = d->pad; r.i[12] = d->out_h; r.i[13] = d->out_w; r.i[14] = d->ldr; r.i[15] = d->res_mode;
+    r.i[16] = d->ldo; r.i[17] = d->relu; r.i[18] = d->rows_per_item; r.i[19] = d->tile; r.i[20] = d->unit_rows;
+    return sd::plan_record(r);
+  }
+  if (!d->x || !d->w || !d->out) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: null pointer");
+  if (d->batch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->n <= 0)
+    return fail(COMA_E_INVALID, "seg_conv_gemm_f32: batch=%d in=%dx%d out=%dx%d n=%d", d->batch, d->in_h, d->in_w, d->out_h, d->out_w, d->n);
+  if (d->c <= 0 || d->c % 4 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->pad < 0)
+    return fail(COMA_E_INVALID, "seg_conv_gemm_f32: c=%d (a multiple of 4) kh=%d kw=%d stride=%d pad=%d", d->c, d->kh, d->kw, d->stride, d->pad);
+  const int ldx = d->ldx ? d->ldx : d->c;
+  if (ldx < d->c || ldx % 4) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: ldx=%d", ldx);
+  if (d->kpad % 32 || d->kpad < d->kh * d->kw * d->c)
+    return fail(COMA_E_INVALID, "seg_conv_gemm_f32: kpad=%d must be a multiple of 32 covering kh*kw*c=%d", d->kpad, d->kh * d->kw * d->c);
+  if (d->res_mode < 0 || d->res_mode > 2) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: res_mode=%d", d->res_mode);
+  if (d->res_mode && !d->res) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: res_mode=%d without a residual", d->res_mode);
+  if (d->res_mode == 2 && ((d->out_h | d->out_w) & 1)) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: up-sampled residual needs even out_h, out_w");
+  if (d->m_dev && (d->rows_per_item <= 0 || d->unit_rows <= 0))
+    return fail(COMA_E_INVALID, "seg_conv_gemm_f32: rows_per_item=%d unit_rows=%d", d->rows_per_item, d->unit_rows);
+  GemmArgs a;
+  a.x = (const float*)d->x; a.w = (const float*)d->w; a.bias = (const float*)d->bias; a.res = (const float*)d->res; a.out = (float*)d->out;
+  a.m_dev = (const int*)d->m_dev;
+  a.B = d->batch; a.H = d->in_h; a.W = d->in_w; a.C = d->c; a.ldx = ldx; a.N = d->n; a.Kpad = d->kpad; a.kh = d->kh; a.kw = d->kw;
+  a.stride = d->stride; a.pad = d->pad; a.OH = d->out_h; a.OW = d->out_w; a.ldr = d->ldr ? d->ldr : d->n; a.res_mode = d->res_mode;
+  a.ldo = d->ldo ? d->ldo : d->n; a.relu = d->relu; a.rows_per_item = d->rows_per_item; a.unit_rows = d->unit_rows;
+  a.M = (long long)d->batch * d->out_h * d->out_w;
+  if (a.ldo < d->n) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: ldo=%d < n=%d", a.ldo, d->n);
+  hipStream_t st = (hipStream_t)stream;
+  // tile: 0 = by width (n <= 32: 128 x 32, n <= 64: 128 x 64, else 128 x 128); 1 / 2 / 3 force 128 x 128 / 128 x 64 / 128 x 32 (tests)
+  int tile = d->tile;
+  if (tile == 0) tile = d->n <= 32 ? 3 : (d->n <= 64 ? 2 : 1);
+  if (tile == 1) return launch_gemm<2, 2, 2, 2>(a, st);
+  if (tile == 2) return launch_gemm<4, 1, 1, 2>(a, st);
+  if (tile == 3) return launch_gemm<4, 1, 1, 1>(a, st);
+  return fail(COMA_E_INVALID, "seg_conv_gemm_f32: tile=%d", d->tile);
+}

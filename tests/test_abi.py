@@ -15,7 +15,7 @@ def _declared():
         if f.endswith(".h"):
             txt = open(os.path.join(ROOT, "include", f)).read()
             txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-            names += re.findall(r"\b((?:coma|sd)_[a-z0-9_]+)\s*\(", txt)
+            names += re.findall(r"\b((?:coma|sd|seg)_[a-z0-9_]+)\s*\(", txt)
     return sorted(set(names))
 
 
