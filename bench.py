@@ -18,6 +18,8 @@ Further sections on the same line, every rank taking part (only rank 0 prints):
   occupancy        config 5's per-GPU row share (H=1310, R=128, S=2000) through the fused pass + all-reduce(MAX) when N > 1
   adaptive_loop    config 3's shape: the full adaptive-mask loop (49 steps, 21 re-estimations) at batch 8, synthetic mask plug-in
   adaptive_loop_b1 the same, one image per pipeline call (the reference's own call shape)
+  adaptive_loop_pointrend  the same at batch 8 with the PointRend-ARCHITECTURE plug-in on the device (coma_amd/seg, fp32; seeded random weights,
+                   detections forced to ~4 per image) + that network's own forward time and fp32-MFMA roofline fraction
   roofline         conv / linear GEMM family of one UNet forward: algorithmic flops / HIP-event time against the 2.5 PF dense MFMA peak
   cpu_baseline     the oracle restatements timed on the host cores (N = 1 only; bounded samples, stated)
 `--workload contact` swaps primary and secondary.  Rank 0 prints ONE JSON line.
@@ -295,7 +297,62 @@ def bench_adaptive_b1(args, dev, world, rank):
     return bench_adaptive(args, dev, world, rank, images=1, n=3)
 
 
-def bench_adaptive(args, dev, world, rank, images=None, n=2):
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (= the fp32 vector rate)
+
+
+def pointrend_plugin(dev, batch, target=4.0):
+    """The PointRend-architecture mask plug-in on the device (coma_amd/seg) with SEEDED RANDOM weights (the checkpoint cannot be fetched) and
+    FORCED detections: random class scores would either detect nothing or 100 instances per image, and the mask head's cost is proportional to
+    the detections, so the background-class bias is bisected (outside any timed region) until a noise image yields ~`target` detections per
+    image -- the order of what a real checkpoint finds in an HOI render.  -> (plug-in, plan, calibration record)."""
+    from coma_amd.seg import weights as SW
+    from coma_amd.seg.predictor import HipPointRendPredictor
+    state = SW.random_state(seed=0, cls_gain=0.2, delta_gain=0.1, person_bias=3.0)
+    pred = HipPointRendPredictor(pointrend_thres=0.2, device=dev, state=state)
+    plan = pred.pointrend_seg_model.plan(batch, 512, 512)
+    g = torch.Generator().manual_seed(9)
+    low = torch.rand(batch, 3, 16, 16, generator=g)
+    img = (torch.nn.functional.interpolate(low, size=(512, 512), mode="bicubic").clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().to(dev)
+    bias = plan.P["box_pred"][1]                       # [81 class scores | 320 box deltas]; the plan reads it in place
+    lo, hi, mean = -20.0, 60.0, 0.0
+    for _ in range(18):
+        mid = 0.5 * (lo + hi)
+        bias[80] = mid
+        mean = float(plan(img)["count"].float().mean())
+        if mean > target:
+            lo = mid
+        else:
+            hi = mid
+        if abs(mean - target) <= 0.5:
+            break
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(3):
+        plan(img)
+    e.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(e) / 3
+    prof = plan.g.profile(reps=2)
+    gemm = [(fl, t) for tag, fl, t in prof if tag.startswith("seg gemm")]
+    big = [(fl, t) for fl, t in gemm if fl >= 2e9 * batch]          # the backbone / FPN / RPN / box-head convolutions (fixed work per image)
+    rec = {"background_bias": float(bias[80]), "detections_per_image_on_calibration_image": mean, "forward_ms": ms, "batch": batch,
+           "launches": len(plan.g.launches), "gflop_per_image_at_capacity": plan.g.flops / batch / 1e9,
+           "roofline": {"bound": "mfma", "kernel": "seg::conv_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; layers of >= 2 GFLOP per image)",
+                        "achieved": sum(f for f, _ in big) / sum(t for _, t in big) / 1e9, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": sum(f for f, _ in big) / sum(t for _, t in big) / 1e9 / FP32_MFMA_PEAK_TFLOPS, "launches": len(big),
+                        "all_gemm_launches_ms": sum(t for _, t in gemm), "eager_sum_ms": sum(t for _, _, t in prof), "traffic": None,
+                        "note": "fp32 as the reference runs detectron2 (no autocast): priced against the fp32 matrix peak; the point-head / "
+                                "coarse-head GEMMs are gated by the device-side detection count and are not in `achieved`"}}
+    return pred, plan, rec
+
+
+def bench_adaptive_pointrend(args, dev, world, rank):
+    """config 3 with the PointRend-architecture plug-in on the device instead of the synthetic ellipse (labelled: random weights, forced detections)."""
+    return bench_adaptive(args, dev, world, rank, n=2, plugin="pointrend")
+
+
+def bench_adaptive(args, dev, world, rank, images=None, n=2, plugin="synthetic"):
     """BASELINE.json config 3 shape: the full adaptive-mask loop on a batch of independent 512x512 images (the reference runs
     one image per call; here each image of the batch adapts its own mask), strength 0.98 -> 49 steps, 21 mask re-estimations
     (x0 decode + mask plug-in per image + device mask glue + VAE re-encode).  The mask plug-in is the deterministic synthetic
@@ -303,7 +360,12 @@ def bench_adaptive(args, dev, world, rank, images=None, n=2):
     from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
     AB = images if images is not None else args.images
     pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=AB, height=512, width=512, device=dev, seed=0)
-    pipe.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
+    seg_rec = None
+    if plugin == "pointrend":
+        model, seg_plan, seg_rec = pointrend_plugin(dev, AB)
+        pipe.register_adaptive_mask_model(model)
+    else:
+        pipe.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
     pipe.register_adaptive_mask_settings(default_adaptive_mask_settings(50, "p"))
     g = torch.Generator().manual_seed(5 + rank)
     image = torch.rand(AB, 3, 512, 512, generator=g) * 2 - 1
@@ -332,12 +394,21 @@ def bench_adaptive(args, dev, world, rank, images=None, n=2):
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt = float(t.item()) / n / AB
+    if seg_rec is not None:
+        seg_rec["detections_per_image_after_the_last_loop"] = float(seg_plan.out["count"].float().mean())
+        del seg_plan, model
     del pipe
     torch.cuda.empty_cache()
     if rank != 0:
         return None
-    return {"metric": "adaptive-mask HOI images/s (49 steps, 21 mask re-estimations)", "value": world / dt, "unit": "images/s", "n_gpus": world,
-            "s_per_image": dt, "config": {"workload": f"config 3 shape: full adaptive loop, synthetic mask plug-in, 512x512, {AB} images per call per GPU"}}
+    what = ("PointRend-ARCHITECTURE plug-in on the device (coma_amd/seg: fp32 R50-FPN + RPN + box head + PointRend point head), seeded RANDOM "
+            "weights, detections FORCED to ~4 per image by the background bias" if plugin == "pointrend" else "synthetic mask plug-in")
+    out = {"metric": "adaptive-mask HOI images/s (49 steps, 21 mask re-estimations)", "value": world / dt, "unit": "images/s", "n_gpus": world,
+           "s_per_image": dt, "plugin": plugin,
+           "config": {"workload": f"config 3 shape: full adaptive loop, {what}, 512x512, {AB} images per call per GPU"}}
+    if seg_rec is not None:
+        out["segmentation"] = seg_rec
+    return out
 
 
 def bench_occupancy(args, dev, world, rank):
@@ -486,7 +557,7 @@ def main():
         args.contact_steps = args.steps
     inp = None if (args.workload == "contact" and args.no_secondary) else bench_inpaint(args, dev, world, rank)
     con = None if (args.workload == "inpaint" and args.no_secondary) else bench_contact(args, dev, world, rank)
-    occ = ada = ada_b1 = None
+    occ = ada = ada_b1 = ada_pr = None
     skip = set(filter(None, args.skip.split(",")))
     def section(fn):
         """One optional section.  Single process: a failure becomes {"error": ...} on the line (never lose the primary result).
@@ -512,13 +583,14 @@ def main():
         if "adaptive" not in skip:
             ada = section(bench_adaptive)
             ada_b1 = section(bench_adaptive_b1)
+            ada_pr = section(bench_adaptive_pointrend)
     if rank == 0:
         primary, secondary = (inp, con) if args.workload == "inpaint" else (con, inp)
         out = dict(primary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_inpaint() if args.workload == "inpaint" else cpu_baseline()
         if not args.no_secondary:
-            out["occupancy"], out["adaptive_loop"], out["adaptive_loop_b1"] = occ, ada, ada_b1
+            out["occupancy"], out["adaptive_loop"], out["adaptive_loop_b1"], out["adaptive_loop_pointrend"] = occ, ada, ada_b1, ada_pr
         if secondary is not None:
             sec = dict(secondary)
             if world == 1 and not args.no_cpu_baseline:

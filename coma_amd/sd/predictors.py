@@ -22,15 +22,21 @@ import numpy as np
 
 from .pipeline import merge_bbox, seg2bbox
 
-# constants/segmentation.py and utils/adaptive_mask_inpainting.py:1239-1243 of the reference (paths inside its ODISE / SAM clones)
-COCO_SEG_CONFIG_PTH = "./imports/ODISE/third_party/detectron2/projects/PointRend/configs/InstanceSegmentation/pointrend_rcnn_X_101_32x8d_FPN_3x_coco.yaml"
-COCO_SEG_WEIGHTS_PTH = "./imports/ODISE/third_party/detectron2/projects/PointRend/models/model_final_edd263.pkl"
+# constants/segmentation.py:4-5 and utils/adaptive_mask_inpainting.py:1239-1243 of the reference
+COCO_SEG_CONFIG_PTH = "./imports/pointrend/config/pointrend_rcnn_R_50_FPN_3x_coco.yaml"
+COCO_SEG_WEIGHTS_PTH = "./imports/pointrend/weights/model_final_edd263.pkl"
 SAM_MODEL_PTH_DICT = {"vit_h": "./imports/segment-anything/sam_vit_h_4b8939.pth", "vit_l": "./imports/segment-anything/sam_vit_h_4b8939.pth",
                       "vit_b": "./imports/segment-anything/sam_vit_h_4b8939.pth"}
 
 
-def pointrend_backend(threshold, device="cuda", config_pth=None, weights_pth=None):
-    """Public name of the detector shared by the adaptive-mask plug-ins and src/generation/segment_human.py."""
+def pointrend_backend(threshold, device="cuda", config_pth=None, weights_pth=None, state=None):
+    """Public name of the detector shared by the adaptive-mask plug-ins and src/generation/segment_human.py: the device plan of
+    coma_amd/seg (no detectron2 needed) when the checkpoint is there or parameters are given, detectron2's DefaultPredictor otherwise."""
+    import os
+    pth = weights_pth or COCO_SEG_WEIGHTS_PTH
+    if state is not None or os.path.exists(pth):
+        from ..seg.predictor import HipPointRendBackend
+        return HipPointRendBackend(state, threshold, device) if state is not None else HipPointRendBackend.from_checkpoint(pth, threshold, device)
     return _detectron2_pointrend(threshold, device, config_pth, weights_pth)
 
 
@@ -87,7 +93,7 @@ class PointRendPredictor:
         self.merge_mode = merge_mode
         self.use_visualizer = use_visualizer
         self.device = device
-        self.pointrend_seg_model = pointrend_backend if pointrend_backend is not None else _detectron2_pointrend(pointrend_thres, device)
+        self.pointrend_seg_model = pointrend_backend if pointrend_backend is not None else globals()["pointrend_backend"](pointrend_thres, device)
 
     # ---- pieces
     def merge_mask(self, masks, scores=None):
@@ -196,6 +202,14 @@ def build_adaptive_mask_model(adaptive_mask_model_type, pointrend_threshold, use
     if adaptive_mask_model_type not in PREDICTOR_TABLE:
         raise ValueError(f"adaptive_mask_model_type '{adaptive_mask_model_type}' not one of {sorted(PREDICTOR_TABLE)}")
     cls, sam = PREDICTOR_TABLE[adaptive_mask_model_type]
+    if cls is PointRendPredictor and not use_visualizer and "pointrend_backend" not in backends:
+        import os
+        if backends.get("pointrend_state") is not None or os.path.exists(COCO_SEG_WEIGHTS_PTH):
+            # PointRend only: the whole plug-in runs on the device (x0 image, detector, merged mask never leave HBM; one call per batch)
+            from ..seg.predictor import HipPointRendPredictor
+            return HipPointRendPredictor(pointrend_thres=pointrend_threshold, device=device, state=backends.get("pointrend_state"),
+                                         weights_pth=None if backends.get("pointrend_state") is not None else COCO_SEG_WEIGHTS_PTH)
+    backends.pop("pointrend_state", None)
     kw = dict(pointrend_thres=pointrend_threshold, device=device, use_visualizer=use_visualizer)
     if sam:
         kw["is_sam_multitask_output"] = enable_sam_multitask_output
