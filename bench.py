@@ -19,7 +19,7 @@ Further sections on the same line, every rank taking part (only rank 0 prints):
   adaptive_loop    config 3's shape: the full adaptive-mask loop (49 steps, 21 re-estimations) at batch 8, synthetic mask plug-in
   adaptive_loop_b1 the same, one image per pipeline call (the reference's own call shape)
   adaptive_loop_pointrend  the same at batch 8 with the PointRend-ARCHITECTURE plug-in on the device (coma_amd/seg, fp32; seeded random weights,
-                   detections forced to ~4 per image) + that network's own forward time and fp32-MFMA roofline fraction
+                   4 detections per image forced) + that network's own forward time and fp32-MFMA roofline fraction
   roofline         conv / linear GEMM family of one UNet forward: algorithmic flops / HIP-event time against the 2.5 PF dense MFMA peak
   cpu_baseline     the oracle restatements timed on the host cores (N = 1 only; bounded samples, stated)
 `--workload contact` swaps primary and secondary.  Rank 0 prints ONE JSON line.
@@ -300,31 +300,20 @@ def bench_adaptive_b1(args, dev, world, rank):
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (= the fp32 vector rate)
 
 
-def pointrend_plugin(dev, batch, target=4.0):
+def pointrend_plugin(dev, batch, forced=4):
     """The PointRend-architecture mask plug-in on the device (coma_amd/seg) with SEEDED RANDOM weights (the checkpoint cannot be fetched) and
-    FORCED detections: random class scores would either detect nothing or 100 instances per image, and the mask head's cost is proportional to
-    the detections, so the background-class bias is bisected (outside any timed region) until a noise image yields ~`target` detections per
-    image -- the order of what a real checkpoint finds in an HOI render.  -> (plug-in, plan, calibration record)."""
+    FORCED detections: random class scores put the 100-detection cap of the reference's config on every image, and the mask head's cost is
+    proportional to the detections -- so the cap (TEST.DETECTIONS_PER_IMAGE) is set to `forced` = 4, the order of what a real checkpoint finds
+    in an HOI render: every image carries exactly 4 instances through the mask head.  -> (plug-in, plan, record)."""
     from coma_amd.seg import weights as SW
     from coma_amd.seg.predictor import HipPointRendPredictor
     state = SW.random_state(seed=0, cls_gain=0.2, delta_gain=0.1, person_bias=3.0)
-    pred = HipPointRendPredictor(pointrend_thres=0.2, device=dev, state=state)
+    pred = HipPointRendPredictor(pointrend_thres=0.2, device=dev, state=state, detections_per_image=forced)
     plan = pred.pointrend_seg_model.plan(batch, 512, 512)
     g = torch.Generator().manual_seed(9)
     low = torch.rand(batch, 3, 16, 16, generator=g)
     img = (torch.nn.functional.interpolate(low, size=(512, 512), mode="bicubic").clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().to(dev)
-    bias = plan.P["box_pred"][1]                       # [81 class scores | 320 box deltas]; the plan reads it in place
-    lo, hi, mean = -20.0, 60.0, 0.0
-    for _ in range(18):
-        mid = 0.5 * (lo + hi)
-        bias[80] = mid
-        mean = float(plan(img)["count"].float().mean())
-        if mean > target:
-            lo = mid
-        else:
-            hi = mid
-        if abs(mean - target) <= 0.5:
-            break
+    mean = float(plan(img)["count"].float().mean())
     torch.cuda.synchronize()
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -336,7 +325,7 @@ def pointrend_plugin(dev, batch, target=4.0):
     prof = plan.g.profile(reps=2)
     gemm = [(fl, t) for tag, fl, t in prof if tag.startswith("seg gemm")]
     big = [(fl, t) for fl, t in gemm if fl >= 2e9 * batch]          # the backbone / FPN / RPN / box-head convolutions (fixed work per image)
-    rec = {"background_bias": float(bias[80]), "detections_per_image_on_calibration_image": mean, "forward_ms": ms, "batch": batch,
+    rec = {"detections_cap": forced, "detections_per_image_on_a_noise_image": mean, "forward_ms": ms, "batch": batch,
            "launches": len(plan.g.launches), "gflop_per_image_at_capacity": plan.g.flops / batch / 1e9,
            "roofline": {"bound": "mfma", "kernel": "seg::conv_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; layers of >= 2 GFLOP per image)",
                         "achieved": sum(f for f, _ in big) / sum(t for _, t in big) / 1e9, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -402,7 +391,7 @@ def bench_adaptive(args, dev, world, rank, images=None, n=2, plugin="synthetic")
     if rank != 0:
         return None
     what = ("PointRend-ARCHITECTURE plug-in on the device (coma_amd/seg: fp32 R50-FPN + RPN + box head + PointRend point head), seeded RANDOM "
-            "weights, detections FORCED to ~4 per image by the background bias" if plugin == "pointrend" else "synthetic mask plug-in")
+            "weights, 4 detections per image FORCED (TEST.DETECTIONS_PER_IMAGE = 4)" if plugin == "pointrend" else "synthetic mask plug-in")
     out = {"metric": "adaptive-mask HOI images/s (49 steps, 21 mask re-estimations)", "value": world / dt, "unit": "images/s", "n_gpus": world,
            "s_per_image": dt, "plugin": plugin,
            "config": {"workload": f"config 3 shape: full adaptive loop, {what}, 512x512, {AB} images per call per GPU"}}

@@ -76,13 +76,16 @@ class HipPointRend:
     non-empty filter), masks u8 [B,100,H,W] (keep_masks), person u8 [B,H,W] (np.any over the masks of cat_id: the plug-in's output)."""
 
     def __init__(self, state, batch, height, width, device="cuda", score_thresh=0.2, keep_masks=True, use_graph=True, cat_id=0, stage="masks",
-                 debug=False):
+                 debug=False, detections_per_image=DET_MAX):
+        """detections_per_image: TEST.DETECTIONS_PER_IMAGE (100 [3rd-party default]) -- the capacity of the mask head's buffers as well."""
         if score_thresh < 1.0 / 8:
             raise ValueError(f"score threshold {score_thresh} < 0.125: a ROI could put more than 8 classes on the candidate list ({CAP} slots for 1000 ROIs)")
         assert stage in ("boxes", "masks")
         self.device = torch.device(device)
         self.B, self.H, self.W = batch, height, width
         self.score_thresh, self.use_graph, self.keep_masks, self.cat_id, self.stage, self.debug = score_thresh, use_graph, keep_masks, cat_id, stage, debug
+        self.D = int(detections_per_image)
+        assert 1 <= self.D <= DET_MAX
         self.nh, self.nw = shortest_edge_size(height, width)
         self.hp, self.wp = -(-self.nh // DIVIS) * DIVIS, -(-self.nw // DIVIS) * DIVIS
         self.P = {k: (w.to(self.device).contiguous(), b.to(self.device).contiguous()) for k, (w, b) in W.prepare(state).items()}
@@ -208,7 +211,7 @@ class HipPointRend:
                                       cap=CAP), tag="seg box predict")
         dsb, dss, dsg, dssrc, dnv = g.buf(B, CAP, 4, dtype=F32), g.buf(B, CAP, dtype=F32), g.buf(B, CAP, dtype=I32), g.buf(B, CAP, dtype=I32), g.buf(B, dtype=I32)
         g.add(lambda: ops.sort_candidates(dk, db, dg, dsb, dss, dsg, dssrc, dnv, batch=B, cap=CAP), tag="seg sort (det)")
-        D = DET_MAX
+        D = self.D
         det, det_sc, det_cls, det_src = g.buf(B, D, 4, dtype=F32), g.buf(B, D, dtype=F32), g.buf(B, D, dtype=I32), g.buf(B, D, dtype=I32)
         det_pos, det_n = g.buf(B, D, dtype=I32), g.buf(B, dtype=I32)
         g.add(lambda: ops.nms(dsb, dss, dsg, dssrc, dnv, mask_ws, det_pos, det, det_sc, det_cls, det_src, det_n, batch=B, cap=CAP, thresh=DET_NMS,

@@ -22,8 +22,9 @@ from .model import HipPointRend
 
 
 class HipPointRendBackend:
-    def __init__(self, state, threshold, device="cuda", cat_id=0, keep_masks=True):
+    def __init__(self, state, threshold, device="cuda", cat_id=0, keep_masks=True, detections_per_image=100):
         self.state, self.threshold, self.device, self.cat_id, self.keep_masks = state, float(threshold), torch.device(device), cat_id, keep_masks
+        self.detections_per_image = detections_per_image
         self._plans = {}
 
     @classmethod
@@ -34,7 +35,7 @@ class HipPointRendBackend:
         key = (batch, height, width)
         if key not in self._plans:
             self._plans[key] = HipPointRend(self.state, batch, height, width, self.device, score_thresh=self.threshold, keep_masks=self.keep_masks,
-                                            cat_id=self.cat_id)
+                                            cat_id=self.cat_id, detections_per_image=self.detections_per_image)
         return self._plans[key]
 
     def _run(self, image):
@@ -64,7 +65,8 @@ class HipPointRendPredictor:
     """utils/adaptive_mask_inpainting.py:1182-1236 with the detector on the device.  Same constructor arguments and result dictionary."""
     accepts_device_tensor = True
 
-    def __init__(self, cat_id_to_focus=0, pointrend_thres=0.9, device="cuda", use_visualizer=False, merge_mode="merge", *, state=None, weights_pth=None):
+    def __init__(self, cat_id_to_focus=0, pointrend_thres=0.9, device="cuda", use_visualizer=False, merge_mode="merge", *, state=None, weights_pth=None,
+                 detections_per_image=100):
         assert merge_mode in ["merge", "max-confidence"], f"'merge_mode': {merge_mode} not implemented."
         if use_visualizer:
             raise NotImplementedError("use_visualizer draws with detectron2's Visualizer; the device plug-in has none")
@@ -73,7 +75,8 @@ class HipPointRendPredictor:
                 raise ValueError("HipPointRendPredictor needs `state` (parameters) or `weights_pth` (a detectron2 .pkl)")
             state = W.load_detectron2_pkl(weights_pth)
         self.cat_id_to_focus, self.merge_mode, self.use_visualizer, self.device = cat_id_to_focus, merge_mode, False, device
-        self.pointrend_seg_model = HipPointRendBackend(state, pointrend_thres, device, cat_id=cat_id_to_focus, keep_masks=merge_mode != "merge")
+        self.pointrend_seg_model = HipPointRendBackend(state, pointrend_thres, device, cat_id=cat_id_to_focus, keep_masks=merge_mode != "merge",
+                                                       detections_per_image=detections_per_image)
 
     def predict_batch(self, images_u8):
         if self.merge_mode != "merge":                     # max-confidence picks ONE instance: per image through the host-side record
