@@ -554,6 +554,8 @@ def main():
         waiting in one until the RCCL timeout -- the failing rank reports on stderr, rank 0 first prints what it has, and the process
         exits non-zero so that the launcher tears the job down at once."""
         try:
+            if rank == 0:
+                print(f"[bench] section {fn.__name__} ...", file=sys.stderr, flush=True)
             return fn(args, dev, world, rank)
         except Exception as e:   # noqa: BLE001
             if world == 1:
@@ -570,9 +572,12 @@ def main():
         if "occupancy" not in skip:
             occ = section(bench_occupancy)
         if "adaptive" not in skip:
-            ada = section(bench_adaptive)
-            ada_b1 = section(bench_adaptive_b1)
-            ada_pr = section(bench_adaptive_pointrend)
+            if "adaptive_b8" not in skip:
+                ada = section(bench_adaptive)
+            if "adaptive_b1" not in skip:
+                ada_b1 = section(bench_adaptive_b1)
+            if "pointrend" not in skip:
+                ada_pr = section(bench_adaptive_pointrend)
     if rank == 0:
         primary, secondary = (inp, con) if args.workload == "inpaint" else (con, inp)
         out = dict(primary)

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # COMA_HIP_LIB=<path>: tuning aid -- load another BUILD of the library (A/B of two builds inside one GPU call: box-to-box spread is larger
 # than most of the effects being measured); the product and the tests use the in-tree library
 LIB_PATH = os.environ.get("COMA_HIP_LIB") or os.path.join(_HERE, "libcoma_hip.so")
+ABI_VERSION = 6                  # = COMA_ABI_VERSION of include/coma_hip.h: bumped with every change of the SIGNATURES table below
 
 _lib = None
 
@@ -124,12 +125,16 @@ def lib():
             raise ComaHipError(
                 f"{LIB_PATH} is missing: build it with `python -m coma_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        if os.environ.get("COMA_HIP_LIB"):
+            import sys
+            print(f"coma_amd: COMA_HIP_LIB override active -- loading {LIB_PATH} instead of the in-tree library (tuning aid)", file=sys.stderr, flush=True)
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)      # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
-        if h.coma_abi_version() != 1:
-            raise ComaHipError(f"ABI version mismatch: library reports {h.coma_abi_version()}")
+        if h.coma_abi_version() != ABI_VERSION:
+            raise ComaHipError(f"ABI version mismatch: {LIB_PATH} reports {h.coma_abi_version()}, this package binds version {ABI_VERSION} "
+                               "(rebuild with `python -m coma_amd.build`)")
         _lib = h
     return _lib
 

@@ -17,8 +17,16 @@
 // two LDS stages (one barrier per chunk), the next chunk's global loads in flight under this chunk's MFMAs.  Per 8 k values a wave reads
 // ONE ds_read_b128 per operand tile: lanes 0-31 take k = 8g .. 8g+3, lanes 32-63 take k = 8g+4 .. 8g+7, and MFMA step e consumes element e
 // of both (the k order inside a sum is free as long as A and W agree) -- 16 MFMAs (1024 cycles) per 4 LDS reads.
+// Epilogue: the accumulators go through LDS (the two operand stages are free by then) and leave as whole rows -- float4 stores of 128 / 64 / 32
+// consecutive columns, the residual and the bias read the same way.  (Storing straight from the MFMA layout is one 4-byte column per lane,
+// two 128-byte row pieces per instruction: the layers with K <= 128 were 4 x off the HBM floor that way, profiles/r06_notes.md 3.)
+// Split-K (deterministic): launches whose tiles fill less than half the chip's 512 workgroup slots and whose K is long cut K into S slices
+// (blockIdx.z); every slice stores its raw partial tile into a slab of the caller's workspace and seg_splitk_reduce_kernel sums the slabs
+// in slice order and applies bias / residual / ReLU -- the same result on every run (no atomics).
 // Algorithmic bytes per launch: A read once (x taps when the window overlaps is NOT counted: the re-reads hit L2), W once, out once.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "common.h"
 #include "sd_plan.h"
@@ -37,6 +45,7 @@ struct GemmArgs {
   const float* x; const float* w; const float* bias; const float* res; float* out; const int* m_dev;
   int B, H, W, C, ldx, N, Kpad, kh, kw, stride, pad, OH, OW, ldr, res_mode, ldo, relu, rows_per_item, unit_rows;
   long long M;
+  float* ws; int splits, nk_per, ws_ld;      // split-K: slab z of the workspace is [gridDim.x * BM][ws_ld] raw partial sums
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -87,7 +96,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     }
   }
   const int ntaps = a.kh * a.kw;
-  const int nk = a.Kpad / kBK;
+  const int nk_all = a.Kpad / kBK;
+  const int kc0 = a.splits > 1 ? (int)blockIdx.z * a.nk_per : 0;
+  const int nk = a.splits > 1 ? (kc0 + a.nk_per < nk_all ? a.nk_per : nk_all - kc0) : nk_all;      // >= 1 by construction of the launch
 
   float4 ra[NA], rb[NB];
   auto gload = [&](int kc) {
@@ -127,13 +138,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
+  gload(kc0);
   lstore(0);
   __syncthreads();
   const int li = lane & 31, lh = lane >> 5;
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
-    if (kc + 1 < nk) gload(kc + 1);
+    if (kc + 1 < nk) gload(kc0 + kc + 1);
     const float* Ab = As + (buf * BM + wm * TM * 32 + li) * kLd + lh * 4;
     const float* Bb = Bs + (buf * BN + wn * TN * 32 + li) * kLd + lh * 4;
 #pragma unroll
@@ -157,44 +168,146 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     __syncthreads();
   }
 
-  // ---- epilogue: D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32]
+  // ---- epilogue through LDS: D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] -> Cs[BM][BN + 8] (the row stride puts the two
+  // lane halves, 4 rows apart, 32 banks apart: conflict-free 4-byte writes), then whole rows leave as float4
+  constexpr int CLD = BN + 8;
+  float* Cs = lds;                                       // the loop's last __syncthreads() released both operand stages
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + li;
-      if (col >= a.N) continue;
-      const float bv = a.bias ? a.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + (wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-        if (!row_ok(m)) continue;
-        float v = acc[i][j][r] + bv;
-        if (a.res_mode == 1) {
-          v += a.res[m * a.ldr + col];
-        } else if (a.res_mode == 2) {                    // nearest x2 up-sampling of a [B, OH / 2, OW / 2] tensor
-          const int b = (int)(m / ohw), rem = (int)(m - (long long)b * ohw);
-          const int oy = rem / a.OW, ox = rem - oy * a.OW;
-          v += a.res[(((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + col];
-        }
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        a.out[m * a.ldo + col] = v;
+      for (int r = 0; r < 16; ++r)
+        Cs[((wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)) * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
+  __syncthreads();
+  constexpr int LPR = BN / 4, RPP = 256 / LPR;           // lanes per row, rows per pass
+  const int col = n0 + (tid % LPR) * 4, rr = tid / LPR;
+  if (col >= a.N) return;
+  if (a.splits > 1) {                                    // raw partial sums; bias / residual / ReLU belong to the reduce pass
+    float* slab = a.ws + (long long)blockIdx.z * ((long long)gridDim.x * BM) * a.ws_ld;
+#pragma unroll 4
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int row = p * RPP + rr;
+      if (!row_ok(m0 + row)) continue;
+      *reinterpret_cast<float4*>(slab + (m0 + row) * a.ws_ld + col) = *reinterpret_cast<const float4*>(Cs + row * CLD + (tid % LPR) * 4);
+    }
+    return;
+  }
+  const bool vec = col + 3 < a.N && !(a.ldo & 3) && (a.res_mode == 0 || !(a.ldr & 3));
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = col + e < a.N ? a.bias[col + e] : 0.f;
+#pragma unroll 4
+  for (int p = 0; p < BM / RPP; ++p) {
+    const int row = p * RPP + rr;
+    const long long m = m0 + row;
+    if (!row_ok(m)) continue;
+    const float4 c4 = *reinterpret_cast<const float4*>(Cs + row * CLD + (tid % LPR) * 4);
+    float v[4] = {c4.x + bv[0], c4.y + bv[1], c4.z + bv[2], c4.w + bv[3]};
+    const float* rp = nullptr;
+    if (a.res_mode == 1) {
+      rp = a.res + m * a.ldr + col;
+    } else if (a.res_mode == 2) {                        // nearest x2 up-sampling of a [B, OH / 2, OW / 2] tensor
+      const int b = (int)(m / ohw), rem = (int)(m - (long long)b * ohw);
+      const int oy = rem / a.OW, ox = rem - oy * a.OW;
+      rp = a.res + (((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + col;
+    }
+    if (vec) {
+      if (rp) {
+        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+      }
+      if (a.relu)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      *reinterpret_cast<float4*>(a.out + m * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (col + e >= a.N) break;
+        float x = v[e] + (rp ? rp[e] : 0.f);
+        if (a.relu) x = x > 0.f ? x : 0.f;
+        a.out[m * a.ldo + col + e] = x;
       }
     }
+  }
 }
 
+// out = act(sum_z slab_z + bias (+ res)) over the valid rows; one float4 of columns per thread
+__global__ __launch_bounds__(256) void seg_splitk_reduce_kernel(const GemmArgs a, long long slab_elems) {
+  const int n4 = (a.N + 3) / 4;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.M * n4) return;
+  const long long m = t / n4;
+  const int col = (int)(t - m * n4) * 4;
+  if (a.m_dev) {
+    const long long u = m / a.unit_rows;
+    if (m - u * a.unit_rows >= (long long)a.m_dev[u] * a.rows_per_item) return;
+  }
+  const float* src = a.ws + m * a.ws_ld + col;
+  float4 acc = *reinterpret_cast<const float4*>(src);
+  for (int z = 1; z < a.splits; ++z) {
+    const float4 p = *reinterpret_cast<const float4*>(src + z * slab_elems);
+    acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+  }
+  float v[4] = {acc.x, acc.y, acc.z, acc.w};
+  const float* rp = nullptr;
+  if (a.res_mode == 1) {
+    rp = a.res + m * a.ldr + col;
+  } else if (a.res_mode == 2) {
+    const int ohw = a.OH * a.OW;
+    const int b = (int)(m / ohw), rem = (int)(m - (long long)b * ohw);
+    const int oy = rem / a.OW, ox = rem - oy * a.OW;
+    rp = a.res + (((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + col;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (col + e >= a.N) break;
+    float x = v[e] + (a.bias ? a.bias[col + e] : 0.f) + (rp ? rp[e] : 0.f);
+    if (a.relu) x = x > 0.f ? x : 0.f;
+    a.out[m * a.ldo + col + e] = x;
+  }
+}
+
+constexpr int kSlots = 512;               // 256 CUs x 2 resident workgroups
+
 template <int WM, int WN, int TM, int TN>
-static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_bytes) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)2 * (BM + BN) * kLd * sizeof(float);
+  static_assert((size_t)BM * (BN + 8) * sizeof(float) <= lds, "the epilogue staging tile must fit into the operand stages");
   static coma::LdsOptIn opt;
   if (lds > 65536)
     if (int rc = coma::opt_in_lds(opt, (const void*)conv_gemm_f32_kernel<WM, WN, TM, TN>, lds, "seg_conv_gemm_f32")) return rc;
   const long long gx = (a.M + BM - 1) / BM;
   const int gy = (a.N + BN - 1) / BN;
   if (gx > 0x7fffffffLL || gy > 65535) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: grid too large");
-  hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN>), dim3((unsigned)gx, (unsigned)gy), dim3(256), lds, st, a);
-  return check_launch("seg::conv_gemm_f32_kernel");
+  // split-K: only where the tiles leave more than half of the chip idle and every slice keeps >= 4 chunks (128 k values)
+  const int nk = a.Kpad / kBK;
+  const long long tiles = gx * gy;
+  int S = 1;
+  if (force_split > 0) S = force_split;
+  else if (force_split == 0 && a.ws && tiles * 2 <= kSlots && nk >= 8) S = (int)std::min<long long>(kSlots / tiles, nk / 4);
+  a.ws_ld = gy * BN;
+  const long long slab = gx * BM * (long long)a.ws_ld;
+  if (S > 1 && a.ws) S = (int)std::min<long long>(S, (long long)(ws_bytes / sizeof(float)) / slab);
+  if (S > nk) S = nk;
+  if (S <= 1 || !a.ws) {
+    a.splits = 1; a.nk_per = nk;
+    if (force_split > 1) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: split_k=%d needs a workspace of %lld bytes", force_split, slab * 4 * force_split);
+  } else {
+    a.nk_per = (nk + S - 1) / S;
+    a.splits = (nk + a.nk_per - 1) / a.nk_per;            // every slice non-empty
+  }
+  hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN>), dim3((unsigned)gx, (unsigned)gy, (unsigned)a.splits), dim3(256), lds, st, a);
+  if (int rc = check_launch("seg::conv_gemm_f32_kernel")) return rc;
+  if (a.splits > 1) {
+    const long long n = a.M * ((a.N + 3) / 4);
+    hipLaunchKernelGGL(seg_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, slab);
+    return check_launch("seg::seg_splitk_reduce_kernel");
+  }
+  return COMA_OK;
 }
 
 }  // namespace seg
@@ -210,6 +323,7 @@ extern "C" int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream) {
     r.i[1] = d->batch; r.i[2] = d->in_h; r.i[3] = d->in_w; r.i[4] = d->c; r.i[5] = d->ldx; r.i[6] = d->n; r.i[7] = d->kpad; r.i[8] = d->kh;
     r.i[9] = d->kw; r.i[10] = d->stride; r.i[11] = d->pad; r.i[12] = d->out_h; r.i[13] = d->out_w; r.i[14] = d->ldr; r.i[15] = d->res_mode;
     r.i[16] = d->ldo; r.i[17] = d->relu; r.i[18] = d->rows_per_item; r.i[19] = d->tile; r.i[20] = d->unit_rows;
+    r.p[6] = d->workspace; r.i[21] = d->split_k; r.i[22] = (int64_t)d->workspace_bytes;
     return sd::plan_record(r);
   }
   if (!d->x || !d->w || !d->out) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: null pointer");
@@ -234,12 +348,16 @@ extern "C" int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream) {
   a.ldo = d->ldo ? d->ldo : d->n; a.relu = d->relu; a.rows_per_item = d->rows_per_item; a.unit_rows = d->unit_rows;
   a.M = (long long)d->batch * d->out_h * d->out_w;
   if (a.ldo < d->n) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: ldo=%d < n=%d", a.ldo, d->n);
+  if (d->split_k < -1 || (d->workspace && d->workspace_bytes < 16)) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: split_k=%d workspace_bytes=%zu", d->split_k, d->workspace_bytes);
+  a.ws = (float*)d->workspace; a.splits = 1; a.nk_per = 0; a.ws_ld = 0;
+  const int fs = d->split_k;                     // 0 = by the rule above, -1 = never, S > 1 = exactly S slices (tests)
+  const size_t wb = d->workspace_bytes;
   hipStream_t st = (hipStream_t)stream;
   // tile: 0 = by width (n <= 32: 128 x 32, n <= 64: 128 x 64, else 128 x 128); 1 / 2 / 3 force 128 x 128 / 128 x 64 / 128 x 32 (tests)
   int tile = d->tile;
   if (tile == 0) tile = d->n <= 32 ? 3 : (d->n <= 64 ? 2 : 1);
-  if (tile == 1) return launch_gemm<2, 2, 2, 2>(a, st);
-  if (tile == 2) return launch_gemm<4, 1, 1, 2>(a, st);
-  if (tile == 3) return launch_gemm<4, 1, 1, 1>(a, st);
+  if (tile == 1) return launch_gemm<2, 2, 2, 2>(a, st, fs, wb);
+  if (tile == 2) return launch_gemm<4, 1, 1, 2>(a, st, fs, wb);
+  if (tile == 3) return launch_gemm<4, 1, 1, 1>(a, st, fs, wb);
   return fail(COMA_E_INVALID, "seg_conv_gemm_f32: tile=%d", d->tile);
 }

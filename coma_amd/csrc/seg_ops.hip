@@ -131,6 +131,18 @@ __global__ void resize_v_norm_kernel(const unsigned char* tmp, int B, int h, int
   out[t] = v;
 }
 
+__global__ void fill_bytes_kernel(unsigned char* dst, unsigned char v, long long n) {        // 16 bytes per thread, scalar head / tail
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long o = t * 16;
+  if (o >= n) return;
+  const unsigned int w = 0x01010101u * v;
+  if (o + 16 <= n && !(reinterpret_cast<unsigned long long>(dst) & 15)) {
+    *reinterpret_cast<uint4*>(dst + o) = make_uint4(w, w, w, w);
+  } else {
+    for (long long i = o; i < n && i < o + 16; ++i) dst[i] = v;
+  }
+}
+
 __global__ void copy_u8_kernel(const unsigned char* src, unsigned char* dst, long long n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) dst[t] = src[t];
@@ -729,8 +741,12 @@ extern "C" int seg_memset(void* dst, int byte, size_t bytes, void* stream) {
     r.p[0] = dst; r.i[1] = byte; r.i[2] = (int64_t)bytes;
   SEG_REC_END
   if (!dst || bytes == 0) return fail(COMA_E_INVALID, "seg_memset: bad args");
-  if (hipMemsetAsync(dst, byte, bytes, (hipStream_t)stream) != hipSuccess) return fail(COMA_E_LAUNCH, "seg_memset: hipMemsetAsync failed");
-  return COMA_OK;
+  // a kernel, not hipMemsetAsync: inside the captured plan a memset NODE sat between kernel nodes, and replays of that graph hung the
+  // queue about once in three processes (profiles/r06_notes.md 2); a fill kernel is an ordinary node of the chain
+  const unsigned char bt = (unsigned char)byte;
+  hipLaunchKernelGGL(fill_bytes_kernel, dim3(blocks_for((long long)bytes, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (unsigned char*)dst, bt,
+                     (long long)bytes);
+  return check_launch("seg::fill_bytes_kernel");
 }
 
 extern "C" int seg_rpn_select(const void* pred, int ld, int batch, int fh, int fw, int stride, const void* cell_anchors, int level, int anchor_base,
@@ -913,6 +929,7 @@ int seg_replay(const PlanRec& r, void* st) {
       d.batch = (int)i[1]; d.in_h = (int)i[2]; d.in_w = (int)i[3]; d.c = (int)i[4]; d.ldx = (int)i[5]; d.n = (int)i[6]; d.kpad = (int)i[7]; d.kh = (int)i[8];
       d.kw = (int)i[9]; d.stride = (int)i[10]; d.pad = (int)i[11]; d.out_h = (int)i[12]; d.out_w = (int)i[13]; d.ldr = (int)i[14]; d.res_mode = (int)i[15];
       d.ldo = (int)i[16]; d.relu = (int)i[17]; d.rows_per_item = (int)i[18]; d.tile = (int)i[19]; d.unit_rows = (int)i[20];
+      d.workspace = p[6]; d.split_k = (int)i[21]; d.workspace_bytes = (size_t)i[22];
       return seg_conv_gemm_f32(&d, st);
     }
     case SEG_OP_RESIZE:

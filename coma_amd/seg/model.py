@@ -21,12 +21,14 @@ from . import ops
 from . import weights as W
 
 F32, I32, I64, U8 = torch.float32, torch.int32, torch.int64, torch.uint8
+_DEBUG_SYNC = __import__("os").environ.get("SEG_DEBUG_SYNC") == "1"
 PIXEL_MEAN = (103.530, 116.280, 123.675)            # MODEL.PIXEL_MEAN [3rd-party default]; applied to the channels IN THE ORDER GIVEN
 MIN_SIZE, MAX_SIZE, DIVIS = 800, 1333, 32
 ANCHOR_SIZES, ANCHOR_RATIOS = (32, 64, 128, 256, 512), (0.5, 1.0, 2.0)
 PRE_TOPK, POST_TOPK, RPN_NMS = 1000, 1000, 0.7
 DET_MAX, DET_NMS = 100, 0.5
 CAP = 8192
+SPLITK_WS_FLOATS = 16 << 20                          # 64 MiB: 256 partial tiles of 128 x 128 x up to 4 slices ... 512 slots' worth
 POINTS = 28 * 28                                     # POINT_HEAD.SUBDIVISION_NUM_POINTS
 INIT_RES, SUBDIV_STEPS = 28, 3                       # 7 -> 28 and 5 -> 3 by PointRendMaskHead._init_point_head's doubling rule
 
@@ -109,7 +111,7 @@ class HipPointRend:
         M = batch * oh * ow
         self.g.add(lambda: ops.conv_gemm(x, wt, out, batch=batch, in_h=h, in_w=w, c=c, n=n, kh=kh, kw=kh, stride=stride, pad=pad, out_h=oh, out_w=ow,
                                          bias=bias, res=res, res_mode=res_mode, ldo=ldo, ldx=ldx, relu=relu, m_dev=m_dev,
-                                         rows_per_item=rows_per_item, unit_rows=unit_rows),
+                                         rows_per_item=rows_per_item, unit_rows=unit_rows, workspace=self.splitk_ws),
                    flops=2 * M * n * kh * kh * c, nbytes=4 * (batch * h * w * c + n * kh * kh * c + M * n * (2 if res is not None else 1)),
                    tag=tag or f"seg gemm {name} M={M} N={n} K={kh * kh * c}")
         return out, oh, ow
@@ -118,6 +120,9 @@ class HipPointRend:
         g, B, dev = self.g, self.B, self.device
         H, Wd, nh, nw, hp, wp = self.H, self.W, self.nh, self.nw, self.hp, self.wp
         t = self.t
+        # split-K scratch of the GEMMs whose tiles leave most of the chip idle (deep levels, the mask head's fully connected layers): one
+        # buffer, the launches of a plan run in order on one stream
+        self.splitk_ws = g.buf(SPLITK_WS_FLOATS, dtype=F32)
         # ---- DefaultPredictor: ResizeShortestEdge (PIL bilinear) + preprocess_image
         self.images = g.buf(B, H, Wd, 3, dtype=U8)
         bx, kx = bilinear_tables(Wd, nw)
@@ -279,6 +284,13 @@ class HipPointRend:
     def __call__(self, images_u8):
         assert tuple(images_u8.shape) == (self.B, self.H, self.W, 3) and images_u8.dtype == U8, (images_u8.shape, images_u8.dtype)
         self.images.copy_(images_u8.to(self.device), non_blocking=True)
+        if _DEBUG_SYNC:                  # SEG_DEBUG_SYNC=1: eager, one synchronisation and one stderr line per launch (locating a faulting launch)
+            import sys
+            for fn, (tag, _) in zip(self.g.launches, self.g.tags):
+                print("seg ->", tag, file=sys.stderr, flush=True)
+                fn()
+                torch.cuda.synchronize(self.device)
+            return self.out
         if self.use_graph:
             self.g.replay()
         else:

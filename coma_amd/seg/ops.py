@@ -16,11 +16,12 @@ class SegConvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("batch", C.c_int), ("in_h", C.c_int), ("in_w", C.c_int), ("c", C.c_int), ("ldx", C.c_int),
                 ("w", C.c_void_p), ("n", C.c_int), ("kpad", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
                 ("out_h", C.c_int), ("out_w", C.c_int), ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_int), ("res_mode", C.c_int),
-                ("out", C.c_void_p), ("ldo", C.c_int), ("relu", C.c_int), ("m_dev", C.c_void_p), ("rows_per_item", C.c_int), ("unit_rows", C.c_int), ("tile", C.c_int)]
+                ("out", C.c_void_p), ("ldo", C.c_int), ("relu", C.c_int), ("m_dev", C.c_void_p), ("rows_per_item", C.c_int), ("unit_rows", C.c_int), ("tile", C.c_int),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("split_k", C.c_int)]
 
 
 def conv_gemm(x, w, out, *, batch, in_h, in_w, c, n, kh=1, kw=1, stride=1, pad=0, out_h=None, out_w=None, bias=None, res=None, res_mode=0,
-              ldr=0, ldo=0, ldx=0, relu=False, m_dev=None, rows_per_item=1, unit_rows=0, tile=0):
+              ldr=0, ldo=0, ldx=0, relu=False, m_dev=None, rows_per_item=1, unit_rows=0, tile=0, workspace=None, split_k=0):
     d = SegConvDesc()
     d.x, d.batch, d.in_h, d.in_w, d.c, d.ldx = _p(x, "x", F32), batch, in_h, in_w, c, ldx
     d.w, d.n, d.kpad = _p(w, "w", F32), n, w.shape[-1]
@@ -30,6 +31,7 @@ def conv_gemm(x, w, out, *, batch, in_h, in_w, c, n, kh=1, kw=1, stride=1, pad=0
     d.bias, d.res, d.ldr, d.res_mode = _p(bias, "bias", F32), _p(res, "res", F32), ldr, res_mode
     d.out, d.ldo, d.relu = _p(out, "out", F32), ldo, 1 if relu else 0
     d.m_dev, d.rows_per_item, d.unit_rows, d.tile = _p(m_dev, "m_dev", I32), rows_per_item, unit_rows, tile
+    d.workspace, d.workspace_bytes, d.split_k = _p(workspace, "workspace", F32), (workspace.numel() * 4 if workspace is not None else 0), split_k
     _lib.check(_lib.lib().seg_conv_gemm_f32(C.byref(d), _stream(out)), "seg_conv_gemm_f32")
     return out
 

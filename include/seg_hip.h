@@ -49,6 +49,10 @@ typedef struct seg_conv_desc {
                            first m_dev[u] * rows_per_item rows are computed */
   int rows_per_item, unit_rows;
   int tile;             /* 0 = by width; 1 / 2 / 3 = 128x128 / 128x64 / 128x32 (tests) */
+  void* workspace;      /* f32 scratch for split-K partial tiles or NULL (then K is never split) */
+  size_t workspace_bytes;
+  int split_k;          /* 0 = by rule (tiles fill < half the chip and K >= 256: up to 512 / tiles slices of >= 128 k values, as many as the
+                           workspace holds), -1 = never, S > 1 = exactly S slices (tests); the slices are summed in order: deterministic */
 } seg_conv_desc;
 int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream);
 

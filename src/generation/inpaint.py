@@ -184,15 +184,20 @@ def prime_mask_model(model, adaptive_mask_model_type, asset_seg, default_mask):
 SETTING_KEYS = ("ddim_steps", "cfg_scale", "strength", "enforce_full_mask_ratio", "human_detection_thres")
 
 
-def group_for_batches(items, batch_size):
+def group_for_batches(items, batch_size, primed=None):
     """Walk the (sorted, sliced) work list in order and cut it into groups of at most `batch_size` CONSECUTIVE items that share
     every per-call setting of the override chain (ddim_steps / cfg_scale / strength / enforce_full_mask_ratio /
     human_detection_thres: one pipeline call has one value of each).  The reference runs one item per call
     (src/generation/inpaint.py:280-352); every item keeps its own generator seeded with its `inpaint_id` (:308-309), its own
-    prompt, mask and plug-in state, so the images do not depend on how the list is cut."""
+    prompt, mask and plug-in state, so the images do not depend on how the list is cut.
+
+    `primed(it)` says whether the item brings its own plug-in state (a segmentation file, :325).  An item that does NOT starts, in the
+    reference's sequential loop, from what the item before it left in the plug-in AFTER that item's pipeline call (e.g. the accumulated
+    `initial_human_bbox`).  Inside a batch the previous slot has not run yet, so such an item always OPENS a group: slot 0 inherits the
+    previous group's last slot after its call -- the sequential loop's state exactly, at the price of a shorter group."""
     groups, cur = [], []
     for it in items:
-        if cur and (len(cur) == batch_size or any(it[k] != cur[0][k] for k in SETTING_KEYS)):
+        if cur and (len(cur) == batch_size or any(it[k] != cur[0][k] for k in SETTING_KEYS) or (primed is not None and not primed(it))):
             groups.append(cur)
             cur = []
         cur.append(it)
@@ -234,7 +239,8 @@ def inpaint_human(args):
         # one plug-in instance serves B images of a batch: its small per-item state (presumed asset mask, person boxes) is swapped
         # in and out around every call, the networks are shared
         pipeline.register_adaptive_mask_model(PerItemState(pipeline.adaptive_mask_model, B))
-    for group in group_for_batches(todo, B):
+    prev_last = None                                   # slot of the last real item of the previous group
+    for group in group_for_batches(todo, B, primed=(lambda it: os.path.exists(it["asset_seg_pth"])) if adaptive else None):
         n = len(group)
         slots = group + [group[-1]] * (B - n)          # ragged tail: the last item fills the spare slots, its copies are dropped
         images = [Image.open(it["asset_render_pth"]).convert("RGB") for it in slots]
@@ -242,10 +248,11 @@ def inpaint_human(args):
         for b, it in enumerate(slots):
             model = pipeline.adaptive_mask_model
             if isinstance(model, PerItemState):
-                # an item without a segmentation file is not primed (reference :325): it starts from whatever the item BEFORE it in
-                # list order left in the plug-in -- the previous slot of this group, or the last slot of the previous group -- not from
-                # the unrelated item that used this slot one group earlier
-                model.select(b, inherit_from=(b - 1) % B if B > 1 else None)
+                # an item without a segmentation file is not primed (reference :325): it starts from what the item BEFORE it in list
+                # order left in the plug-in after its call.  group_for_batches() makes such an item slot 0 of its group, so the state it
+                # copies is the previous group's LAST REAL slot after that group's pipeline call (not the unrelated item that used this
+                # slot one group earlier); slots b > 0 are always primed below and the copy they receive here is overwritten
+                model.select(b, inherit_from=(prev_last if b == 0 else b - 1) if B > 1 else None)
             if os.path.exists(it["asset_seg_pth"]):
                 prime_mask_model(model, args.adaptive_mask_model_type, np.array(Image.open(it["asset_seg_pth"]).convert("L")) > 0,
                                  np.asarray(masks[b]) > 0)
@@ -265,6 +272,7 @@ def inpaint_human(args):
                            generator=generators if B > 1 else generators[0], num_inference_steps=it0["ddim_steps"],
                            enforce_full_mask_ratio=it0["enforce_full_mask_ratio"], visualization_save_dir=it0["visualization_save_dir"],
                            human_detection_thres=it0["human_detection_thres"], **text).images
+        prev_last = n - 1
         for it, img in zip(group, results[:n]):
             img.save(it["result_save_pth"])
 

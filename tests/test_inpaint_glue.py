@@ -172,6 +172,11 @@ def test_group_for_batches_keeps_order_and_settings():
     assert [len(g) for g in gi.group_for_batches(items, 1)] == [1] * 16
     assert gi.group_for_batches([], 8) == []
     assert gi.build_parser().parse_args([]).batch_size == gi.DEFAULT_BATCH_SIZE == 8
+    # an item without its own plug-in state (no segmentation file) always OPENS a group: it inherits the state the item before it left
+    # AFTER its pipeline call, as in the reference's sequential loop (src/generation/inpaint.py:325 of the reference)
+    unprimed = {3, 4, 10}
+    groups = gi.group_for_batches(items[:11], 8, primed=lambda it: it["inpaint_id"] not in unprimed)
+    assert [[it["inpaint_id"] for it in g] for g in groups] == [[0, 1, 2], [3], [4, 5, 6, 7, 8, 9], [10]]
 
 
 def test_per_item_state_swaps_only_the_small_state():

@@ -125,6 +125,62 @@ def test_linear_with_device_row_counts(hip_lib):
         assert bool((o[mid:hi] == -5.0).all()) and bool((o[lo:mid, 256:] == -5.0).all())
 
 
+@pytest.mark.parametrize("split", [0, 2, 5, -1])
+@pytest.mark.parametrize("shape", ["conv3x3+res", "rpn_pred", "fc_rows"])
+def test_conv_gemm_split_k_is_deterministic_and_matches(hip_lib, split, shape):
+    """Split-K (seg_gemm.hip): launches with few tiles and a long K cut K into slices summed in order by a second pass.  split = 0 is the
+    launch rule (these shapes all qualify), 2 / 5 exact slice counts (5 does not divide the chunk count: ragged last slice), -1 never.
+    Every variant meets the torch fp32 result; two runs of one variant are bit-identical (no atomics); the padding columns of a wide output
+    buffer and the rows past a device-side count are never touched."""
+    from coma_amd.seg import ops, weights as W
+    g = torch.Generator().manual_seed(11)
+    ws = torch.empty(4 << 20, device=DEV)
+    if shape == "conv3x3+res":
+        B, H, Wd, C, N = 2, 10, 12, 128, 256
+        x, w, bias = torch.randn(B, C, H, Wd, generator=g), torch.randn(N, C, 3, 3, generator=g) / (9 * C) ** 0.5, torch.randn(N, generator=g)
+        res = torch.randn(B, N, H, Wd, generator=g)
+        ref = F.relu(F.conv2d(x, w, bias, padding=1) + res).permute(0, 2, 3, 1).reshape(-1, N)
+        kw = dict(batch=B, in_h=H, in_w=Wd, c=C, n=N, kh=3, kw=3, pad=1, bias=d(bias), res=d(res.permute(0, 2, 3, 1)), res_mode=1, relu=True)
+        xin, wt, ldo, rows = d(x.permute(0, 2, 3, 1)), d(W.conv_weight(w, cpad=C)), N, B * H * Wd
+        valid = slice(0, rows)
+    elif shape == "rpn_pred":
+        B, H, Wd, C, N = 1, 13, 13, 256, 15
+        x, w, bias = torch.randn(B, C, H, Wd, generator=g), torch.randn(N, C, 1, 1, generator=g) / C ** 0.5, torch.randn(N, generator=g)
+        ref = F.conv2d(x, w, bias).permute(0, 2, 3, 1).reshape(-1, N)
+        kw = dict(batch=B, in_h=H, in_w=Wd, c=C, n=N, bias=d(bias))
+        xin, wt, ldo, rows = d(x.permute(0, 2, 3, 1)), d(W.conv_weight(w, cpad=C)), 16, B * H * Wd
+        valid = slice(0, rows)
+    else:
+        units, unit_rows, K, N = 2, 100, 1024, 1024                  # the coarse head's fully connected layers: 100 ROI slots per image, 3 / 7 used
+        counts = [3, 7]
+        x, w, bias = torch.randn(units * unit_rows, K, generator=g), torch.randn(N, K, generator=g) / 32, torch.randn(N, generator=g)
+        ref = F.relu(x @ w.t() + bias)
+        xin = x.clone()
+        for u, c in enumerate(counts):
+            xin[u * unit_rows + c:(u + 1) * unit_rows] = float("nan")
+        kw = dict(batch=units * unit_rows, in_h=1, in_w=1, c=K, n=N, bias=d(bias), relu=True, m_dev=d(np.asarray(counts), I32), rows_per_item=1,
+                  unit_rows=unit_rows)
+        xin, wt, ldo, rows = d(xin), d(W._pad_k(w)), N, units * unit_rows
+        valid = torch.tensor([u * unit_rows + i for u, c in enumerate(counts) for i in range(c)])
+    outs = []
+    for rep in range(2):
+        out = torch.full((rows, ldo), 3.0, device=DEV)
+        ops.conv_gemm(xin, wt, out, ldo=ldo, workspace=ws, split_k=split, **kw)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    o = outs[0]
+    n = ref.shape[1]
+    r = _rel(o[valid, :n], ref[valid])
+    print(f"METRIC split-K {shape} split={split}: {r:.2e}")
+    assert r <= 2e-5
+    if ldo > n:
+        assert float((o[:, n:] - 3.0).abs().max()) == 0.0
+    if shape == "fc_rows":
+        mask = torch.ones(rows, dtype=torch.bool)
+        mask[valid] = False
+        assert bool((o[mask] == 3.0).all())
+
+
 def test_pooling(hip_lib):
     from coma_amd.seg import ops
     x = torch.randn(2, 64, 37, 41, generator=torch.Generator().manual_seed(0))
