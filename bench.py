@@ -291,12 +291,6 @@ def bench_contact(args, dev, world, rank):
     }
 
 
-def bench_adaptive_b1(args, dev, world, rank):
-    """The reference-shaped call of the same loop: ONE image per pipeline call (src/generation/inpaint.py:280-352 of the reference
-    loops item by item; `--batch_size 1` of this repo's CLI).  Reported so that the cost of not batching the work list is a number."""
-    return bench_adaptive(args, dev, world, rank, images=1, n=3)
-
-
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 (= the fp32 vector rate)
 
 
@@ -336,27 +330,29 @@ def pointrend_plugin(dev, batch, forced=4):
     return pred, plan, rec
 
 
-def bench_adaptive_pointrend(args, dev, world, rank):
-    """config 3 with the PointRend-architecture plug-in on the device instead of the synthetic ellipse (labelled: random weights, forced detections)."""
-    return bench_adaptive(args, dev, world, rank, n=2, plugin="pointrend")
+ADAPTIVE_SECTIONS = {            # name -> (images per call or None = --images, timed loops, plug-in)
+    "adaptive_b8": (None, 2, "synthetic"),
+    "adaptive_b1": (1, 3, "synthetic"),        # ONE image per pipeline call: the reference's own call shape (src/generation/inpaint.py:280-352 there)
+    "pointrend": (None, 2, "pointrend"),       # the PointRend-architecture plug-in on the device (labelled: random weights, forced detections)
+}
+CHILD_TIMEOUT_S = 300
 
 
-def bench_adaptive(args, dev, world, rank, images=None, n=2, plugin="synthetic"):
+def adaptive_measure(dev, images, n, plugin, seed_rank=0):
     """BASELINE.json config 3 shape: the full adaptive-mask loop on a batch of independent 512x512 images (the reference runs
     one image per call; here each image of the batch adapts its own mask), strength 0.98 -> 49 steps, 21 mask re-estimations
-    (x0 decode + mask plug-in per image + device mask glue + VAE re-encode).  The mask plug-in is the deterministic synthetic
-    stand-in (PointRend weights are unreachable offline); it runs on the host and is inside the timed region."""
+    (x0 decode + mask plug-in + device mask glue + VAE re-encode), the plug-in inside the timed region.  -> (seconds per loop, seg record)"""
     from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
-    AB = images if images is not None else args.images
+    AB = images
     pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=AB, height=512, width=512, device=dev, seed=0)
-    seg_rec = None
+    seg_rec = seg_plan = None
     if plugin == "pointrend":
         model, seg_plan, seg_rec = pointrend_plugin(dev, AB)
         pipe.register_adaptive_mask_model(model)
     else:
         pipe.register_adaptive_mask_model(SyntheticHumanMaskPredictor())
     pipe.register_adaptive_mask_settings(default_adaptive_mask_settings(50, "p"))
-    g = torch.Generator().manual_seed(5 + rank)
+    g = torch.Generator().manual_seed(5 + seed_rank)
     image = torch.rand(AB, 3, 512, 512, generator=g) * 2 - 1
     mask = torch.zeros(AB, 1, 512, 512)
     mask[:, :, 100:420, 150:400] = 1
@@ -368,36 +364,79 @@ def bench_adaptive(args, dev, world, rank, images=None, n=2, plugin="synthetic")
         return pipe(image=image, default_mask_image=mask, prompt_embeds=pe, negative_prompt_embeds=ne, num_inference_steps=50,
                     strength=0.98, guidance_scale=11.0, generator=gen, output_type="u8", use_adaptive_mask=True,
                     enforce_full_mask_ratio=0.0, human_detection_thres=0.015).images
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
 
     one(0)
-    barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(n):
         one(1 + k)
-    barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item()) / n / AB
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
     if seg_rec is not None:
         seg_rec["detections_per_image_after_the_last_loop"] = float(seg_plan.out["count"].float().mean())
-        del seg_plan, model
-    del pipe
+    return dt, seg_rec
+
+
+def child_main(name, device_index, images, seed_rank):
+    """`bench.py --child-section NAME`: one adaptive section measured in its OWN process, one JSON line on stdout."""
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    im, n, plugin = ADAPTIVE_SECTIONS[name]
+    dt, seg_rec = adaptive_measure(dev, im if im is not None else images, n, plugin, seed_rank)
+    print(json.dumps({"child_section": name, "s_per_loop": dt, "segmentation": seg_rec}), flush=True)
+
+
+def bench_adaptive_isolated(name, args, dev, world, rank):
+    """One adaptive section in a CHILD process on this rank's device (no collective inside: the loops of different ranks are independent;
+    the parent takes the MAX of the ranks' times).  A device fault or a hang in an optional section -- the seg plan's captured graph hung
+    about one process in three before its memset node was replaced, profiles/r06_notes.md 2 -- then costs that section, not the line."""
+    import subprocess
+    im, n, plugin = ADAPTIVE_SECTIONS[name]
+    AB = im if im is not None else args.images
+    torch.cuda.synchronize()
     torch.cuda.empty_cache()
+    cmd = [sys.executable, os.path.abspath(__file__), "--child-section", name, "--child-device", str(dev.index), "--images", str(args.images),
+           "--child-seed-rank", str(rank)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    err, rec, dt = None, None, float("inf")
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=CHILD_TIMEOUT_S, env=env, start_new_session=True)
+        lines = [l for l in p.stdout.splitlines() if l.startswith('{"child_section"')]
+        if p.returncode == 0 and lines:
+            rec = json.loads(lines[-1])
+            dt = rec["s_per_loop"]
+        else:
+            err = f"child exited with {p.returncode}: {(p.stderr or '').strip().splitlines()[-3:]}"
+    except subprocess.TimeoutExpired:
+        err = f"child exceeded {CHILD_TIMEOUT_S} s and was killed"
+    t = torch.tensor([dt if err is None else 1e30], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     if rank != 0:
         return None
+    if float(t.item()) >= 1e30:
+        return {"error": err or "a rank's child process failed", "plugin": plugin}
+    dt = float(t.item()) / AB
     what = ("PointRend-ARCHITECTURE plug-in on the device (coma_amd/seg: fp32 R50-FPN + RPN + box head + PointRend point head), seeded RANDOM "
             "weights, 4 detections per image FORCED (TEST.DETECTIONS_PER_IMAGE = 4)" if plugin == "pointrend" else "synthetic mask plug-in")
     out = {"metric": "adaptive-mask HOI images/s (49 steps, 21 mask re-estimations)", "value": world / dt, "unit": "images/s", "n_gpus": world,
-           "s_per_image": dt, "plugin": plugin,
+           "s_per_image": dt, "plugin": plugin, "process": "child (isolated from the primary measurement)",
            "config": {"workload": f"config 3 shape: full adaptive loop, {what}, 512x512, {AB} images per call per GPU"}}
-    if seg_rec is not None:
-        out["segmentation"] = seg_rec
+    if rec.get("segmentation") is not None:
+        out["segmentation"] = rec["segmentation"]
     return out
+
+
+def bench_adaptive(args, dev, world, rank):
+    return bench_adaptive_isolated("adaptive_b8", args, dev, world, rank)
+
+
+def bench_adaptive_b1(args, dev, world, rank):
+    return bench_adaptive_isolated("adaptive_b1", args, dev, world, rank)
+
+
+def bench_adaptive_pointrend(args, dev, world, rank):
+    return bench_adaptive_isolated("pointrend", args, dev, world, rank)
 
 
 def bench_occupancy(args, dev, world, rank):
@@ -507,7 +546,12 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph "
                     "(profiling aid: rocprofv3 --pmc segfaults under graph replay on this image)")
     ap.add_argument("--ddim-steps", type=int, default=50, help="only for profiling runs; the metric is defined at 50")
+    ap.add_argument("--child-section", default=None, choices=sorted(ADAPTIVE_SECTIONS), help="internal: measure one adaptive section in this process")
+    ap.add_argument("--child-device", type=int, default=0)
+    ap.add_argument("--child-seed-rank", type=int, default=0)
     args = ap.parse_args()
+    if args.child_section:
+        return child_main(args.child_section, args.child_device, args.images, args.child_seed_rank)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on a free local port

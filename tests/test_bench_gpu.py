@@ -33,6 +33,11 @@ def test_single_gpu_line(hip_lib):
     occ = line["occupancy"]
     assert occ["value"] > 0 and occ["roofline"]["traffic"] > 0 and 0 < occ["roofline"]["frac"] < occ["roofline"]["structure_b_frac"] < 1
     assert line["adaptive_loop"]["value"] > line["adaptive_loop_b1"]["value"] > 0        # the one-image-per-call shape is a stated number
+    pr = line["adaptive_loop_pointrend"]                                    # the device PointRend-architecture plug-in, measured in a child process
+    assert 0 < pr["value"] < line["adaptive_loop"]["value"] and pr["plugin"] == "pointrend" and "child" in pr["process"]
+    seg = pr["segmentation"]
+    assert seg["forward_ms"] > 0 and 0 < seg["roofline"]["frac"] < 1 and seg["roofline"]["peak"] == 157.3
+    assert seg["detections_per_image_after_the_last_loop"] == seg["detections_cap"] == 4
 
 
 @pytest.mark.parametrize("launcher", ["torchrun", "self"])
