@@ -14,7 +14,9 @@
 //   the first m_dev[u] * rows_per_item rows are computed -- the mask heads run on however many detections each image produced without the
 //   host ever learning the number; workgroups with no valid row exit, invalid rows are neither gathered nor stored.
 // Workgroup = 4 waves, tile 128 x 128 (2 x 2 waves, 2 x 2 MFMA tiles each), 128 x 64 or 128 x 32 (4 x 1 waves); K in chunks of 32 through
-// two LDS stages (one barrier per chunk), the next chunk's global loads in flight under this chunk's MFMAs.  Per 8 k values a wave reads
+// two LDS stages (one barrier per chunk) and two register sets: a chunk's global loads are issued two chunks ahead and stored to LDS in the
+// middle of the chunk before it is used; operand addresses of the 1 x 1 / 3 x 3 layers advance incrementally on the scalar unit (a VALU
+// instruction does not overlap with the issuing wave's own MFMAs, so address arithmetic is paid in matrix-pipe time).  Per 8 k values a wave reads
 // ONE ds_read_b128 per operand tile: lanes 0-31 take k = 8g .. 8g+3, lanes 32-63 take k = 8g+4 .. 8g+7, and MFMA step e consumes element e
 // of both (the k order inside a sum is free as long as A and W agree) -- 16 MFMAs (1024 cycles) per 4 LDS reads.
 // Epilogue: the accumulators go through LDS (the two operand stages are free by then) and leave as whole rows -- float4 stores of 128 / 64 / 32
@@ -38,6 +40,11 @@ using coma::check_launch;
 using coma::fail;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // operand registers: a first-class vector value (HIP's float4 is a struct)
+
+__device__ float kZerosDev[4] = {0.f, 0.f, 0.f, 0.f};      // what an out-of-range operand load reads; reaches the kernel as an ordinary global pointer
+                                                       // (GemmArgs::zeros): selecting between a kernel-argument pointer and the symbol itself made every
+                                                       // load a flat_load and sent the register sets to scratch
 
 constexpr int kBK = 32, kLd = kBK + 4;      // LDS row stride in floats (144 B: 16-byte aligned, rows spread over the banks)
 
@@ -45,33 +52,35 @@ struct GemmArgs {
   const float* x; const float* w; const float* bias; const float* res; float* out; const int* m_dev;
   int B, H, W, C, ldx, N, Kpad, kh, kw, stride, pad, OH, OW, ldr, res_mode, ldo, relu, rows_per_item, unit_rows;
   long long M;
+  const float* zeros;                        // 16 bytes of zeros in global memory
   float* ws; int splits, nk_per, ws_ld;      // split-K: slab z of the workspace is [gridDim.x * BM][ws_ld] raw partial sums
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool UNI>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int NA = BM / 32, NB = (BN + 31) / 32;       // float4 loads per thread and chunk (A rows / W rows in steps of 32)
+  constexpr int NA = BM / 32, NB = BN / 32;
+  static_assert(BN % 32 == 0 && BM % 32 == 0, "whole 32-row load steps");       // float4 loads per thread and chunk (A rows / W rows in steps of 32)
   extern __shared__ float lds[];
   float* As = lds;                                       // [2][BM][kLd]
   float* Bs = lds + 2 * BM * kLd;                        // [2][BN][kLd]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const long long m0 = (long long)blockIdx.x * BM;
+  const int m0 = blockIdx.x * BM;                        // M < 2^31 - BM (checked by the launcher): row arithmetic in 32 bits
   const int n0 = blockIdx.y * BN;
-  const long long Mv = a.M;
+  const int Mv = (int)a.M;
   if (m0 >= Mv) return;
-  auto row_ok = [&](long long m) {
+  auto row_ok = [&](int m) __attribute__((always_inline)) {
     if (m >= Mv) return false;
     if (!a.m_dev) return true;
-    const long long u = m / a.unit_rows;
-    return m - u * a.unit_rows < (long long)a.m_dev[u] * a.rows_per_item;
+    const unsigned u = (unsigned)m / (unsigned)a.unit_rows;
+    return (long long)(m - (int)u * a.unit_rows) < (long long)a.m_dev[u] * a.rows_per_item;
   };
   if (a.m_dev) {                                         // valid rows are a prefix of every unit: does any unit this tile touches have one here?
-    const long long last = (m0 + BM - 1 < Mv ? m0 + BM - 1 : Mv - 1);
+    const int last = (m0 + BM - 1 < Mv ? m0 + BM - 1 : Mv - 1);
     bool any = false;
-    for (long long u = m0 / a.unit_rows; u <= last / a.unit_rows; ++u) {
-      const long long lo = u * a.unit_rows > m0 ? u * a.unit_rows : m0;
+    for (int u = m0 / a.unit_rows; u <= last / a.unit_rows; ++u) {
+      const int lo = u * a.unit_rows > m0 ? u * a.unit_rows : m0;
       any = any || row_ok(lo);
     }
     if (!any) return;
@@ -84,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
   const int ohw = a.OH * a.OW;
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const long long m = m0 + lr + 32 * j;
+    const int m = m0 + lr + 32 * j;
     if (row_ok(m)) {
-      const int b = (int)(m / ohw), rem = (int)(m - (long long)b * ohw);
+      const int b = (int)((unsigned)m / (unsigned)ohw), rem = m - b * ohw;
       const int oy = rem / a.OW, ox = rem - oy * a.OW;
       riy[j] = oy * a.stride - a.pad;
       rix[j] = ox * a.stride - a.pad;
@@ -100,34 +109,74 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
   const int kc0 = a.splits > 1 ? (int)blockIdx.z * a.nk_per : 0;
   const int nk = a.splits > 1 ? (kc0 + a.nk_per < nk_all ? a.nk_per : nk_all - kc0) : nk_all;      // >= 1 by construction of the launch
 
-  float4 ra[NA], rb[NB];
-  auto gload = [&](int kc) {
-    const int k = kc * kBK + lk;
-    const int tap = k / a.C, c = k - tap * a.C;
-    const int ky = tap / a.kw, kx = tap - ky * a.kw;
-    const bool tv = tap < ntaps;
+  f32x4 ra[NA], rb[NB];
+  // Uniform-tap path (UNI: C % 32 == 0, every layer but the stem): a chunk of 32 k values lies inside ONE tap, so (ky, kx, c0) are wave-
+  // uniform and advance incrementally -- no division in the loop, one 64-bit add per operand row (VALU instructions do not overlap with the
+  // issuing wave's own MFMAs, profiles/r01_probe_mfma_valu.txt: the per-chunk address arithmetic is paid in matrix-pipe time).
+  const float* xrow[NA];                                 // (b, oy * stride - pad, ox * stride - pad, channel lk): only dereferenced for taps in bounds
+  const float* wrow[NB];
+  int u_ky = 0, u_kx = 0, u_c0 = 0;
+  long long u_koff = 0;
+  if constexpr (UNI) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int iy = riy[j] + ky, ix = rix[j] + kx;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-        v = *reinterpret_cast<const float4*>(a.x + (rbase[j] + (long long)iy * a.W + ix) * a.ldx + c);
-      ra[j] = v;
-    }
+    for (int j = 0; j < NA; ++j) xrow[j] = a.x + (rbase[j] + (long long)riy[j] * a.W + rix[j]) * a.ldx + lk;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int n = n0 + lr + 32 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (lr + 32 * j < BN && n < a.N) v = *reinterpret_cast<const float4*>(a.w + (long long)n * a.Kpad + k);
-      rb[j] = v;
+      wrow[j] = n < a.N ? a.w + (long long)n * a.Kpad + lk : nullptr;
+    }
+    const int tap0 = (kc0 * kBK) / a.C;
+    u_c0 = kc0 * kBK - tap0 * a.C;
+    u_ky = tap0 / a.kw;
+    u_kx = tap0 - u_ky * a.kw;
+    u_koff = (long long)kc0 * kBK;
+  }
+  auto gload = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], int kc) __attribute__((always_inline)) {
+    // branch-free and wait-free: an invalid tap / row / column reads 16 bytes of zeros (GemmArgs::zeros) instead -- a conditional load costs
+    // a divergent branch per load, and a select on the loaded value would make the wave wait for the load right here instead of at the LDS
+    // store one chunk later
+    if constexpr (UNI) {                                 // called once per chunk in ascending order: the running state IS chunk kc
+      const long long tapoff = ((long long)u_ky * a.W + u_kx) * a.ldx + u_c0;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int iy = riy[j] + u_ky, ix = rix[j] + u_kx;
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        ra[j] = *reinterpret_cast<const f32x4*>(ok ? xrow[j] + tapoff : a.zeros);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wrow[j] ? wrow[j] + u_koff : a.zeros);
+      u_koff += kBK;
+      u_c0 += kBK;
+      if (u_c0 >= a.C) {
+        u_c0 = 0;
+        if (++u_kx == a.kw) { u_kx = 0; ++u_ky; }
+      }
+    } else {
+      const int k = kc * kBK + lk;
+      const int tap = k / a.C, c = k - tap * a.C;
+      const int ky = tap / a.kw, kx = tap - ky * a.kw;
+      const bool tv = tap < ntaps;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int iy = riy[j] + ky, ix = rix[j] + kx;
+        const bool ok = tv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const float* src = ok ? a.x + (rbase[j] + (long long)iy * a.W + ix) * a.ldx + c : a.zeros;
+        ra[j] = *reinterpret_cast<const f32x4*>(src);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int n = n0 + lr + 32 * j;
+        const bool ok = n < a.N;                          // rows lr + 32 j >= BN do not exist: NB * 32 == BN for every instantiated tile
+        const float* src = ok ? a.w + (long long)n * a.Kpad + k : a.zeros;
+        rb[j] = *reinterpret_cast<const f32x4*>(src);
+      }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *reinterpret_cast<float4*>(As + (buf * BM + lr + 32 * j) * kLd + lk) = ra[j];
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(As + (buf * BM + lr + 32 * j) * kLd + lk) = ra[j];
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (lr + 32 * j < BN) *reinterpret_cast<float4*>(Bs + (buf * BN + lr + 32 * j) * kLd + lk) = rb[j];
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lr + 32 * j) * kLd + lk) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -138,34 +187,49 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(kc0);
-  lstore(0);
-  __syncthreads();
   const int li = lane & 31, lh = lane >> 5;
-  for (int kc = 0; kc < nk; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < nk) gload(kc0 + kc + 1);
-    const float* Ab = As + (buf * BM + wm * TM * 32 + li) * kLd + lh * 4;
-    const float* Bb = Bs + (buf * BN + wn * TN * 32 + li) * kLd + lh * 4;
+  auto mma = [&](int buf, int g) __attribute__((always_inline)) {                       // 8 k values: one ds_read_b128 per operand tile, 4 MFMA steps on each tile pair
+    const float* Ab = As + (buf * BM + wm * TM * 32 + li) * kLd + lh * 4 + g * 8;
+    const float* Bb = Bs + (buf * BN + wn * TN * 32 + li) * kLd + lh * 4 + g * 8;
+    float4 fa[TM], fb[TN];
 #pragma unroll
-    for (int g = 0; g < kBK / 8; ++g) {
-      float4 fa[TM], fb[TN];
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * kLd);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * kLd + g * 8);
+    for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * kLd);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * kLd + g * 8);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    if (kc + 1 < nk) lstore(buf ^ 1);
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+      }
+  };
+  {
+    // two register sets: chunk kc + 2 is requested from memory at the top of chunk kc (two chunks of MFMA time to arrive) and chunk kc + 1,
+    // requested one chunk earlier, goes into the free LDS stage after the first quarter of this chunk's MFMAs -- the barrier at the end of
+    // the chunk then only synchronises; nothing waits on memory or on LDS writes there
+    f32x4 sa[NA], sb[NB];
+    gload(ra, rb, kc0);
+    lstore(ra, rb, 0);
+    if (nk > 1) gload(ra, rb, kc0 + 1);
     __syncthreads();
+    auto chunk = [&](int kc, f32x4 (&xa)[NA], f32x4 (&xb)[NB], f32x4 (&ya)[NA], f32x4 (&yb)[NB]) __attribute__((always_inline)) {   // x: holds chunk kc + 1; y: free
+      const int buf = kc & 1;
+      if (kc + 2 < nk) gload(ya, yb, kc0 + kc + 2);
+      mma(buf, 0);
+      if (kc + 1 < nk) lstore(xa, xb, buf ^ 1);
+#pragma unroll
+      for (int g = 1; g < kBK / 8; ++g) mma(buf, g);
+      __syncthreads();
+    };
+    int kc = 0;
+    for (; kc + 1 < nk; kc += 2) {
+      chunk(kc, ra, rb, sa, sb);
+      chunk(kc + 1, sa, sb, ra, rb);
+    }
+    if (kc < nk) chunk(kc, ra, rb, sa, sb);
   }
 
   // ---- epilogue through LDS: D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] -> Cs[BM][BN + 8] (the row stride puts the two
@@ -189,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     for (int p = 0; p < BM / RPP; ++p) {
       const int row = p * RPP + rr;
       if (!row_ok(m0 + row)) continue;
-      *reinterpret_cast<float4*>(slab + (m0 + row) * a.ws_ld + col) = *reinterpret_cast<const float4*>(Cs + row * CLD + (tid % LPR) * 4);
+      *reinterpret_cast<float4*>(slab + (long long)(m0 + row) * a.ws_ld + col) = *reinterpret_cast<const float4*>(Cs + row * CLD + (tid % LPR) * 4);
     }
     return;
   }
@@ -201,16 +265,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 #pragma unroll 4
   for (int p = 0; p < BM / RPP; ++p) {
     const int row = p * RPP + rr;
-    const long long m = m0 + row;
-    if (!row_ok(m)) continue;
+    const int mi = m0 + row;
+    if (!row_ok(mi)) continue;
+    const long long m = mi;
     const float4 c4 = *reinterpret_cast<const float4*>(Cs + row * CLD + (tid % LPR) * 4);
     float v[4] = {c4.x + bv[0], c4.y + bv[1], c4.z + bv[2], c4.w + bv[3]};
     const float* rp = nullptr;
     if (a.res_mode == 1) {
       rp = a.res + m * a.ldr + col;
     } else if (a.res_mode == 2) {                        // nearest x2 up-sampling of a [B, OH / 2, OW / 2] tensor
-      const int b = (int)(m / ohw), rem = (int)(m - (long long)b * ohw);
-      const int oy = rem / a.OW, ox = rem - oy * a.OW;
+      const int b = (int)((unsigned)mi / (unsigned)ohw), rem = mi - b * ohw;
+      const int oy = (int)((unsigned)rem / (unsigned)a.OW), ox = rem - oy * a.OW;
       rp = a.res + (((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + col;
     }
     if (vec) {
@@ -272,23 +337,33 @@ __global__ __launch_bounds__(256) void seg_splitk_reduce_kernel(const GemmArgs a
 
 constexpr int kSlots = 512;               // 256 CUs x 2 resident workgroups
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool UNI>
 static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_bytes) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr size_t lds = (size_t)2 * (BM + BN) * kLd * sizeof(float);
   static_assert((size_t)BM * (BN + 8) * sizeof(float) <= lds, "the epilogue staging tile must fit into the operand stages");
   static coma::LdsOptIn opt;
   if (lds > 65536)
-    if (int rc = coma::opt_in_lds(opt, (const void*)conv_gemm_f32_kernel<WM, WN, TM, TN>, lds, "seg_conv_gemm_f32")) return rc;
+    if (int rc = coma::opt_in_lds(opt, (const void*)conv_gemm_f32_kernel<WM, WN, TM, TN, UNI>, lds, "seg_conv_gemm_f32")) return rc;
   const long long gx = (a.M + BM - 1) / BM;
   const int gy = (a.N + BN - 1) / BN;
-  if (gx > 0x7fffffffLL || gy > 65535) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: grid too large");
+  if (a.M >= 0x7fffffffLL - BM || gy > 65535) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: M=%lld rows / %d column tiles exceed the kernel's 32-bit row arithmetic", a.M, gy);
   // split-K: only where the tiles leave more than half of the chip idle and every slice keeps >= 4 chunks (128 k values)
   const int nk = a.Kpad / kBK;
   const long long tiles = gx * gy;
   int S = 1;
   if (force_split > 0) S = force_split;
-  else if (force_split == 0 && a.ws && tiles * 2 <= kSlots && nk >= 8) S = (int)std::min<long long>(kSlots / tiles, nk / 4);
+  else if (force_split == 0 && a.ws && tiles < kSlots && nk >= 8) {
+    // cost model in units of "one chunk with two workgroups per CU": a launch of W = tiles * S workgroups of nk / S chunks (+ 3 for prologue,
+    // epilogue and its share of the reduce pass) runs max(1, W / 512) rounds; a launch that leaves CUs with one workgroup or none is as slow
+    // as its CUs with two.  Keep every slice >= 4 chunks.
+    double best = (nk + 3.0) * 1.0;
+    for (int c = 2; c <= 16 && nk / c >= 4; ++c) {
+      const double w = (double)tiles * c / kSlots;
+      const double cost = ((double)nk / c + 3.0) * (w > 1.0 ? w : 1.0);
+      if (cost < best * 0.95) { best = cost; S = c; }
+    }
+  }
   a.ws_ld = gy * BN;
   const long long slab = gx * BM * (long long)a.ws_ld;
   if (S > 1 && a.ws) S = (int)std::min<long long>(S, (long long)(ws_bytes / sizeof(float)) / slab);
@@ -300,7 +375,7 @@ static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_b
     a.nk_per = (nk + S - 1) / S;
     a.splits = (nk + a.nk_per - 1) / a.nk_per;            // every slice non-empty
   }
-  hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN>), dim3((unsigned)gx, (unsigned)gy, (unsigned)a.splits), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN, UNI>), dim3((unsigned)gx, (unsigned)gy, (unsigned)a.splits), dim3(256), lds, st, a);
   if (int rc = check_launch("seg::conv_gemm_f32_kernel")) return rc;
   if (a.splits > 1) {
     const long long n = a.M * ((a.N + 3) / 4);
@@ -350,14 +425,24 @@ extern "C" int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream) {
   if (a.ldo < d->n) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: ldo=%d < n=%d", a.ldo, d->n);
   if (d->split_k < -1 || (d->workspace && d->workspace_bytes < 16)) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: split_k=%d workspace_bytes=%zu", d->split_k, d->workspace_bytes);
   a.ws = (float*)d->workspace; a.splits = 1; a.nk_per = 0; a.ws_ld = 0;
+  static const float* zeros = [] { void* p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(kZerosDev)) == hipSuccess ? (const float*)p : nullptr; }();
+  if (!zeros) return fail(COMA_E_DEVICE, "seg_conv_gemm_f32: hipGetSymbolAddress(kZerosDev) failed");
+  a.zeros = zeros;
   const int fs = d->split_k;                     // 0 = by the rule above, -1 = never, S > 1 = exactly S slices (tests)
   const size_t wb = d->workspace_bytes;
   hipStream_t st = (hipStream_t)stream;
   // tile: 0 = by width (n <= 32: 128 x 32, n <= 64: 128 x 64, else 128 x 128); 1 / 2 / 3 force 128 x 128 / 128 x 64 / 128 x 32 (tests)
   int tile = d->tile;
   if (tile == 0) tile = d->n <= 32 ? 3 : (d->n <= 64 ? 2 : 1);
-  if (tile == 1) return launch_gemm<2, 2, 2, 2>(a, st, fs, wb);
-  if (tile == 2) return launch_gemm<4, 1, 1, 2>(a, st, fs, wb);
-  if (tile == 3) return launch_gemm<4, 1, 1, 1>(a, st, fs, wb);
+  // uniform-tap addressing wherever a 32-wide K chunk lies inside one tap (every layer but the stem, C = 4, and the point head, C = 336)
+  if (d->c % kBK == 0) {
+    if (tile == 1) return launch_gemm<2, 2, 2, 2, true>(a, st, fs, wb);
+    if (tile == 2) return launch_gemm<4, 1, 1, 2, true>(a, st, fs, wb);
+    if (tile == 3) return launch_gemm<4, 1, 1, 1, true>(a, st, fs, wb);
+  } else {
+    if (tile == 1) return launch_gemm<2, 2, 2, 2, false>(a, st, fs, wb);
+    if (tile == 2) return launch_gemm<4, 1, 1, 2, false>(a, st, fs, wb);
+    if (tile == 3) return launch_gemm<4, 1, 1, 1, false>(a, st, fs, wb);
+  }
   return fail(COMA_E_INVALID, "seg_conv_gemm_f32: tile=%d", d->tile);
 }

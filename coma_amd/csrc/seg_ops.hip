@@ -255,17 +255,27 @@ __global__ __launch_bounds__(1024) void sort_candidates_kernel(const u64* keys, 
   extern __shared__ unsigned char smem[];
   u64* K = reinterpret_cast<u64*>(smem);                       // [cap]
   unsigned short* S = reinterpret_cast<unsigned short*>(smem + (size_t)cap * 8);      // [cap]
-  __shared__ int nv;
+  __shared__ int nv, last;
   const int b = blockIdx.x;
-  if (threadIdx.x == 0) nv = 0;
-  for (int i = threadIdx.x; i < cap; i += blockDim.x) {
-    K[i] = keys[(long long)b * cap + i];
-    S[i] = (unsigned short)i;
-  }
+  if (threadIdx.x == 0) { nv = 0; last = -1; }
   __syncthreads();
-  for (int size = 2; size <= cap; size <<= 1) {
+  int mylast = -1;
+  for (int i = threadIdx.x; i < cap; i += blockDim.x) {
+    const u64 kx = keys[(long long)b * cap + i];
+    K[i] = kx;
+    S[i] = (unsigned short)i;
+    if (kx != ~0ull) mylast = i;
+  }
+  if (mylast >= 0) atomicMax(&last, mylast);
+  __syncthreads();
+  // only the slots up to the last valid key take part: everything behind it is ~0 and already sits where an ascending sort would put it
+  // (the detection candidates fill a few hundred of the 8192 slots: 9 instead of 13 bitonic stages)
+  int P = 64;
+  while (P < last + 1) P <<= 1;
+  if (P > cap) P = cap;
+  for (int size = 2; size <= P; size <<= 1) {
     for (int strd = size >> 1; strd > 0; strd >>= 1) {
-      for (int t = threadIdx.x; t < cap / 2; t += blockDim.x) {
+      for (int t = threadIdx.x; t < P / 2; t += blockDim.x) {
         const int lo = 2 * t - (t & (strd - 1));
         const int hi = lo + strd;
         const bool up = (lo & size) == 0;
