@@ -19,7 +19,7 @@ for f in glob.glob(os.path.join(root, "trace", "*kernel_stats.csv")):
             w.writerow(row)
 src = os.path.join(root, "pmc_summary.txt")
 if os.path.exists(src):
-    keep = [l for l in open(src).read().splitlines() if l.startswith("==") or "coma::" in l or "sd::" in l or "_ZN2sd" in l]
+    keep = [l for l in open(src).read().splitlines() if l.startswith("==") or "coma::" in l or "sd::" in l or "_ZN2sd" in l or "seg::" in l]
     open(os.path.join("profiles", f"{rnd}_{tag}_pmc.txt"), "w").write(
         "# rocprofv3 --pmc passes (one counter group per pass), mean per dispatch; FETCH_SIZE/WRITE_SIZE in KiB.\n"
         "# gfx950: FETCH_SIZE reads 1/2 of the bytes of a coalesced stream (MI355X_MICROARCH.md, HBM) -> double it.\n"
@@ -27,4 +27,7 @@ if os.path.exists(src):
 j = os.path.join(root, "bench_line_under_profiler.json")
 if os.path.exists(j):
     shutil.copy(j, os.path.join("profiles", f"{rnd}_{tag}_bench_line_under_profiler.json"))
+t = os.path.join(root, "time_seg.log")
+if os.path.exists(t):          # the per-launch HIP-event table of scripts/time_seg.py taken in the same call
+    shutil.copy(t, os.path.join("profiles", f"{rnd}_{tag}_per_launch.txt"))
 print(open(os.path.join("profiles", f"{rnd}_{tag}_kernel_stats.csv")).read()[:1500])

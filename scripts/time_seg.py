@@ -20,8 +20,13 @@ def main():
     from coma_amd.seg.predictor import HipPointRendPredictor
     dev = torch.device("cuda:0")
     state = SW.random_state(seed=0, cls_gain=0.2, delta_gain=0.1, person_bias=3.0)
-    pred = HipPointRendPredictor(pointrend_thres=0.2, device=dev, state=state, detections_per_image=forced)
-    plan = pred.pointrend_seg_model.plan(batch, 512, 512)
+    eager_only = "--eager-only" in sys.argv          # counter passes: rocprofv3 --pmc segfaults under hipGraph replay on this image
+    if eager_only:
+        from coma_amd.seg.model import HipPointRend
+        plan = HipPointRend(state, batch, 512, 512, dev, score_thresh=0.2, keep_masks=False, use_graph=False, detections_per_image=forced)
+    else:
+        pred = HipPointRendPredictor(pointrend_thres=0.2, device=dev, state=state, detections_per_image=forced)
+        plan = pred.pointrend_seg_model.plan(batch, 512, 512)
     g = torch.Generator().manual_seed(9)
     low = torch.rand(batch, 3, 16, 16, generator=g)
     img = (torch.nn.functional.interpolate(low, size=(512, 512), mode="bicubic").clamp(0, 1) * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().to(dev)
@@ -29,7 +34,7 @@ def main():
     plan(img)
     torch.cuda.synchronize()
     print("detections per image:", out["count"].tolist(), " proposals:", plan.t["prop_count"].tolist())
-    for rep in range(3):
+    for rep in range(0 if eager_only else 3):
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):
