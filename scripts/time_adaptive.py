@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Where the adaptive-mask loop spends its time (batch of 8 images): plug-in host time vs everything else."""
+"""Where the adaptive-mask loop spends its time (batch of AB images: python scripts/time_adaptive.py [AB]): plug-in host time vs everything else."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from coma_amd.sd.pipeline import AdaptiveMaskInpaintPipeline, SyntheticHumanMaskPredictor, default_adaptive_mask_settings
 dev = "cuda:0"
-AB = 8
+AB = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 pipe = AdaptiveMaskInpaintPipeline.from_random(batch_size=AB, height=512, width=512, device=dev, seed=0)
 
 
