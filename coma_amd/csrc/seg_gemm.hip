@@ -53,10 +53,11 @@ struct GemmArgs {
   int B, H, W, C, ldx, N, Kpad, kh, kw, stride, pad, OH, OW, ldr, res_mode, ldo, relu, rows_per_item, unit_rows;
   long long M;
   const float* zeros;                        // 16 bytes of zeros in global memory
-  float* ws; int splits, nk_per, ws_ld;      // split-K: slab z of the workspace is [gridDim.x * BM][ws_ld] raw partial sums
+  float* ws; int splits, nk_per, ws_ld;      // split-K: slab z of the workspace is [gx * BM][ws_ld] raw partial sums
+  int gx, gy, band;                                                  // row / column tiles (the grid is 1-D: see the tile order in the kernel)
 };
 
-template <int WM, int WN, int TM, int TN, bool UNI>
+template <int WM, int WN, int TM, int TN, bool UNI, bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int NA = BM / 32, NB = BN / 32;
@@ -66,8 +67,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
   float* Bs = lds + 2 * BM * kLd;                        // [2][BN][kLd]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM;                        // M < 2^31 - BM (checked by the launcher): row arithmetic in 32 bits
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order: the hardware deals consecutive workgroup ids round-robin over the 8 XCDs (one L2 each).  Workgroup L of the
+  // 1-D grid runs on XCD L % 8 as that XCD's (L / 8)-th workgroup; XCD i is given the CONTIGUOUS band of tiles [start_i, start_i + count_i)
+  // of the (row tile major, column tile minor) order, so the column tiles that share an A row band -- and the neighbouring row bands whose
+  // 3 x 3 windows overlap -- are resident on ONE XCD at about the same time and the operand is pulled into one L2 instead of gy of them.
+  int tile_id;
+  {
+    const int T = a.gx * a.gy, L = (int)blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3, q = T >> 3, r = T & 7;
+    tile_id = a.band ? xcd * q + (xcd < r ? xcd : r) + slot : L;
+  }
+  int tmx, tnx;
+  if (a.band) { tmx = tile_id / a.gy; tnx = tile_id - tmx * a.gy; }       // banded: column tiles of one row band adjacent
+  else { tnx = tile_id / a.gx; tmx = tile_id - tnx * a.gx; }             // plain: row tiles fastest (the order of a 2-D grid)
+  const int m0 = tmx * BM;                               // M < 2^31 - BM (checked by the launcher): row arithmetic in 32 bits
+  const int n0 = tnx * BN;
   const int Mv = (int)a.M;
   if (m0 >= Mv) return;
   auto row_ok = [&](int m) __attribute__((always_inline)) {
@@ -206,6 +220,44 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
       }
   };
+  // ---- PRE (launches with a residual operand and no split-K): the residual rows and the bias of this thread's output pieces are requested at
+  // the top of the LAST K chunk (whose load slot is free), so their memory latency hides under that chunk's MFMAs and the LDS staging
+  // instead of being paid per group of passes after it -- the K <= 512 1 x 1 layers with a shortcut operand were 2 x off both of their
+  // floors (326 -> 220 us at K = 64, 200 -> 140 us at K = 128, profiles/r06_notes.md 5).  Rows that are not computed read the zero buffer.
+  // A separate instantiation: the 64 registers of the residual pieces put the kernel at 254 VGPRs, and the long-K layers WITHOUT a residual
+  // lost 20 % to the schedule the compiler found under that pressure (fpn_output3 761 -> 905 us) when both shared one kernel.
+  constexpr int CLD = BN + 8;
+  constexpr int LPR = BN / 4, RPP = 256 / LPR, NP = BM / RPP;      // lanes per output row, rows per pass, passes
+  const int ecol = n0 + (tid % LPR) * 4, err = tid / LPR;
+  const bool evec = ecol + 3 < a.N && !(a.ldo & 3) && (a.res_mode == 0 || !(a.ldr & 3));
+  const bool pre_res = PRE && evec;                                 // PRE launches have res_mode != 0 and splits == 1 (the launcher's rule)
+  f32x4 rres[PRE ? NP : 1];
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  auto epi_prefetch = [&]() __attribute__((always_inline)) {
+    if (a.bias && ecol < a.N) {
+      if (ecol + 3 < a.N && !((uintptr_t)a.bias & 15)) bias4 = *reinterpret_cast<const f32x4*>(a.bias + ecol);
+      else
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias4[e] = ecol + e < a.N ? a.bias[ecol + e] : 0.f;
+    }
+    if (pre_res) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int mi = m0 + p * RPP + err;
+        const float* rp = a.zeros;
+        if (row_ok(mi)) {
+          if (a.res_mode == 1) {
+            rp = a.res + (long long)mi * a.ldr + ecol;
+          } else {                                       // nearest x2 up-sampling of a [B, OH / 2, OW / 2] tensor
+            const int b = (int)((unsigned)mi / (unsigned)ohw), rem = mi - b * ohw;
+            const int oy = (int)((unsigned)rem / (unsigned)a.OW), ox = rem - oy * a.OW;
+            rp = a.res + (((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + ecol;
+          }
+        }
+        rres[PRE ? p : 0] = *reinterpret_cast<const f32x4*>(rp);
+      }
+    }
+  };
   {
     // two register sets: chunk kc + 2 is requested from memory at the top of chunk kc (two chunks of MFMA time to arrive) and chunk kc + 1,
     // requested one chunk earlier, goes into the free LDS stage after the first quarter of this chunk's MFMAs -- the barrier at the end of
@@ -213,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
     f32x4 sa[NA], sb[NB];
     gload(ra, rb, kc0);
     lstore(ra, rb, 0);
-    if (nk > 1) gload(ra, rb, kc0 + 1);
+    if (nk > 1) gload(ra, rb, kc0 + 1);                  // (requesting chunk 1 before the LDS store of chunk 0 measured neutral: not kept)
     __syncthreads();
     auto chunk = [&](int kc, f32x4 (&xa)[NA], f32x4 (&xb)[NB], f32x4 (&ya)[NA], f32x4 (&yb)[NB]) __attribute__((always_inline)) {   // x: holds chunk kc + 1; y: free
       const int buf = kc & 1;
@@ -225,16 +277,32 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
       __syncthreads();
     };
     int kc = 0;
-    for (; kc + 1 < nk; kc += 2) {
-      chunk(kc, ra, rb, sa, sb);
-      chunk(kc + 1, sa, sb, ra, rb);
+    if constexpr (PRE) {
+      for (; kc + 2 < nk; kc += 2) {
+        chunk(kc, ra, rb, sa, sb);
+        chunk(kc + 1, sa, sb, ra, rb);
+      }
+      // one or two chunks left; the last one is peeled out of the loop so that the epilogue operands requested in front of it are not
+      // loop-carried registers
+      if (kc + 2 == nk) {
+        chunk(kc, ra, rb, sa, sb);
+        epi_prefetch();
+        chunk(kc + 1, sa, sb, ra, rb);
+      } else {
+        epi_prefetch();
+        chunk(kc, ra, rb, sa, sb);
+      }
+    } else {
+      for (; kc + 1 < nk; kc += 2) {
+        chunk(kc, ra, rb, sa, sb);
+        chunk(kc + 1, sa, sb, ra, rb);
+      }
+      if (kc < nk) chunk(kc, ra, rb, sa, sb);
     }
-    if (kc < nk) chunk(kc, ra, rb, sa, sb);
   }
 
   // ---- epilogue through LDS: D[row = 8 (r / 4) + 4 (lane / 32) + r % 4][col = lane % 32] -> Cs[BM][BN + 8] (the row stride puts the two
   // lane halves, 4 rows apart, 32 banks apart: conflict-free 4-byte writes), then whole rows leave as float4
-  constexpr int CLD = BN + 8;
   float* Cs = lds;                                       // the loop's last __syncthreads() released both operand stages
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -244,57 +312,66 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
       for (int r = 0; r < 16; ++r)
         Cs[((wm * TM + i) * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)) * CLD + (wn * TN + j) * 32 + li] = acc[i][j][r];
   __syncthreads();
-  constexpr int LPR = BN / 4, RPP = 256 / LPR;           // lanes per row, rows per pass
-  const int col = n0 + (tid % LPR) * 4, rr = tid / LPR;
+  const int col = ecol, rr = err;
   if (col >= a.N) return;
+  if constexpr (!PRE) {
+    if (a.splits <= 1) epi_prefetch();                   // the bias only
+  }
   if (a.splits > 1) {                                    // raw partial sums; bias / residual / ReLU belong to the reduce pass
-    float* slab = a.ws + (long long)blockIdx.z * ((long long)gridDim.x * BM) * a.ws_ld;
+    float* slab = a.ws + (long long)blockIdx.z * ((long long)a.gx * BM) * a.ws_ld;
 #pragma unroll 4
-    for (int p = 0; p < BM / RPP; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int row = p * RPP + rr;
       if (!row_ok(m0 + row)) continue;
       *reinterpret_cast<float4*>(slab + (long long)(m0 + row) * a.ws_ld + col) = *reinterpret_cast<const float4*>(Cs + row * CLD + (tid % LPR) * 4);
     }
     return;
   }
-  const bool vec = col + 3 < a.N && !(a.ldo & 3) && (a.res_mode == 0 || !(a.ldr & 3));
-  float bv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias)
+  if (evec) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = col + e < a.N ? a.bias[col + e] : 0.f;
-#pragma unroll 4
-  for (int p = 0; p < BM / RPP; ++p) {
+    for (int p = 0; p < NP; ++p) {
+      const int row = p * RPP + rr;
+      const int mi = m0 + row;
+      if (!row_ok(mi)) continue;
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(Cs + row * CLD + (tid % LPR) * 4);
+      f32x4 v = c4 + bias4;                              // (acc + bias) + residual: the order of the reduce pass and of the scalar tail below
+      if (pre_res) v += rres[PRE ? p : 0];
+      else if (a.res_mode == 1) v += *reinterpret_cast<const f32x4*>(a.res + (long long)mi * a.ldr + col);
+      else if (a.res_mode == 2) {
+        const int b = (int)((unsigned)mi / (unsigned)ohw), rem = mi - b * ohw;
+        const int oy = (int)((unsigned)rem / (unsigned)a.OW), ox = rem - oy * a.OW;
+        v += *reinterpret_cast<const f32x4*>(a.res + (((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + col);
+      }
+      if (a.relu)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      *reinterpret_cast<f32x4*>(a.out + (long long)mi * a.ldo + col) = v;
+    }
+    return;
+  }
+  // ragged tail (N or a leading dimension not a multiple of 4): scalar stores, the residual read here
+#pragma unroll 2
+  for (int p = 0; p < NP; ++p) {
     const int row = p * RPP + rr;
     const int mi = m0 + row;
     if (!row_ok(mi)) continue;
     const long long m = mi;
     const float4 c4 = *reinterpret_cast<const float4*>(Cs + row * CLD + (tid % LPR) * 4);
-    float v[4] = {c4.x + bv[0], c4.y + bv[1], c4.z + bv[2], c4.w + bv[3]};
+    const float v[4] = {c4.x + bias4[0], c4.y + bias4[1], c4.z + bias4[2], c4.w + bias4[3]};
     const float* rp = nullptr;
     if (a.res_mode == 1) {
       rp = a.res + m * a.ldr + col;
-    } else if (a.res_mode == 2) {                        // nearest x2 up-sampling of a [B, OH / 2, OW / 2] tensor
+    } else if (a.res_mode == 2) {
       const int b = (int)((unsigned)mi / (unsigned)ohw), rem = mi - b * ohw;
       const int oy = (int)((unsigned)rem / (unsigned)a.OW), ox = rem - oy * a.OW;
       rp = a.res + (((long long)b * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1)) * a.ldr + col;
     }
-    if (vec) {
-      if (rp) {
-        const float4 r4 = *reinterpret_cast<const float4*>(rp);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-      }
-      if (a.relu)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-      *reinterpret_cast<float4*>(a.out + m * a.ldo + col) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (col + e >= a.N) break;
-        float x = v[e] + (rp ? rp[e] : 0.f);
-        if (a.relu) x = x > 0.f ? x : 0.f;
-        a.out[m * a.ldo + col + e] = x;
-      }
+    for (int e = 0; e < 4; ++e) {
+      if (col + e >= a.N) break;
+      float x = v[e] + (rp ? rp[e] : 0.f);
+      if (a.relu) x = x > 0.f ? x : 0.f;
+      a.out[m * a.ldo + col + e] = x;
     }
   }
 }
@@ -343,24 +420,30 @@ static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_b
   constexpr size_t lds = (size_t)2 * (BM + BN) * kLd * sizeof(float);
   static_assert((size_t)BM * (BN + 8) * sizeof(float) <= lds, "the epilogue staging tile must fit into the operand stages");
   static coma::LdsOptIn opt;
-  if (lds > 65536)
-    if (int rc = coma::opt_in_lds(opt, (const void*)conv_gemm_f32_kernel<WM, WN, TM, TN, UNI>, lds, "seg_conv_gemm_f32")) return rc;
+  static coma::LdsOptIn opt_pre;
+  if (lds > 65536) {
+    if (int rc = coma::opt_in_lds(opt, (const void*)conv_gemm_f32_kernel<WM, WN, TM, TN, UNI, false>, lds, "seg_conv_gemm_f32")) return rc;
+    if (int rc = coma::opt_in_lds(opt_pre, (const void*)conv_gemm_f32_kernel<WM, WN, TM, TN, UNI, true>, lds, "seg_conv_gemm_f32")) return rc;
+  }
   const long long gx = (a.M + BM - 1) / BM;
   const int gy = (a.N + BN - 1) / BN;
-  if (a.M >= 0x7fffffffLL - BM || gy > 65535) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: M=%lld rows / %d column tiles exceed the kernel's 32-bit row arithmetic", a.M, gy);
+  if (a.M >= 0x7fffffffLL - BM || gx * gy >= 0x7fffffffLL) return fail(COMA_E_INVALID, "seg_conv_gemm_f32: M=%lld rows / %d column tiles exceed the kernel's 32-bit row arithmetic", a.M, gy);
   // split-K: only where the tiles leave more than half of the chip idle and every slice keeps >= 4 chunks (128 k values)
   const int nk = a.Kpad / kBK;
   const long long tiles = gx * gy;
   int S = 1;
   if (force_split > 0) S = force_split;
   else if (force_split == 0 && a.ws && tiles < kSlots && nk >= 8) {
-    // cost model in units of "one chunk with two workgroups per CU": a launch of W = tiles * S workgroups of nk / S chunks (+ 3 for prologue,
-    // epilogue and its share of the reduce pass) runs max(1, W / 512) rounds; a launch that leaves CUs with one workgroup or none is as slow
-    // as its CUs with two.  Keep every slice >= 4 chunks.
+    // cost model in units of "one chunk with two workgroups per CU" (~3.5 us on a 128 x 128 tile): a launch of W = tiles * S workgroups of
+    // nk / S chunks (+ 3 for prologue and epilogue) runs max(1, W / 512) rounds -- a launch that leaves CUs with one workgroup or none is as
+    // slow as its CUs with two -- and a split launch pays the reduce pass: a second launch (~3 units) that reads S slabs and the GEMM's
+    // writes of them at ~4 TB/s.  (Without the reduce term the point head, 392 tiles x 11 chunks, was split in two: 78 us against 58 us
+    // unsplit, profiles/r06_notes.md 5.)  Keep every slice >= 4 chunks.
     double best = (nk + 3.0) * 1.0;
+    const double slab_units = 8.0 * (double)a.M * a.N / 4.0e6 / 3.5 * ((double)BM * BN / (128.0 * 128.0));
     for (int c = 2; c <= 16 && nk / c >= 4; ++c) {
       const double w = (double)tiles * c / kSlots;
-      const double cost = ((double)nk / c + 3.0) * (w > 1.0 ? w : 1.0);
+      const double cost = ((double)nk / c + 3.0) * (w > 1.0 ? w : 1.0) + 3.0 + c * slab_units;
       if (cost < best * 0.95) { best = cost; S = c; }
     }
   }
@@ -375,7 +458,16 @@ static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_b
     a.nk_per = (nk + S - 1) / S;
     a.splits = (nk + a.nk_per - 1) / a.nk_per;            // every slice non-empty
   }
-  hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN, UNI>), dim3((unsigned)gx, (unsigned)gy, (unsigned)a.splits), dim3(256), lds, st, a);
+  a.gx = (int)gx; a.gy = gy;
+  static const int band_env = getenv("SEG_XCD_BAND") ? atoi(getenv("SEG_XCD_BAND")) : -1;      // A/B aid: 0 = plain order, 1 = banded everywhere
+  a.band = band_env >= 0 ? band_env : 1;
+  static const int pre_env = getenv("SEG_EPI_PREFETCH") ? atoi(getenv("SEG_EPI_PREFETCH")) : 1;  // A/B aid: 0 = residual read inside the epilogue
+  // (only for K <= 128: from K = 256 on the K loop hides the epilogue of the co-resident workgroup anyway, and the 254-register kernel
+  // is the slower one -- res5.x.conv3, K = 512: 124 us without, 146 us with)
+  if (a.res_mode != 0 && a.splits == 1 && nk <= 4 && pre_env)
+    hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN, UNI, true>), dim3((unsigned)(gx * gy), 1, 1), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((conv_gemm_f32_kernel<WM, WN, TM, TN, UNI, false>), dim3((unsigned)(gx * gy), 1, (unsigned)a.splits), dim3(256), lds, st, a);
   if (int rc = check_launch("seg::conv_gemm_f32_kernel")) return rc;
   if (a.splits > 1) {
     const long long n = a.M * ((a.N + 3) / 4);
@@ -433,7 +525,19 @@ extern "C" int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // tile: 0 = by width (n <= 32: 128 x 32, n <= 64: 128 x 64, else 128 x 128); 1 / 2 / 3 force 128 x 128 / 128 x 64 / 128 x 32 (tests)
   int tile = d->tile;
-  if (tile == 0) tile = d->n <= 32 ? 3 : (d->n <= 64 ? 2 : 1);
+  if (tile == 0) {
+    tile = d->n <= 32 ? 3 : (d->n <= 64 ? 2 : 1);
+    if (tile == 1) {
+      // mid-size launches: 128 x 64 tiles when the 128 x 128 grid leaves the last CU round mostly empty.  Per-CU model: a CU works through
+      // ceil(tiles / 256) tiles; a 128 x 64 tile costs 0.5 (short K: prologue / epilogue bound) ... 0.6 (K >= 2048: it re-reads its A rows
+      // from LDS for half the columns) of a 128 x 128 one.  Measured on the plan's shapes (profiles/r06_notes.md 5): res3.x.conv2 241 -> 212 us,
+      // res3.x.conv1 116 -> 103, res4.x.conv1 141 -> 119, res5.x.conv3 147 -> 123; the large layers (fpn_output2 / 3, box_fc1, res2) stay.
+      const long long t1 = ((a.M + 127) / 128) * ((d->n + 127) / 128), t2 = ((a.M + 127) / 128) * ((d->n + 63) / 64);
+      const double nk = d->kpad / 32.0;
+      const double r = 0.5 + 0.1 * (nk < 64.0 ? nk / 64.0 : 1.0);
+      if ((double)((t2 + 255) / 256) * r < (double)((t1 + 255) / 256)) tile = 2;
+    }
+  }
   // uniform-tap addressing wherever a 32-wide K chunk lies inside one tap (every layer but the stem, C = 4, and the point head, C = 336)
   if (d->c % kBK == 0) {
     if (tile == 1) return launch_gemm<2, 2, 2, 2, true>(a, st, fs, wb);

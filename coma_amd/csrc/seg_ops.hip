@@ -362,9 +362,11 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* mask, const flo
   const long long base = (long long)b * cap;
   u64 rem0 = 0, rem1 = 0;
   int cnt = 0;
+  u64 diag_next = lane < n ? mask[(base + lane) * W] : 0ull;
   for (int blk = 0; blk < nwords && cnt < max_keep; ++blk) {
     const int row = blk * 64 + lane;
-    const u64 diag = row < n ? mask[(base + row) * W + blk] : 0ull;
+    const u64 diag = diag_next;                                    // the next block's diagonal word is already on its way while this block resolves
+    diag_next = (blk + 1 < nwords && row + 64 < n) ? mask[(base + row + 64) * W + blk + 1] : 0ull;
     u64 rw = blk < 64 ? bcast64(rem0, blk) : bcast64(rem1, blk - 64);
     u64 keep = 0;
     const int jmax = min(64, n - blk * 64);
@@ -374,12 +376,24 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* mask, const flo
         rw |= bcast64(diag, j);
       }
     }
+    // removal rows of the kept candidates, FOUR rows (eight independent loads) in flight at a time: one wave walks ~1000 kept rows per image
+    // and a load-wait-OR per row was most of this kernel's 0.5 ms
+    const bool h0 = lane > blk && lane < nwords, h1 = lane + 64 > blk && lane + 64 < nwords;      // words behind the diagonal (the others were never written)
     for (u64 kb = keep; kb;) {
-      const int j = __builtin_ctzll(kb);
-      kb &= kb - 1;
-      const long long r = (base + blk * 64 + j) * W;
-      if (lane > blk && lane < nwords) rem0 |= mask[r + lane];
-      if (lane + 64 > blk && lane + 64 < nwords) rem1 |= mask[r + lane + 64];
+      u64 v0[4], v1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v0[q] = v1[q] = 0ull;
+        if (kb) {
+          const int j = __builtin_ctzll(kb);
+          kb &= kb - 1;
+          const long long r = (base + blk * 64 + j) * W;
+          if (h0) v0[q] = mask[r + lane];
+          if (h1) v1[q] = mask[r + lane + 64];
+        }
+      }
+      rem0 |= (v0[0] | v0[1]) | (v0[2] | v0[3]);
+      rem1 |= (v1[0] | v1[1]) | (v1[2] | v1[3]);
     }
     if ((keep >> lane) & 1ull) {
       const int pos = cnt + __popcll(keep & ((1ull << lane) - 1));

@@ -14,6 +14,9 @@ from .model import BUF_ZEROED, SdModel
 
 F16 = torch.float16
 _TORCH_GRAPH = __import__("os").environ.get("SD_TORCH_GRAPH") == "1"
+# GroupNorm statistics ride on the producer's epilogue from this many output rows on (below, the GEMMs are split-K launches whose reduce pass
+# owns the epilogue, and a one-launch GroupNorm is as cheap as the finalize + apply pair); SD_GN_STATS_MIN_M=<rows> for A/B runs
+GN_STATS_MIN_M = int(__import__("os").environ.get("SD_GN_STATS_MIN_M", 16384))
 
 
 class LaunchGraph:
@@ -68,7 +71,7 @@ class LaunchGraph:
         M = batch * oh * ow
         alg_flops = kw.pop("alg_flops", None)
         tag_note = kw.pop("tag_note", "")
-        if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= 16384 and M % 32 == 0:
+        if kw.pop("stats", False) and self.fuse_gn_stats and z == 1 and M >= GN_STATS_MIN_M and M % 32 == 0:
             cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
             kw["colstats"] = cs
             self._colstats[out.data_ptr()] = cs
@@ -91,7 +94,7 @@ class LaunchGraph:
         M = batch * in_h * in_w
         ws = upsample_phase_weights(w_raw)
         cs = None
-        if stats and self.fuse_gn_stats and 4 * M >= 16384 and (in_h * in_w) % 32 == 0:
+        if stats and self.fuse_gn_stats and 4 * M >= GN_STATS_MIN_M and (in_h * in_w) % 32 == 0:
             cs = self.buf(4 * M // 32, 2, n, dtype=torch.float32, zero=True)          # 4 M / 32 slots: phase p of sample b owns a quarter of b's range
             self._colstats[out.data_ptr()] = cs
         for ph in range(4):
@@ -146,7 +149,7 @@ class LaunchGraph:
         vscale: the scale the producer of V applied (the planes are WINO_USCALE * vscale times the true products)."""
         mscale = 1.0 / (self.WINO_USCALE * vscale)
         cs, M = None, batch * h * w
-        if stats and self.fuse_gn_stats and w == 32 and n % 128 == 0 and M >= 16384:
+        if stats and self.fuse_gn_stats and w == 32 and n % 128 == 0 and M >= GN_STATS_MIN_M:
             cs = self.buf(M // 32, 2, n, dtype=torch.float32, zero=True)
             self._colstats[out.data_ptr()] = cs
         self.add(lambda: ops.winograd_output(P, out, batch=batch, h=h, w=w, n=n, bias=bias, bias_bn=bias_bn, ldbb=ldbb, res=res, colstats=cs, mscale=mscale),
@@ -243,7 +246,7 @@ class LaunchGraph:
     def xtail(self, n3, h2, x, w1, b1, w2, b2, wpo, bpo, out, *, rows):
         c = 320
         cs = None
-        if self.fuse_gn_stats and rows >= 16384:        # the next GroupNorm takes its statistics from these column sums
+        if self.fuse_gn_stats and rows >= GN_STATS_MIN_M:        # the next GroupNorm takes its statistics from these column sums
             cs = self.buf(rows // 32, 2, c, dtype=torch.float32, zero=True)
             self._colstats[out.data_ptr()] = cs
         self.add(lambda: ops.xtail(n3, h2, x, w1, b1, w2, b2, wpo, bpo, out, cs, rows=rows),

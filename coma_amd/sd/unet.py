@@ -35,6 +35,9 @@ class _Cfg(dict):
 GN_WINOGRAD_MIN_CG = 40     # GroupNorm folded into the Winograd input transform only for groups of >= 40 channels: a workgroup owns one (sample, group)
                             # slice, and with 20-channel groups (C = 640) its 40-byte pieces of every (plane, tile) row waste most of each memory
                             # transaction (48-114 us per launch at the 32 x 32 level against 18 us at C = 1280, profiles/r04_notes.md 4)
+XTAIL_MIN_ROWS = 32768      # the fused feed-forward tail (sd_xtail_f16, 128-row tiles) from one workgroup per CU on: at UNet batch 2 (8192 rows, 64
+                            # workgroups) the three separate GEMMs are 2.1 % of a forward faster (7.13 -> 6.97 ms, profiles/r06_notes.md 6), at batch 16 the
+                            # fused launch wins (r5)
 WINOGRAD_MAX_H = 32         # ResNet 3x3 convolutions of feature maps up to 32 x 32 with >= 640 channels run as Winograd F(2x2,3x3).  Measured inside
                             # the captured batch-16 forward (A B A B on one box, profiles/r04_notes.md 4): 19.02 ms direct, 18.18 ms with the
                             # 16 x 16 / 8 x 8 levels, 18.01 ms with the 32 x 32 level as well; the 64 x 64 level (C = 320) loses.
@@ -43,7 +46,7 @@ WINOGRAD_MAX_H = 32         # ResNet 3x3 convolutions of feature maps up to 32 x
 class HipUNet2DConditionModel:
     def __init__(self, state, batch, height=64, width=64, ctx_len=77, device="cuda", cfg=UNET_CFG, use_graph=True,
                  cfg_shared_prefix=False, fuse_xchain=True, fuse_xfront=True, fuse_xtail=True, fuse_qkv=True, winograd_max_h=None,
-                 winograd_min_batch=8):
+                 winograd_min_batch=8, xtail_min_rows=XTAIL_MIN_ROWS):
         """cfg_shared_prefix: the caller guarantees that the two halves of the batch carry IDENTICAL sample and timestep
         (classifier-free guidance: [uncond | cond] differ only in the text context, utils/adaptive_mask_inpainting.py:990).
         Everything before the first cross-attention (conv_in, the first ResNet block, the first self-attention) then
@@ -63,6 +66,7 @@ class HipUNet2DConditionModel:
         # this UNet batch on (at batch 2 -- one image per call -- the plane products are a few tiles each and the direct form is 0.7 % faster)
         self.winograd_max_h = int(os.environ.get("SD_WINOGRAD", WINOGRAD_MAX_H)) if winograd_max_h is None else int(winograd_max_h)
         self.winograd_min_batch = int(winograd_min_batch)
+        self.xtail_min_rows = int(xtail_min_rows)
         self.cfg_shared_prefix = bool(cfg_shared_prefix) and batch % 2 == 0 and cfg["down_has_attn"][0]
         self._B = batch                              # batch the block builders currently emit launches for
         self.dtype = F16
@@ -305,7 +309,7 @@ class HipUNet2DConditionModel:
                    bias=s[t + ".attn2.to_out.0.bias"], res=h1)
         # ---- feed-forward (GEGLU)
         wff, bff = geglu_interleave(s[t + ".ff.net.0.proj.weight"], s[t + ".ff.net.0.proj.bias"])
-        if xchain and self.fuse_xtail and M % 128 == 0:
+        if xchain and self.fuse_xtail and M % 128 == 0 and M >= self.xtail_min_rows:
             # ... and so is everything after it: feed-forward + residual + proj_out + residual in one launch, the hidden tensor never exists
             out = g.buf(M, C)
             g.xtail(n3, h2, x, wff, bff, s[t + ".ff.net.2.weight"], s[t + ".ff.net.2.bias"], conv_weight(s[p + ".proj_out.weight"]),

@@ -102,7 +102,8 @@ class HipPointRend:
         return t
 
     def _conv(self, x, name, *, batch, h, w, c, kh=1, stride=1, pad=0, relu=False, res=None, res_mode=0, ldo=0, ldx=0, out=None, m_dev=None,
-              rows_per_item=1, unit_rows=0, tag=None):
+              rows_per_item=1, unit_rows=0, tag=None, k_alg=None):
+        """k_alg: the layer's own K where `c` includes zero padding (flop count and tag follow the layer, not the padded buffer)."""
         wt, bias = self.P[name]
         n = wt.shape[0]
         oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kh) // stride + 1
@@ -112,8 +113,8 @@ class HipPointRend:
         self.g.add(lambda: ops.conv_gemm(x, wt, out, batch=batch, in_h=h, in_w=w, c=c, n=n, kh=kh, kw=kh, stride=stride, pad=pad, out_h=oh, out_w=ow,
                                          bias=bias, res=res, res_mode=res_mode, ldo=ldo, ldx=ldx, relu=relu, m_dev=m_dev,
                                          rows_per_item=rows_per_item, unit_rows=unit_rows, workspace=self.splitk_ws),
-                   flops=2 * M * n * kh * kh * c, nbytes=4 * (batch * h * w * c + n * kh * kh * c + M * n * (2 if res is not None else 1)),
-                   tag=tag or f"seg gemm {name} M={M} N={n} K={kh * kh * c}")
+                   flops=2 * M * n * (k_alg or kh * kh * c), nbytes=4 * (batch * h * w * c + n * kh * kh * c + M * n * (2 if res is not None else 1)),
+                   tag=tag or f"seg gemm {name} M={M} N={n} K={k_alg or kh * kh * c}")
         return out, oh, ow
 
     def _build(self):
@@ -242,7 +243,11 @@ class HipPointRend:
         t.update(grid14=grid14, coarse=coarse)
         # ... then the point head on 784 points per instance and step: a regular 28 x 28 grid, then the most uncertain points of the x2 map
         NP = NR * POINTS
-        X = g.buf(4, NP, 336, dtype=F32)
+        # point-head inputs [fine 256 | coarse 80 | 16 zero columns]: rows of 352 floats, so that a 32-wide K chunk never straddles the end of
+        # a row and the GEMM takes its wave-uniform addressing path (weights are zero-padded to K = 352 by weights._pad_k; the pad columns
+        # are zeroed once, nothing writes them)
+        XW = 352
+        X = g.buf(4, NP, XW, dtype=F32, zero=True)
         wp_, bp_ = self.P["point_pred"]
         idx, coords = g.buf(NR, POINTS, dtype=I32), g.buf(NR, POINTS, 2, dtype=F32)
         s, cur = INIT_RES, None
@@ -258,14 +263,14 @@ class HipPointRend:
                 cur = g.buf(NR, s, s, dtype=F32)
             cd = coords if step > 0 else None
             g.add(lambda cd=cd: ops.point_sample(p2, X[0], fh=h2, fw=w2, c=256, per_roi=False, feat_scale=0.25, boxes=det, count=det_n, batch=B, R=D,
-                                                 coords=cd, P=POINTS, grid_side=INIT_RES, ldo=336), tag="seg point features (p2)")
+                                                 coords=cd, P=POINTS, grid_side=INIT_RES, ldo=XW), tag="seg point features (p2)")
             g.add(lambda cd=cd: ops.point_sample(coarse, X[0], fh=7, fw=7, c=80, per_roi=True, count=det_n, batch=B, R=D, coords=cd, P=POINTS,
-                                                 grid_side=INIT_RES, ldo=336, col0=256, n_copies=4, copy_stride=NP * 336), tag="seg point features (coarse)")
+                                                 grid_side=INIT_RES, ldo=XW, col0=256, n_copies=4, copy_stride=NP * XW), tag="seg point features (coarse)")
             for k in (1, 2, 3):
-                self._conv(X[k - 1], f"point_fc{k}", batch=NP, h=1, w=1, c=336, relu=True, out=X[k], ldo=336, rows_per_item=POINTS,
+                self._conv(X[k - 1], f"point_fc{k}", batch=NP, h=1, w=1, c=XW, k_alg=336, relu=True, out=X[k], ldo=XW, rows_per_item=POINTS,
                            unit_rows=D * POINTS, **gate)
             ix = idx if step > 0 else None
-            g.add(lambda cur=cur, ix=ix, s=s: ops.point_logit_scatter(X[3], wp_, bp_, det_cls, det_n, cur, ix, ldx=336, kdim=336, batch=B, R=D, P=POINTS,
+            g.add(lambda cur=cur, ix=ix, s=s: ops.point_logit_scatter(X[3], wp_, bp_, det_cls, det_n, cur, ix, ldx=XW, kdim=336, batch=B, R=D, P=POINTS,
                                                                        s=s), tag=f"seg point logits -> {s}")
             if self.debug:
                 keep, kidx = g.buf(NR, s, s, dtype=F32), g.buf(NR, POINTS, dtype=I32)

@@ -11,7 +11,9 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = "cuda:0"
 state = weights.random_state(weights.unet_shapes(), seed=0, device=dev)
 unet = HipUNet2DConditionModel(state, batch=B, height=64, width=64, device=dev, use_graph="--eager" not in sys.argv, cfg_shared_prefix="--shared" in sys.argv,
-                               fuse_xchain="--no-xchain" not in sys.argv, fuse_xfront="--no-xfront" not in sys.argv, fuse_xtail="--no-xtail" not in sys.argv, fuse_qkv="--no-qkv" not in sys.argv)
+                               fuse_xchain="--no-xchain" not in sys.argv, fuse_xfront="--no-xfront" not in sys.argv, fuse_xtail="--no-xtail" not in sys.argv, fuse_qkv="--no-qkv" not in sys.argv,
+                               winograd_min_batch=int(next((a.split("=")[1] for a in sys.argv if a.startswith("--wino-min-batch=")), 8)),
+                               **({"xtail_min_rows": 0} if "--xtail-always" in sys.argv else {}))
 g = torch.Generator(device=dev).manual_seed(0)
 unet.set_context(torch.randn(B, 77, 768, generator=g, device=dev))
 unet.x_in.copy_(torch.randn(unet.x_in.shape, generator=g, device=dev).half())

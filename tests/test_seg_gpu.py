@@ -123,6 +123,15 @@ def test_linear_with_device_row_counts(hip_lib):
         if c:
             assert _rel(o[lo:mid, :256], ref[lo:mid]) <= 2e-5
         assert bool((o[mid:hi] == -5.0).all()) and bool((o[lo:mid, 256:] == -5.0).all())
+    # the plan's own layout (coma_amd/seg/model.py): rows of 352 floats with 16 zero columns, so c = 352 is a multiple of the K chunk and the
+    # wave-uniform addressing path runs -- same products in the same order, bit-identical to the 336-wide launch
+    xin2 = torch.zeros(units * unit_rows, 352)
+    xin2[:, :336] = xin
+    xin2[:, 336:] = torch.where(torch.isnan(xin[:, :1]), xin[:, :1], torch.zeros(1))          # NaN rows stay NaN everywhere
+    out2 = torch.full((units * unit_rows, 352), -5.0, device=DEV)
+    ops.conv_gemm(d(xin2), d(W._pad_k(w)), out2, batch=units * unit_rows, in_h=1, in_w=1, c=352, n=256, bias=d(b), relu=True, ldo=352,
+                  m_dev=d(np.asarray(counts), I32), rows_per_item=rpi, unit_rows=unit_rows)
+    assert torch.equal(out2.cpu()[:, :256], o[:, :256]) and bool((out2.cpu()[:, 256:] == -5.0).all())
 
 
 @pytest.mark.parametrize("split", [0, 2, 5, -1])
