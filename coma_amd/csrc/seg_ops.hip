@@ -59,9 +59,19 @@ __device__ void radix_select_desc(KeyFn key, int n, int k, u32* hist /* LDS [256
     const int shift = 24 - 8 * pass;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const u32 u = key(i);
-      if (pass == 0 || (u >> (shift + 8)) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+    // four keys per thread in flight: with one load per iteration a 120 000-key pass was 118 dependent memory latencies long
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+      u32 u[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * (int)blockDim.x;
+        u[q] = i < n ? key(i) : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * (int)blockDim.x;
+        if (i < n && (pass == 0 || (u[q] >> (shift + 8)) == prefix)) atomicAdd(&hist[(u[q] >> shift) & 255], 1u);
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -201,7 +211,6 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const float* pred, int
                                                           u64* keys, float* boxes, int* group) {
   __shared__ u32 hist[256];
   __shared__ u32 sh[2];
-  __shared__ int wsum[17];
   const int b = blockIdx.x;
   const int n = fh * fw * 3;
   const int k = n < pre_topk ? n : pre_topk;
@@ -213,39 +222,66 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const float* pred, int
   int base_gt = 0, base_eq = 0;
   // how many are strictly greater: k - r
   const int n_gt = k < n ? k - r : 0;
-  for (int i0 = 0; i0 < n; i0 += blockDim.x) {
-    const int i = i0 + threadIdx.x;
-    u32 u = 0;
-    int gt = 0, eq = 0;
-    if (i < n) {
-      u = key(i);
-      if (k >= n) gt = 1;
-      else { gt = u > T; eq = u == T; }
+  // slots in index order (ties at the threshold go to the lowest indices): FOUR strips of blockDim.x consecutive anchors per round -- four
+  // loads in flight per thread and one pair of barriers per round for both counts (one strip per round was 118 rounds x 4 barriers at p2)
+  constexpr int Q = 4;
+  __shared__ int wcnt[2][Q][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i0 = 0; i0 < n; i0 += Q * blockDim.x) {
+    u32 u[Q];
+    int gt[Q], eq[Q], rg[Q], re[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = i0 + q * (int)blockDim.x + (int)threadIdx.x;
+      u[q] = i < n ? key(i) : 0u;
     }
-    int tg, te;
-    const int rg = block_excl_scan(gt, wsum, tg);
-    const int re = block_excl_scan(eq, wsum, te);
-    int slot = -1;
-    if (gt) slot = base_gt + rg;
-    else if (eq && base_eq + re < r) slot = n_gt + base_eq + re;
-    base_gt += tg;
-    base_eq += te;
-    if (slot >= 0) {
-      const int pix = i / 3, a = i % 3;
-      const float* row = p + (long long)pix * ld;
-      const float sx = (float)((pix % fw) * stride), sy = (float)((pix / fw) * stride);
-      float anc[4] = {sx + cell[4 * a], sy + cell[4 * a + 1], sx + cell[4 * a + 2], sy + cell[4 * a + 3]};
-      float o[4];
-      decode_box(anc, row[3 + 4 * a], row[4 + 4 * a], row[5 + 4 * a], row[6 + 4 * a], 1.f, 1.f, 1.f, 1.f, o);
-      const float sc = row[a];
-      const bool fin = finitef(o[0]) && finitef(o[1]) && finitef(o[2]) && finitef(o[3]) && finitef(sc);
-      o[0] = clampf(o[0], img_w); o[2] = clampf(o[2], img_w); o[1] = clampf(o[1], img_h); o[3] = clampf(o[3], img_h);
-      const bool ok = fin && (o[2] - o[0]) > 0.f && (o[3] - o[1]) > 0.f;
-      const long long s = (long long)b * cap + cand_offset + slot;
-      keys[s] = ok ? (((u64)(~u)) << 32) | (u32)(anchor_base + i) : ~0ull;
-      boxes[4 * s] = o[0]; boxes[4 * s + 1] = o[1]; boxes[4 * s + 2] = o[2]; boxes[4 * s + 3] = o[3];
-      group[s] = level;
+    __syncthreads();                                     // the previous round's readers of wcnt are done
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = i0 + q * (int)blockDim.x + (int)threadIdx.x;
+      gt[q] = eq[q] = 0;
+      if (i < n) {
+        if (k >= n) gt[q] = 1;
+        else { gt[q] = u[q] > T; eq[q] = u[q] == T; }
+      }
+      const u64 bg = __ballot(gt[q] != 0), be = __ballot(eq[q] != 0);
+      rg[q] = __popcll(bg & ((1ull << lane) - 1));
+      re[q] = __popcll(be & ((1ull << lane) - 1));
+      if (lane == 0) { wcnt[0][q][wave] = __popcll(bg); wcnt[1][q][wave] = __popcll(be); }
     }
+    __syncthreads();
+    int run_g = base_gt, run_e = base_eq;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      int mg = run_g, me = run_e;                        // first slot of this thread's wave in strip q
+      for (int w = 0; w < nw; ++w) {
+        const int cg = wcnt[0][q][w], ce = wcnt[1][q][w];
+        if (w < wave) { mg += cg; me += ce; }
+        run_g += cg; run_e += ce;
+      }
+      int slot = -1;
+      if (gt[q]) slot = mg + rg[q];
+      else if (eq[q] && me + re[q] < r) slot = n_gt + me + re[q];
+      if (slot >= 0) {
+        const int i = i0 + q * (int)blockDim.x + (int)threadIdx.x;
+        const int pix = i / 3, a = i % 3;
+        const float* row = p + (long long)pix * ld;
+        const float sx = (float)((pix % fw) * stride), sy = (float)((pix / fw) * stride);
+        float anc[4] = {sx + cell[4 * a], sy + cell[4 * a + 1], sx + cell[4 * a + 2], sy + cell[4 * a + 3]};
+        float o[4];
+        decode_box(anc, row[3 + 4 * a], row[4 + 4 * a], row[5 + 4 * a], row[6 + 4 * a], 1.f, 1.f, 1.f, 1.f, o);
+        const float sc = row[a];
+        const bool fin = finitef(o[0]) && finitef(o[1]) && finitef(o[2]) && finitef(o[3]) && finitef(sc);
+        o[0] = clampf(o[0], img_w); o[2] = clampf(o[2], img_w); o[1] = clampf(o[1], img_h); o[3] = clampf(o[3], img_h);
+        const bool ok = fin && (o[2] - o[0]) > 0.f && (o[3] - o[1]) > 0.f;
+        const long long s = (long long)b * cap + cand_offset + slot;
+        keys[s] = ok ? (((u64)(~u[q])) << 32) | (u32)(anchor_base + i) : ~0ull;
+        boxes[4 * s] = o[0]; boxes[4 * s + 1] = o[1]; boxes[4 * s + 2] = o[2]; boxes[4 * s + 3] = o[3];
+        group[s] = level;
+      }
+    }
+    base_gt = run_g;
+    base_eq = run_e;
   }
 }
 
@@ -425,8 +461,9 @@ struct RoiArgs {
   const float* boxes; const int* count; float* out; int* level;
 };
 
-__global__ __launch_bounds__(64) void roi_align_kernel(const RoiArgs a) {
-  const int roi = blockIdx.x, bin = blockIdx.y, lane = threadIdx.x;
+// one workgroup per (ROI, row of bins), one wave per bin: 8000 x 49 single-wave workgroups were dispatch-bound (0.62 ms for 401 MB of output)
+__global__ __launch_bounds__(1024) void roi_align_kernel(const RoiArgs a) {
+  const int roi = blockIdx.x, bin = blockIdx.y * a.out_size + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int b = roi / a.R, i = roi % a.R;
   if (i >= a.count[b]) return;
   const float* bx = a.boxes + 4ll * roi;
@@ -839,7 +876,8 @@ extern "C" int seg_roi_align_f32(const void* p2, const void* p3, const void* p4,
   a.feat[0] = (const float*)p2; a.feat[1] = (const float*)p3; a.feat[2] = (const float*)p4; a.feat[3] = (const float*)p5;
   for (int l = 0; l < 4; ++l) { a.fh[l] = h2 >> l; a.fw[l] = w2 >> l; }
   a.c = c; a.R = R; a.out_size = out_size; a.boxes = (const float*)boxes; a.count = (const int*)count; a.out = (float*)out; a.level = (int*)level;
-  hipLaunchKernelGGL(roi_align_kernel, dim3(batch * R, out_size * out_size), dim3(64), 0, (hipStream_t)stream, a);
+  if (out_size > 16) return fail(COMA_E_INVALID, "seg_roi_align_f32: out_size=%d > 16 (one wave per bin of a row)", out_size);
+  hipLaunchKernelGGL(roi_align_kernel, dim3(batch * R, out_size), dim3(64 * out_size), 0, (hipStream_t)stream, a);
   return check_launch("seg::roi_align_kernel");
 }
 
