@@ -33,21 +33,32 @@ __device__ __forceinline__ float from_asc_bits(u32 a) {
 __device__ __forceinline__ bool finitef(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
 
 // ---- block-wide helpers for 1024-thread blocks (16 waves)
-__device__ __forceinline__ int block_excl_scan(int flag, int* wsum /* LDS [17] */, int& total) {
+// exclusive ranks of the set flags over Q strips of blockDim.x consecutive elements (element of strip q, thread t = base + q * blockDim.x + t):
+// index order across strips, waves, lanes; one pair of barriers for all Q strips.  wcnt: LDS [Q][16].
+template <int Q>
+__device__ __forceinline__ void strips_excl_scan(const int (&flag)[Q], int (*wcnt)[16], int (&rank)[Q], int& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const u64 b = __ballot(flag != 0);
-  const int rank = __popcll(b & ((1ull << lane) - 1));
-  __syncthreads();
-  if (lane == 0) wsum[wave] = __popcll(b);
-  __syncthreads();
-  int base = 0, tot = 0;
-  for (int w = 0; w < nw; ++w) {
-    const int c = wsum[w];
-    if (w < wave) base += c;
-    tot += c;
+  int inw[Q];
+  __syncthreads();                                       // earlier readers of wcnt are done
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const u64 b = __ballot(flag[q] != 0);
+    inw[q] = __popcll(b & ((1ull << lane) - 1));
+    if (lane == 0) wcnt[q][wave] = __popcll(b);
   }
-  total = tot;
-  return base + rank;
+  __syncthreads();
+  int run = 0;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    int mine = run;
+    for (int w = 0; w < nw; ++w) {
+      const int c = wcnt[q][w];
+      if (w < wave) mine += c;
+      run += c;
+    }
+    rank[q] = mine + inw[q];
+  }
+  total = run;
 }
 
 // k-th largest of key(i), i < n (k >= 1, k <= n): returns T and r = how many of the elements equal to T belong to the k largest
@@ -643,7 +654,6 @@ __global__ void upsample2x_kernel(const float* x, const int* count, int R, int s
 __global__ __launch_bounds__(1024) void topk_points_kernel(const float* logits, const int* count, int R, int s, int k, int* idx, float* coords) {
   __shared__ u32 hist[256];
   __shared__ u32 sh[2];
-  __shared__ int wsum[17];
   const int roi = blockIdx.x;
   if (roi % R >= count[roi / R]) return;
   const int n = s * s;
@@ -655,23 +665,39 @@ __global__ __launch_bounds__(1024) void topk_points_kernel(const float* logits, 
   int r = 0;
   if (k < n) radix_select_desc(key, n, k, hist, sh, T, r);
   int base = 0, base_eq = 0;
-  for (int i0 = 0; i0 < n; i0 += blockDim.x) {
-    const int i = i0 + threadIdx.x;
-    int gt = 0, eq = 0;
-    if (i < n) {
-      const u32 u = key(i);
-      if (k >= n) gt = 1;
-      else { gt = u > T; eq = u == T; }
+  constexpr int Q = 4;                                   // four strips per round: four loads in flight, two pairs of barriers per 4096 points
+  __shared__ int wcnt[Q][16];
+  for (int i0 = 0; i0 < n; i0 += Q * blockDim.x) {
+    int gt[Q], eq[Q], take[Q], re[Q], rt[Q];
+    u32 u[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = i0 + q * (int)blockDim.x + (int)threadIdx.x;
+      u[q] = i < n ? key(i) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int i = i0 + q * (int)blockDim.x + (int)threadIdx.x;
+      gt[q] = eq[q] = 0;
+      if (i < n) {
+        if (k >= n) gt[q] = 1;
+        else { gt[q] = u[q] > T; eq[q] = u[q] == T; }
+      }
     }
     int te, tt;
-    const int re = block_excl_scan(eq, wsum, te);
-    const int take = gt || (eq && base_eq + re < r);
-    const int rt = block_excl_scan(take, wsum, tt);
-    if (take) {
-      const long long o = (long long)roi * k + base + rt;
-      idx[o] = i;
-      coords[2 * o] = 1.f / (2.f * (float)s) + (float)(i % s) / (float)s;
-      coords[2 * o + 1] = 1.f / (2.f * (float)s) + (float)(i / s) / (float)s;
+    strips_excl_scan<Q>(eq, wcnt, re, te);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) take[q] = gt[q] || (eq[q] && base_eq + re[q] < r);
+    strips_excl_scan<Q>(take, wcnt, rt, tt);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (take[q]) {
+        const int i = i0 + q * (int)blockDim.x + (int)threadIdx.x;
+        const long long o = (long long)roi * k + base + rt[q];
+        idx[o] = i;
+        coords[2 * o] = 1.f / (2.f * (float)s) + (float)(i % s) / (float)s;
+        coords[2 * o + 1] = 1.f / (2.f * (float)s) + (float)(i / s) / (float)s;
+      }
     }
     base += tt;
     base_eq += te;

@@ -61,6 +61,9 @@ CONV_CASES = [
     (2, 12, 16, 512, 256, 1, 1, 0, False, 2, 0),      # FPN lateral + nearest-x2 top-down
     (3, 14, 14, 256, 256, 2, 2, 0, True, 0, 0),       # coarse head's 2 x 2 / stride 2
     (1, 20, 20, 256, 15, 1, 1, 0, False, 0, 0),       # RPN predictors: N = 15 (128 x 32 tile)
+    (2, 14, 14, 64, 256, 1, 1, 0, True, 1, 0),        # K <= 128 with a shortcut: the instantiation that requests residual + bias before the last K chunk
+    (2, 12, 16, 128, 256, 1, 1, 0, False, 2, 0),      # ... with the nearest-x2 top-down operand
+    (1, 10, 10, 64, 250, 1, 1, 0, True, 1, 0),        # ... ragged N (scalar tail: the residual is read in the epilogue)
     (2, 9, 9, 64, 256, 3, 1, 1, True, 0, 1),          # forced tiles on one shape
     (2, 9, 9, 64, 256, 3, 1, 1, True, 0, 2),
     (2, 9, 9, 64, 256, 3, 1, 1, True, 0, 3),
