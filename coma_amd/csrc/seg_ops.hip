@@ -81,7 +81,22 @@ __device__ void radix_select_desc(KeyFn key, int n, int k, u32* hist /* LDS [256
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = i0 + q * (int)blockDim.x;
-        if (i < n && (pass == 0 || (u[q] >> (shift + 8)) == prefix)) atomicAdd(&hist[(u[q] >> shift) & 255], 1u);
+        const u32 bin = (u[q] >> shift) & 255;
+        if (pass == 0) {
+          // the top byte (sign + 7 exponent bits) takes a handful of values: 64 lanes adding to the same LDS word serialise, so one lane adds
+          // the count of its whole group instead
+          const int lane = threadIdx.x & 63;
+          u64 todo = __ballot(i < n);
+          while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const u32 lb = (u32)__shfl((int)bin, leader);
+            const u64 same = __ballot(i < n && bin == lb);
+            if (lane == leader) atomicAdd(&hist[lb], (u32)__popcll(same));
+            todo &= ~same;
+          }
+        } else if (i < n && (u[q] >> (shift + 8)) == prefix) {
+          atomicAdd(&hist[bin], 1u);
+        }
       }
     }
     __syncthreads();
@@ -472,16 +487,18 @@ struct RoiArgs {
   const float* boxes; const int* count; float* out; int* level;
 };
 
-// one workgroup per (ROI, row of bins), one wave per bin: 8000 x 49 single-wave workgroups were dispatch-bound (0.62 ms for 401 MB of output)
+// one workgroup per ROI, one wave per bin column, the bin rows in a loop: 8000 x 49 single-wave workgroups were dispatch-bound (0.62 ms for
+// 401 MB of output), and with the rows of one ROI in seven workgroups on seven XCDs the ROI's patch of the feature map was pulled into seven
+// L2s (FETCH_SIZE 4 GB per launch, profiles/r06_seg_pmc.txt)
 __global__ __launch_bounds__(1024) void roi_align_kernel(const RoiArgs a) {
-  const int roi = blockIdx.x, bin = blockIdx.y * a.out_size + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int roi = blockIdx.x, pw = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = roi / a.R, i = roi % a.R;
   if (i >= a.count[b]) return;
   const float* bx = a.boxes + 4ll * roi;
   const float area = (bx[2] - bx[0]) * (bx[3] - bx[1]);
   const float v = sqrtf(area) / 224.f + 1e-8f;
   const int lv = (v >= 0.5f) + (v >= 1.f) + (v >= 2.f);             // = clamp(floor(4 + log2(v)), 2, 5) - 2
-  if (bin == 0 && lane == 0 && a.level) a.level[roi] = lv;
+  if (threadIdx.x == 0 && a.level) a.level[roi] = lv;
   const float scale = 1.f / (float)(4 << lv);
   const int H = a.fh[lv], W = a.fw[lv];
   const float* f = a.feat[lv] + (long long)b * H * W * a.c;
@@ -489,36 +506,60 @@ __global__ __launch_bounds__(1024) void roi_align_kernel(const RoiArgs a) {
   const float rw = x2 - x1, rh = y2 - y1;
   const float bw = rw / (float)a.out_size, bh = rh / (float)a.out_size;
   const int gh = (int)ceilf(rh / (float)a.out_size), gw = (int)ceilf(rw / (float)a.out_size);
-  const int ph = bin / a.out_size, pw = bin % a.out_size;
   const int c4 = a.c / 4;
+  for (int ph = 0; ph < a.out_size; ++ph) {
+  const int bin = ph * a.out_size + pw;
+  // one sample = four corner loads; TWO samples (eight independent loads) are requested before either is accumulated -- the sampling
+  // grid is data dependent, so the compiler cannot overlap iterations by itself; samples outside the map contribute 0 (weights zeroed,
+  // corner addresses clamped) and the sum keeps the sample order
+  struct Smp { float w1, w2, w3, w4; long long o1, o2, o3, o4; };
+  auto sample = [&](int si) __attribute__((always_inline)) {
+    Smp q;
+    const int iy = si / gw, ix = si - iy * gw;
+    float yy = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+    float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+    const bool in = !(yy < -1.f || yy > (float)H || x < -1.f || x > (float)W);
+    if (yy <= 0.f) yy = 0.f;
+    if (x <= 0.f) x = 0.f;
+    if (!in) { yy = 0.f; x = 0.f; }
+    int yl = (int)yy, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+    q.w1 = in ? hy * hx : 0.f; q.w2 = in ? hy * lx : 0.f; q.w3 = in ? ly * hx : 0.f; q.w4 = in ? ly * lx : 0.f;
+    q.o1 = ((long long)yl * W + xl) * a.c; q.o2 = ((long long)yl * W + xh) * a.c;
+    q.o3 = ((long long)yh * W + xl) * a.c; q.o4 = ((long long)yh * W + xh) * a.c;
+    return q;
+  };
+  const int ns = gh * gw;
   for (int ch = lane; ch < c4; ch += 64) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int iy = 0; iy < gh; ++iy) {
-      float y = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
-        float yy = y;
-        if (yy < -1.f || yy > (float)H || x < -1.f || x > (float)W) continue;
-        if (yy <= 0.f) yy = 0.f;
-        if (x <= 0.f) x = 0.f;
-        int yl = (int)yy, xl = (int)x, yh, xh;
-        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
-        if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
-        const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
-        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-        const float4 v1 = *reinterpret_cast<const float4*>(f + ((long long)yl * W + xl) * a.c + 4 * ch);
-        const float4 v2 = *reinterpret_cast<const float4*>(f + ((long long)yl * W + xh) * a.c + 4 * ch);
-        const float4 v3 = *reinterpret_cast<const float4*>(f + ((long long)yh * W + xl) * a.c + 4 * ch);
-        const float4 v4 = *reinterpret_cast<const float4*>(f + ((long long)yh * W + xh) * a.c + 4 * ch);
-        acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-        acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-        acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-        acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-      }
+    const float* fc = f + 4 * ch;
+    auto fma4 = [&](const Smp& q, const float4& v1, const float4& v2, const float4& v3, const float4& v4) __attribute__((always_inline)) {
+      acc.x += q.w1 * v1.x + q.w2 * v2.x + q.w3 * v3.x + q.w4 * v4.x;
+      acc.y += q.w1 * v1.y + q.w2 * v2.y + q.w3 * v3.y + q.w4 * v4.y;
+      acc.z += q.w1 * v1.z + q.w2 * v2.z + q.w3 * v3.z + q.w4 * v4.z;
+      acc.w += q.w1 * v1.w + q.w2 * v2.w + q.w3 * v3.w + q.w4 * v4.w;
+    };
+    int si = 0;
+    for (; si + 1 < ns; si += 2) {
+      const Smp p = sample(si), q = sample(si + 1);
+      const float4 a1 = *reinterpret_cast<const float4*>(fc + p.o1), a2 = *reinterpret_cast<const float4*>(fc + p.o2);
+      const float4 a3 = *reinterpret_cast<const float4*>(fc + p.o3), a4 = *reinterpret_cast<const float4*>(fc + p.o4);
+      const float4 b1 = *reinterpret_cast<const float4*>(fc + q.o1), b2 = *reinterpret_cast<const float4*>(fc + q.o2);
+      const float4 b3 = *reinterpret_cast<const float4*>(fc + q.o3), b4 = *reinterpret_cast<const float4*>(fc + q.o4);
+      fma4(p, a1, a2, a3, a4);
+      fma4(q, b1, b2, b3, b4);
+    }
+    if (si < ns) {
+      const Smp p = sample(si);
+      fma4(p, *reinterpret_cast<const float4*>(fc + p.o1), *reinterpret_cast<const float4*>(fc + p.o2), *reinterpret_cast<const float4*>(fc + p.o3),
+           *reinterpret_cast<const float4*>(fc + p.o4));
     }
     const float cntf = (float)max(gh * gw, 1);
     acc.x /= cntf; acc.y /= cntf; acc.z /= cntf; acc.w /= cntf;
     *reinterpret_cast<float4*>(a.out + ((long long)roi * a.out_size * a.out_size + bin) * a.c + 4 * ch) = acc;
+  }
   }
 }
 
@@ -903,7 +944,7 @@ extern "C" int seg_roi_align_f32(const void* p2, const void* p3, const void* p4,
   for (int l = 0; l < 4; ++l) { a.fh[l] = h2 >> l; a.fw[l] = w2 >> l; }
   a.c = c; a.R = R; a.out_size = out_size; a.boxes = (const float*)boxes; a.count = (const int*)count; a.out = (float*)out; a.level = (int*)level;
   if (out_size > 16) return fail(COMA_E_INVALID, "seg_roi_align_f32: out_size=%d > 16 (one wave per bin of a row)", out_size);
-  hipLaunchKernelGGL(roi_align_kernel, dim3(batch * R, out_size), dim3(64 * out_size), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(roi_align_kernel, dim3(batch * R), dim3(64 * out_size), 0, (hipStream_t)stream, a);
   return check_launch("seg::roi_align_kernel");
 }
 

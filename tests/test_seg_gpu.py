@@ -637,3 +637,36 @@ def test_plan_masks_match_oracle(seg_setup):
     assert all(torch.equal(keep[k], out2[k]) for k in keep)
     out3 = plan(torch.from_numpy(imgs[::-1].copy()))
     assert torch.equal(out3["person"][0], keep["person"][1]) and torch.equal(out3["scores"][1], keep["scores"][0])
+
+
+def test_plan_batch_8_dispatch_matches_oracle(seg_setup):
+    """The benchmarked call shape: ONE plan for 8 images (the GEMMs then see 4 x the rows of the batch-2 plans above: other tiles, other split-K
+    choices, the XCD-banded order over more bands).  Images 0 and 7 of the batch against the ORACLE's records of the same two pictures:
+    detection count, classes, scores, boxes, the merged person mask."""
+    from coma_amd.seg.model import HipPointRend
+    state, imgs, ref, trace = seg_setup
+    order = [0, 1, 1, 0, 0, 1, 0, 1]
+    batch = np.stack([imgs[k] for k in order])
+    plan = HipPointRend(state, 8, 128, 128, DEV, score_thresh=0.2, stage="masks", keep_masks=False)
+    out = plan(torch.from_numpy(batch))
+    for b in (0, 7):
+        r = ref[order[b]]
+        m = int(out["count"][b])
+        ok = out["valid"][b, :m].cpu().bool()
+        cls = out["classes"][b, :m].cpu().long()[ok]
+        sc = out["scores"][b, :m].cpu()[ok]
+        n_ref = len(r["scores"])
+        print(f"METRIC batch-8 image {b}: {int(ok.sum())} detections vs {n_ref}")
+        assert abs(int(ok.sum()) - n_ref) <= 2
+        k = min(int(ok.sum()), n_ref) - 2                  # two scores 1e-6 apart may swap places: lists compared as sorted scores / by nearest box
+        assert k > 30 and _rel(sc[:k], r["scores"][:k]) <= 1e-3
+        bx = out["boxes"][b, :m].cpu()[ok]
+        d = (bx[:k, None, :] - r["pred_boxes"][None, :, :]).abs().amax(dim=2)           # [mine, theirs]
+        near = d.argmin(dim=1)
+        assert float(d.min(dim=1)[0].max()) <= 2e-2 and torch.equal(cls[:k], r["pred_classes"].long()[near])
+        pm = so.person_mask(r, 128, 128)
+        pdiff = int((out["person"][b].cpu().numpy() != pm).sum())
+        print(f"METRIC batch-8 image {b}: merged person mask differs in {pdiff} of {pm.size} pixels ({int(pm.sum())} set)")
+        assert pdiff <= 0.002 * pm.size and pm.sum() > 0
+    # equal pictures at different positions of the batch give identical records
+    assert torch.equal(out["person"][0], out["person"][3]) and torch.equal(out["scores"][1], out["scores"][7])
