@@ -433,17 +433,22 @@ static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_b
   const long long tiles = gx * gy;
   int S = 1;
   if (force_split > 0) S = force_split;
-  else if (force_split == 0 && a.ws && tiles < kSlots && nk >= 8) {
+  else if (force_split == 0 && a.ws && tiles < 2 * kSlots && nk >= 8) {
     // cost model in units of "one chunk with two workgroups per CU" (~3.5 us on a 128 x 128 tile): a launch of W = tiles * S workgroups of
-    // nk / S chunks (+ 3 for prologue and epilogue) runs max(1, W / 512) rounds -- a launch that leaves CUs with one workgroup or none is as
-    // slow as its CUs with two -- and a split launch pays the reduce pass: a second launch (~3 units) that reads S slabs and the GEMM's
-    // writes of them at ~4 TB/s.  (Without the reduce term the point head, 392 tiles x 11 chunks, was split in two: 78 us against 58 us
-    // unsplit, profiles/r06_notes.md 5.)  Keep every slice >= 4 chunks.
-    double best = (nk + 3.0) * 1.0;
-    const double slab_units = 8.0 * (double)a.M * a.N / 4.0e6 / 3.5 * ((double)BM * BN / (128.0 * 128.0));
+    // nk / S chunks (+ 3 for prologue and epilogue) runs rounds(W) rounds of 512 workgroups; a last partial round costs 0.6 of a round while
+    // no CU holds two of its workgroups (<= 256) and a whole round beyond that (the CUs with two set the time).  A split launch also pays
+    // the reduce pass: a second launch (~3 us behind the GEMM inside a graph) that reads S slabs at ~4 TB/s.  Measured against forced
+    // factors on the plan's shapes (profiles/r06_notes.md 5): res5.x.conv2 picks 3 (220 us; 2: 315, 4: 250), res4.x.conv2 on 128 x 64 tiles
+    // picks 2 (227 us; unsplit 252), the point head (392 tiles x 11 chunks) stays unsplit (56 us; split in two 78).  Every slice >= 4 chunks.
+    auto rounds = [](double w) {
+      const double full = (double)(long long)(w / kSlots), frac = w / kSlots - full;
+      return full + (frac <= 0.0 ? 0.0 : (frac <= 0.5 ? 0.6 : 1.0));
+    };
+    double best = (nk + 3.0) * rounds((double)tiles);
+    const double unit_us = 3.5 * ((double)BM * BN / (128.0 * 128.0));
+    const double slab_units = 4.0 * (double)a.M * a.N / 4.0e6 / unit_us;      // one slab read back (the GEMM's slab writes overlap with its own work)
     for (int c = 2; c <= 16 && nk / c >= 4; ++c) {
-      const double w = (double)tiles * c / kSlots;
-      const double cost = ((double)nk / c + 3.0) * (w > 1.0 ? w : 1.0) + 3.0 + c * slab_units;
+      const double cost = ((double)nk / c + 3.0) * rounds((double)tiles * c) + 3.0 / unit_us + c * slab_units;
       if (cost < best * 0.95) { best = cost; S = c; }
     }
   }

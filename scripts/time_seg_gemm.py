@@ -31,7 +31,7 @@ SHAPES = [
     ("point_fc", 25088, 1, 1, 352, 256, 1, 1, False),
 ]
 only = [a for a in sys.argv[1:] if not a.startswith("--")]
-ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+ws = torch.empty((256 << 20) if "--splits" in sys.argv else (16 << 20), dtype=torch.float32, device=dev)      # 64 MiB = the plan's; forced factors need more
 for name, B, H, W, C, N, kh, stride, has_res in SHAPES:
     if only and not any(o in name for o in only):
         continue
@@ -48,7 +48,9 @@ for name, B, H, W, C, N, kh, stride, has_res in SHAPES:
     for tile in (0, 1, 2, 3):
         if tile == 3 and N > 64:
             continue
-        for split in ((0, -1) if tile == 0 else (-1,)):
+        for split in ((0, -1) if tile == 0 else ((-1, 2, 3, 4) if "--splits" in sys.argv else (-1,))):
+            if split > 1 and K // 32 // split < 2:
+                continue
             def run():
                 ops.conv_gemm(x, w, out, batch=B, in_h=H, in_w=W, c=C, n=N, kh=kh, kw=kh, stride=stride, pad=pad, bias=bias, res=res,
                               res_mode=1 if has_res else 0, relu=True, tile=tile, workspace=ws, split_k=split)
@@ -61,5 +63,5 @@ for name, B, H, W, C, N, kh, stride, has_res in SHAPES:
             e.record()
             torch.cuda.synchronize()
             ms = a.elapsed_time(e) / 20
-            print(f"{name:11s} M={M:7d} N={N:5d} K={K:6d} tile={tile} split={'rule' if split == 0 else 'off':4s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TF/s  "
+            print(f"{name:11s} M={M:7d} N={N:5d} K={K:6d} tile={tile} split={'rule' if split == 0 else ('off' if split < 0 else str(split)):4s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TF/s  "
                   f"{byt / ms / 1e6:6.0f} GB/s algorithmic", flush=True)
