@@ -487,24 +487,12 @@ struct RoiArgs {
   const float* boxes; const int* count; float* out; int* level;
 };
 
-// One workgroup per ROI, one wave per bin column, the bin rows in a loop (8000 x 49 single-wave workgroups were dispatch-bound: 0.62 ms for
-// 401 MB of output).  The bilinear weight of sample (iy, ix) on pixel (r, c) is wy(iy, r) * wx(ix, c), and a sample is skipped when EITHER
-// coordinate is outside [-1, size] -- so the bin is  sum_r sum_c WY[r] WX[c] f[r][c] / count  with per-axis sums WY, WX over the samples:
-// every pixel of the bin's footprint is loaded ONCE (<= 6 x 6 at the configured sizes) instead of four corners per sample (16 samples x 4
-// = 64 loads for the same footprint: the kernel was L1-bandwidth bound, 25 GB of corner loads per launch).  Same sum up to fp32 rounding.
-struct AxisSample { bool ok; int lo, hi; float wlo, whi; };
-__device__ __forceinline__ AxisSample roi_axis(float v, int size) {       // one coordinate of one sample: detectron2's bilinear_interpolate
-  AxisSample q;
-  q.ok = !(v < -1.f || v > (float)size);
-  if (v <= 0.f) v = 0.f;
-  q.lo = (int)v;
-  if (q.lo >= size - 1) { q.hi = q.lo = size - 1; v = (float)q.lo; } else q.hi = q.lo + 1;
-  q.whi = v - (float)q.lo;
-  q.wlo = 1.f - q.whi;
-  if (!q.ok) { q.lo = 0; q.hi = 0; q.wlo = 0.f; q.whi = 0.f; }
-  return q;
-}
-
+// one workgroup per ROI, one wave per bin column, the bin rows in a loop: 8000 x 49 single-wave workgroups were dispatch-bound (0.62 ms for
+// 401 MB of output), and with the rows of one ROI in seven workgroups on seven XCDs the ROI's patch of the feature map was pulled into seven
+// L2s (FETCH_SIZE 4 GB per launch; 0.74 GB in this form, profiles/r06_seg_pmc.txt).  VALU-bound now (2.6e8 wave instructions per launch: every
+// lane recomputes the wave-uniform sample geometry).  Measured and NOT kept (profiles/r06_notes.md 5): the separable form -- per-axis weight
+// sums, each footprint pixel loaded once -- with the sums recomputed per pixel (1.7 ms: elongated proposals have 15 samples on their long
+// axis) and with the sums computed one pixel per lane through LDS (0.64 ms: two barriers per bin row, a serial chain per wave).
 __global__ __launch_bounds__(1024) void roi_align_kernel(const RoiArgs a) {
   const int roi = blockIdx.x, pw = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = roi / a.R, i = roi % a.R;
@@ -522,67 +510,59 @@ __global__ __launch_bounds__(1024) void roi_align_kernel(const RoiArgs a) {
   const float bw = rw / (float)a.out_size, bh = rh / (float)a.out_size;
   const int gh = (int)ceilf(rh / (float)a.out_size), gw = (int)ceilf(rw / (float)a.out_size);
   const int c4 = a.c / 4;
-  const float cntf = (float)max(gh * gw, 1);
-  // ---- x axis of this wave's bin column: footprint [clo, chi] and the summed weights of up to NX columns in registers
-  constexpr int NX = 8;
-  auto xs = [&](int ix) __attribute__((always_inline)) { return roi_axis(x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw, W); };
-  int clo = 1 << 30, chi = -1, nvx = 0;
-  for (int ix = 0; ix < gw; ++ix) {
-    const AxisSample q = xs(ix);
-    if (q.ok) { clo = min(clo, q.lo); chi = max(chi, q.hi); ++nvx; }
-  }
-  auto wx_of = [&](int c) __attribute__((always_inline)) {
-    float w = 0.f;
-    for (int ix = 0; ix < gw; ++ix) {
-      const AxisSample q = xs(ix);
-      w += (q.lo == c ? q.wlo : 0.f) + (q.hi == c ? q.whi : 0.f);       // (lo == hi at the clamped edge: wlo + whi = 1 + 0)
-    }
-    return w;
-  };
-  float wx[NX];
-  const bool wide = chi - clo + 1 > NX;                  // not at the configured sizes (a bin spans <= 6 pixels): weights recomputed per pixel
-  if (!wide)
-#pragma unroll
-    for (int j = 0; j < NX; ++j) wx[j] = (nvx > 0 && clo + j <= chi) ? wx_of(clo + j) : 0.f;
   for (int ph = 0; ph < a.out_size; ++ph) {
-    const int bin = ph * a.out_size + pw;
-    auto ys = [&](int iy) __attribute__((always_inline)) { return roi_axis(y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh, H); };
-    int rlo = 1 << 30, rhi = -1;
-    for (int iy = 0; iy < gh; ++iy) {
-      const AxisSample q = ys(iy);
-      if (q.ok) { rlo = min(rlo, q.lo); rhi = max(rhi, q.hi); }
+  const int bin = ph * a.out_size + pw;
+  // one sample = four corner loads; TWO samples (eight independent loads) are requested before either is accumulated -- the sampling
+  // grid is data dependent, so the compiler cannot overlap iterations by itself; samples outside the map contribute 0 (weights zeroed,
+  // corner addresses clamped) and the sum keeps the sample order
+  struct Smp { float w1, w2, w3, w4; long long o1, o2, o3, o4; };
+  auto sample = [&](int si) __attribute__((always_inline)) {
+    Smp q;
+    const int iy = si / gw, ix = si - iy * gw;
+    float yy = y1 + ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+    float x = x1 + pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+    const bool in = !(yy < -1.f || yy > (float)H || x < -1.f || x > (float)W);
+    if (yy <= 0.f) yy = 0.f;
+    if (x <= 0.f) x = 0.f;
+    if (!in) { yy = 0.f; x = 0.f; }
+    int yl = (int)yy, xl = (int)x, yh, xh;
+    if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = yy - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+    q.w1 = in ? hy * hx : 0.f; q.w2 = in ? hy * lx : 0.f; q.w3 = in ? ly * hx : 0.f; q.w4 = in ? ly * lx : 0.f;
+    q.o1 = ((long long)yl * W + xl) * a.c; q.o2 = ((long long)yl * W + xh) * a.c;
+    q.o3 = ((long long)yh * W + xl) * a.c; q.o4 = ((long long)yh * W + xh) * a.c;
+    return q;
+  };
+  const int ns = gh * gw;
+  for (int ch = lane; ch < c4; ch += 64) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* fc = f + 4 * ch;
+    auto fma4 = [&](const Smp& q, const float4& v1, const float4& v2, const float4& v3, const float4& v4) __attribute__((always_inline)) {
+      acc.x += q.w1 * v1.x + q.w2 * v2.x + q.w3 * v3.x + q.w4 * v4.x;
+      acc.y += q.w1 * v1.y + q.w2 * v2.y + q.w3 * v3.y + q.w4 * v4.y;
+      acc.z += q.w1 * v1.z + q.w2 * v2.z + q.w3 * v3.z + q.w4 * v4.z;
+      acc.w += q.w1 * v1.w + q.w2 * v2.w + q.w3 * v3.w + q.w4 * v4.w;
+    };
+    int si = 0;
+    for (; si + 1 < ns; si += 2) {
+      const Smp p = sample(si), q = sample(si + 1);
+      const float4 a1 = *reinterpret_cast<const float4*>(fc + p.o1), a2 = *reinterpret_cast<const float4*>(fc + p.o2);
+      const float4 a3 = *reinterpret_cast<const float4*>(fc + p.o3), a4 = *reinterpret_cast<const float4*>(fc + p.o4);
+      const float4 b1 = *reinterpret_cast<const float4*>(fc + q.o1), b2 = *reinterpret_cast<const float4*>(fc + q.o2);
+      const float4 b3 = *reinterpret_cast<const float4*>(fc + q.o3), b4 = *reinterpret_cast<const float4*>(fc + q.o4);
+      fma4(p, a1, a2, a3, a4);
+      fma4(q, b1, b2, b3, b4);
     }
-    for (int ch = lane; ch < c4; ch += 64) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nvx > 0) {
-        for (int r = rlo; r <= rhi; ++r) {
-          float wy = 0.f;
-          for (int iy = 0; iy < gh; ++iy) {
-            const AxisSample q = ys(iy);
-            wy += (q.lo == r ? q.wlo : 0.f) + (q.hi == r ? q.whi : 0.f);
-          }
-          const float* frow = f + ((long long)r * W + clo) * a.c + 4 * ch;
-          if (!wide) {
-            float4 px[NX];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) px[j] = clo + j <= chi ? *reinterpret_cast<const float4*>(frow + (long long)j * a.c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-              const float w = wy * wx[j];
-              acc.x += w * px[j].x; acc.y += w * px[j].y; acc.z += w * px[j].z; acc.w += w * px[j].w;
-            }
-          } else {
-            for (int c = clo; c <= chi; ++c) {
-              const float w = wy * wx_of(c);
-              const float4 pxl = *reinterpret_cast<const float4*>(frow + (long long)(c - clo) * a.c);
-              acc.x += w * pxl.x; acc.y += w * pxl.y; acc.z += w * pxl.z; acc.w += w * pxl.w;
-            }
-          }
-        }
-      }
-      acc.x /= cntf; acc.y /= cntf; acc.z /= cntf; acc.w /= cntf;
-      *reinterpret_cast<float4*>(a.out + ((long long)roi * a.out_size * a.out_size + bin) * a.c + 4 * ch) = acc;
+    if (si < ns) {
+      const Smp p = sample(si);
+      fma4(p, *reinterpret_cast<const float4*>(fc + p.o1), *reinterpret_cast<const float4*>(fc + p.o2), *reinterpret_cast<const float4*>(fc + p.o3),
+           *reinterpret_cast<const float4*>(fc + p.o4));
     }
+    const float cntf = (float)max(gh * gw, 1);
+    acc.x /= cntf; acc.y /= cntf; acc.z /= cntf; acc.w /= cntf;
+    *reinterpret_cast<float4*>(a.out + ((long long)roi * a.out_size * a.out_size + bin) * a.c + 4 * ch) = acc;
+  }
   }
 }
 
