@@ -324,7 +324,12 @@ def pointrend_plugin(dev, batch, forced=4):
            "roofline": {"bound": "mfma", "kernel": "seg::conv_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; layers of >= 2 GFLOP per image)",
                         "achieved": sum(f for f, _ in big) / sum(t for _, t in big) / 1e9, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": sum(f for f, _ in big) / sum(t for _, t in big) / 1e9 / FP32_MFMA_PEAK_TFLOPS, "launches": len(big),
-                        "all_gemm_launches_ms": sum(t for _, t in gemm), "eager_sum_ms": sum(t for _, _, t in prof), "traffic": None,
+                        "all_gemm_launches_ms": sum(t for _, t in gemm), "eager_sum_ms": sum(t for _, _, t in prof),
+                        "algorithmic_bytes": sum(b for (tag, _), b in zip(plan.g.tags, plan.g.alg_bytes) if tag.startswith("seg gemm")) / max(1, len(gemm)),
+                        "traffic": SEG_GEMM_PMC_TRAFFIC_BYTES if (batch, forced) == (8, 4) else None,
+                        "traffic_source": "profiles/r06_seg_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) over the five conv_gemm_f32 instantiations of one eager "
+                                          "forward at batch 8 (15.6 GB fetched, 6.4 GB written) / 90 launches; a CONSTANT from the builder's counter pass, "
+                                          "not measured by this run",
                         "note": "fp32 as the reference runs detectron2 (no autocast): priced against the fp32 matrix peak; the point-head / "
                                 "coarse-head GEMMs are gated by the device-side detection count and are not in `achieved`"}}
     return pred, plan, rec
@@ -514,11 +519,13 @@ def bench_occupancy(args, dev, world, rank):
 
 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this round (separate --pmc passes for FETCH_SIZE and WRITE_SIZE;
 # FETCH_SIZE doubled: gfx950 reports half of a coalesced stream, MI355X_MICROARCH.md):
+#   profiles/r06_seg_pmc.txt             (2*FETCH + WRITE) of the seg::conv_gemm_f32_kernel instantiations, one eager forward at batch 8, / 90 launches
 #   profiles/r05_unet_gemm_traffic.txt   (2*FETCH + WRITE) / conv_gemm launch, mean over eager UNet forwards at batch 16
 #   profiles/r05_inpaint_pmc.txt         contact_accumulate_kernel: FETCH_SIZE 1.91569e6 KiB, WRITE_SIZE 3.71278e6 KiB per launch
 #   profiles/r05_inpaint_pmc.txt         occupancy at the config-5 share: fused WRITE 11.02 GB + 2 * FETCH 0.124 GB, rowprep 2 * 0.209 + 0.232 GB,
 #                                        groupmax 0.04 GB
 UNET_GEMM_PMC_TRAFFIC_BYTES = int(158.17e6)
+SEG_GEMM_PMC_TRAFFIC_BYTES = int(21.92e9 / 90)   # 243.6 MB per launch against 177 MB algorithmic (1.37 x): halo re-reads of the 3 x 3 layers across XCDs + split-K slabs
 OCCUPANCY_PMC_TRAFFIC_BYTES = int(11.96e9)   # fused 11.02 + 0.25, rowprep 0.42 + 0.23, groupmax 0.04 GB
 OCCUPANCY_PMC_SOURCE = ("profiles/r05_inpaint_pmc.txt: (2*FETCH_SIZE + WRITE_SIZE) of occupancy_rowprep (0.42 GB fetched, 0.23 GB of bucketed 16-byte "
                         "incidences written) + occupancy_fused (11.02 GB written, 0.25 GB fetched) + occupancy_groupmax (0.04 GB) at H=1310, R=128, S=2000: "
