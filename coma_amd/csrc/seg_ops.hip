@@ -232,9 +232,9 @@ __device__ __forceinline__ void decode_box(const float* anchor, float d0, float 
 // torch.clamp(x, min=0, max=hi) keeps NaN; fminf / fmaxf would drop it
 __device__ __forceinline__ float clampf(float x, float hi) { return x != x ? x : fminf(fmaxf(x, 0.f), hi); }
 
-__global__ __launch_bounds__(1024) void rpn_select_kernel(const float* pred, int ld, int fh, int fw, int stride, const float* cell, int level,
-                                                          int anchor_base, int pre_topk, float img_h, float img_w, int cand_offset, int cap,
-                                                          u64* keys, float* boxes, int* group) {
+__device__ __forceinline__ void rpn_select_body(const float* pred, int ld, int fh, int fw, int stride, const float* cell, int level,
+                                                int anchor_base, int pre_topk, float img_h, float img_w, int cand_offset, int cap,
+                                                u64* keys, float* boxes, int* group) {
   __shared__ u32 hist[256];
   __shared__ u32 sh[2];
   const int b = blockIdx.x;
@@ -309,6 +309,25 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(const float* pred, int
     base_gt = run_g;
     base_eq = run_e;
   }
+}
+
+__global__ __launch_bounds__(1024) void rpn_select_kernel(const float* pred, int ld, int fh, int fw, int stride, const float* cell, int level,
+                                                          int anchor_base, int pre_topk, float img_h, float img_w, int cand_offset, int cap,
+                                                          u64* keys, float* boxes, int* group) {
+  rpn_select_body(pred, ld, fh, fw, stride, cell, level, anchor_base, pre_topk, img_h, img_w, cand_offset, cap, keys, boxes, group);
+}
+
+// every FPN level in ONE launch, blockIdx.y = level: a level is one workgroup per image, so five launches in a row kept 8 of 256 CUs busy for
+// the sum of their times (0.59 ms at batch 8); side by side the launch takes as long as the largest level (p2)
+struct RpnLevels {
+  const float* pred[6]; const float* cell[6];
+  int fh[6], fw[6], stride[6], anchor_base[6], cand_offset[6];
+};
+__global__ __launch_bounds__(1024) void rpn_select_levels_kernel(const RpnLevels L, int ld, int pre_topk, float img_h, float img_w, int cap, u64* keys,
+                                                                 float* boxes, int* group) {
+  const int l = blockIdx.y;
+  rpn_select_body(L.pred[l], ld, L.fh[l], L.fw[l], L.stride[l], L.cell[l], l, L.anchor_base[l], pre_topk, img_h, img_w, L.cand_offset[l], cap, keys,
+                  boxes, group);
 }
 
 // ------------------------------------------------------------------ candidate sort (bitonic, one workgroup per image)
@@ -896,6 +915,33 @@ extern "C" int seg_rpn_select(const void* pred, int ld, int batch, int fh, int f
   return check_launch("seg::rpn_select_kernel");
 }
 
+extern "C" int seg_rpn_select_levels(const void* const* preds, const void* const* cell_anchors, const int* fh, const int* fw, int n_levels, int first_stride,
+                                     int ld, int batch, int pre_topk, float img_h, float img_w, int cap, void* cand_keys, void* cand_boxes,
+                                     void* cand_group, void* stream) {
+  if (!preds || !cell_anchors || !fh || !fw || n_levels <= 0 || n_levels > 6) return fail(COMA_E_INVALID, "seg_rpn_select_levels: 1 .. 6 levels, got %d", n_levels);
+  SEG_REC_BEGIN(SEG_OP_RPN_SELECT_LEVELS)
+    for (int l = 0; l < n_levels; ++l) { r.p[l] = (void*)preds[l]; r.p[6 + l] = (void*)cell_anchors[l]; r.i[8 + l] = fh[l]; r.i[14 + l] = fw[l]; }
+    r.p[12] = cand_keys; r.p[13] = cand_boxes; r.p[14] = cand_group;
+    r.i[1] = n_levels; r.i[2] = first_stride; r.i[3] = ld; r.i[4] = batch; r.i[5] = pre_topk; r.i[6] = cap; r.f[0] = img_h; r.f[1] = img_w;
+  SEG_REC_END
+  if (!cand_keys || !cand_boxes || !cand_group) return fail(COMA_E_INVALID, "seg_rpn_select_levels: null pointer");
+  if (ld < 15 || batch <= 0 || pre_topk <= 0 || first_stride <= 0) return fail(COMA_E_INVALID, "seg_rpn_select_levels: bad sizes (ld=%d, batch=%d, topk=%d)", ld, batch, pre_topk);
+  RpnLevels L{};
+  int abase = 0, off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    if (!preds[l] || !cell_anchors[l] || fh[l] <= 0 || fw[l] <= 0) return fail(COMA_E_INVALID, "seg_rpn_select_levels: level %d: null pointer or empty map", l);
+    L.pred[l] = (const float*)preds[l]; L.cell[l] = (const float*)cell_anchors[l];
+    L.fh[l] = fh[l]; L.fw[l] = fw[l]; L.stride[l] = first_stride << l; L.anchor_base[l] = abase; L.cand_offset[l] = off;
+    const int n = fh[l] * fw[l] * 3;
+    abase += n;
+    off += n < pre_topk ? n : pre_topk;
+  }
+  if (off > cap) return fail(COMA_E_INVALID, "seg_rpn_select_levels: %d candidates exceed the list capacity %d", off, cap);
+  hipLaunchKernelGGL(rpn_select_levels_kernel, dim3(batch, n_levels), dim3(1024), 0, (hipStream_t)stream, L, ld, pre_topk, img_h, img_w, cap, (u64*)cand_keys,
+                     (float*)cand_boxes, (int*)cand_group);
+  return check_launch("seg::rpn_select_levels_kernel");
+}
+
 extern "C" int seg_sort_candidates(const void* keys, const void* boxes, const void* group, int batch, int cap, void* s_boxes, void* s_scores,
                                    void* s_group, void* s_src, void* n_valid, void* stream) {
   SEG_REC_BEGIN(SEG_OP_SORT)
@@ -1073,6 +1119,12 @@ int seg_replay(const PlanRec& r, void* st) {
     case SEG_OP_RPN_SELECT:
       return seg_rpn_select(p[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], p[1], (int)i[6], (int)i[7], (int)i[8], (float)f[0], (float)f[1],
                             (int)i[9], (int)i[10], p[2], p[3], p[4], st);
+    case SEG_OP_RPN_SELECT_LEVELS: {
+      const void* preds[6]; const void* cells[6]; int fh[6], fw[6];
+      for (int l = 0; l < (int)i[1]; ++l) { preds[l] = p[l]; cells[l] = p[6 + l]; fh[l] = (int)i[8 + l]; fw[l] = (int)i[14 + l]; }
+      return seg_rpn_select_levels(preds, cells, fh, fw, (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], (float)f[0], (float)f[1], (int)i[6], p[12], p[13],
+                                   p[14], st);
+    }
     case SEG_OP_SORT: return seg_sort_candidates(p[0], p[1], p[2], (int)i[1], (int)i[2], p[3], p[4], p[5], p[6], p[7], st);
     case SEG_OP_NMS:
       return seg_nms(p[0], p[1], p[2], p[3], p[4], (int)i[1], (int)i[2], (float)f[0], (int)i[3], p[5], p[6], p[7], p[8], p[9], p[10], p[11], st);

@@ -175,20 +175,21 @@ class HipPointRend:
         # ---- RPN: head per level, top-k + decode, one sort, one NMS
         ck, cb, cg = g.buf(B, CAP, dtype=I64), g.buf(B, CAP, 4, dtype=F32), g.buf(B, CAP, dtype=I32)
         g.add(lambda: ops.memset(ck, 0xFF), tag="seg memset keys")
-        off, abase = 0, 0
+        off = 0
         t["rpn_pred"] = {}
+        preds, cells, dims = [], [], []
         for li, lvl in enumerate((2, 3, 4, 5, 6)):
             f, fh, fw = feats[lvl]
             hid, _, _ = self._conv(f, "rpn_conv", batch=B, h=fh, w=fw, c=256, kh=3, pad=1, relu=True)
             pred, _, _ = self._conv(hid, "rpn_pred", batch=B, h=fh, w=fw, c=256, ldo=16)
             t["rpn_pred"][lvl] = pred
-            cell = self._const(cell_anchors(ANCHOR_SIZES[li]).numpy(), F32)
-            k = min(fh * fw * 3, PRE_TOPK)
-            g.add(lambda pred=pred, cell=cell, fh=fh, fw=fw, li=li, lvl=lvl, off=off, abase=abase:
-                  ops.rpn_select(pred, cell, ck, cb, cg, ld=16, batch=B, fh=fh, fw=fw, stride=1 << lvl, level=li, anchor_base=abase, pre_topk=PRE_TOPK,
-                                 img_h=nh, img_w=nw, cand_offset=off, cap=CAP), tag=f"seg rpn select p{lvl}")
-            off += k
-            abase += fh * fw * 3
+            preds.append(pred)
+            cells.append(self._const(cell_anchors(ANCHOR_SIZES[li]).numpy(), F32))
+            dims.append((fh, fw))
+            off += min(fh * fw * 3, PRE_TOPK)
+        # one launch for the five levels (a level is one workgroup per image: side by side they take as long as p2 alone)
+        g.add(lambda: ops.rpn_select_levels(preds, cells, ck, cb, cg, ld=16, batch=B, dims=dims, first_stride=4, pre_topk=PRE_TOPK, img_h=nh, img_w=nw,
+                                            cap=CAP), tag="seg rpn select p2..p6")
         self.n_rpn_cand = off
         sb, ss, sg, ssrc, nv = g.buf(B, CAP, 4, dtype=F32), g.buf(B, CAP, dtype=F32), g.buf(B, CAP, dtype=I32), g.buf(B, CAP, dtype=I32), g.buf(B, dtype=I32)
         mask_ws = g.buf(B, CAP, CAP // 64, dtype=I64)

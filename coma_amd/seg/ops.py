@@ -67,6 +67,18 @@ def rpn_select(pred, cell, keys, boxes, group, *, ld, batch, fh, fw, stride, lev
     _lib.check(rc, "seg_rpn_select")
 
 
+def rpn_select_levels(preds, cells, keys, boxes, group, *, ld, batch, dims, first_stride, pre_topk, img_h, img_w, cap):
+    """seg_rpn_select for consecutive FPN levels in one launch; dims: [(fh, fw), ...] per level."""
+    n = len(preds)
+    pa = (C.c_void_p * n)(*[_p(t, "pred", F32) for t in preds])
+    ca = (C.c_void_p * n)(*[_p(t, "cell_anchors", F32) for t in cells])
+    fh = (C.c_int * n)(*[d[0] for d in dims])
+    fw = (C.c_int * n)(*[d[1] for d in dims])
+    rc = _lib.lib().seg_rpn_select_levels(pa, ca, fh, fw, n, first_stride, ld, batch, pre_topk, float(img_h), float(img_w), cap, _p(keys, "keys", I64),
+                                          _p(boxes, "boxes", F32), _p(group, "group", I32), _stream(preds[0]))
+    _lib.check(rc, "seg_rpn_select_levels")
+
+
 def sort_candidates(keys, boxes, group, s_boxes, s_scores, s_group, s_src, n_valid, *, batch, cap):
     rc = _lib.lib().seg_sort_candidates(_p(keys, "keys", I64), _p(boxes, "boxes", F32), _p(group, "group", I32), batch, cap, _p(s_boxes, "s_boxes", F32),
                                         _p(s_scores, "s_scores", F32), _p(s_group, "s_group", I32), _p(s_src, "s_src", I32), _p(n_valid, "n_valid", I32),

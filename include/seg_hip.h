@@ -25,7 +25,7 @@ extern "C" {
 /* operator codes of a recorded launch (sd_plan.h PK_SEG: PlanRec.i[0]) */
 enum {
   SEG_OP_CONV = 1, SEG_OP_RESIZE, SEG_OP_MAXPOOL, SEG_OP_SUBSAMPLE, SEG_OP_MEMSET, SEG_OP_RPN_SELECT, SEG_OP_SORT, SEG_OP_NMS, SEG_OP_ROI_ALIGN,
-  SEG_OP_BOX_PREDICT, SEG_OP_FINALIZE, SEG_OP_POINT_SAMPLE, SEG_OP_UPSAMPLE2X, SEG_OP_TOPK_POINTS, SEG_OP_POINT_LOGIT, SEG_OP_PASTE
+  SEG_OP_BOX_PREDICT, SEG_OP_FINALIZE, SEG_OP_POINT_SAMPLE, SEG_OP_UPSAMPLE2X, SEG_OP_TOPK_POINTS, SEG_OP_POINT_LOGIT, SEG_OP_PASTE, SEG_OP_RPN_SELECT_LEVELS
 };
 
 /* out[m, n] = act(sum_k A[m, k] W[n, k] + bias[n] (+ res)),  m = (b, oy, ox), k = (ky, kx, c): Conv2d / Linear + folded FrozenBatchNorm
@@ -77,6 +77,14 @@ int seg_memset(void* dst, int byte, size_t bytes, void* stream);
 int seg_rpn_select(const void* pred, int ld, int batch, int fh, int fw, int stride, const void* cell_anchors /* f32 [3][4], DefaultAnchorGenerator's
                    cell anchors of this level, computed by the host as detectron2 does (f64 -> f32) */, int level, int anchor_base, int pre_topk,
                    float img_h, float img_w, int cand_offset, int cap, void* cand_keys, void* cand_boxes, void* cand_group, void* stream);
+
+/* seg_rpn_select for n_levels (<= 6) consecutive FPN levels in ONE launch (a level is one workgroup per image: side by side the levels take
+ * as long as the largest).  Level l: stride first_stride << l, group id l, anchor_base = anchors of the levels before it, candidate slots
+ * [sum of min(anchors, pre_topk) of the levels before it, + min(anchors, pre_topk)) -- the layout RPN.predict_proposals' per-level loop
+ * produces (utils/adaptive_mask_inpainting.py:1225-1236 -> detectron2 find_top_rpn_proposals).  preds / cell_anchors / fh / fw: HOST arrays. */
+int seg_rpn_select_levels(const void* const* preds, const void* const* cell_anchors, const int* fh, const int* fw, int n_levels, int first_stride,
+                          int ld, int batch, int pre_topk, float img_h, float img_w, int cap, void* cand_keys, void* cand_boxes, void* cand_group,
+                          void* stream);
 
 /* Sort the cap (a power of two <= 8192) candidate slots of each image by key, ascending (= score descending, ties ascending index).
  * -> sorted boxes / scores / group / source (low 32 bits of the key), n_valid i32 [batch] = slots with key != ~0. */

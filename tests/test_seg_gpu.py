@@ -272,6 +272,7 @@ def test_rpn_select_takes_the_oracles_candidates(hip_lib):
     ck = torch.full((1, cap), -1, dtype=I64, device=DEV)
     cb, cg = torch.zeros(1, cap, 4, device=DEV), torch.zeros(1, cap, dtype=I32, device=DEV)
     logits, deltas, off, abase = [], [], 0, 0
+    dev_preds = []
     for li, (fh, fw) in enumerate(dims):
         pred = rng.normal(0, 1, (1, fh * fw, 16)).astype(np.float32)
         pred[..., 3:15] *= 0.3
@@ -280,10 +281,19 @@ def test_rpn_select_takes_the_oracles_candidates(hip_lib):
             pred[0, 7, 5] = np.nan                                          # a non-finite delta: the candidate is dropped after selection
         logits.append(torch.from_numpy(pred[0, :, 0:3].reshape(fh, fw, 3)).permute(2, 0, 1)[None])
         deltas.append(torch.from_numpy(pred[0, :, 3:15].reshape(fh, fw, 12)).permute(2, 0, 1)[None])
-        ops.rpn_select(d(pred), d(M.cell_anchors(M.ANCHOR_SIZES[li])), ck, cb, cg, ld=16, batch=1, fh=fh, fw=fw, stride=4 << li, level=li, anchor_base=abase,
+        dev_preds.append(d(pred))
+        ops.rpn_select(dev_preds[-1], d(M.cell_anchors(M.ANCHOR_SIZES[li])), ck, cb, cg, ld=16, batch=1, fh=fh, fw=fw, stride=4 << li, level=li, anchor_base=abase,
                        pre_topk=1000, img_h=nh, img_w=nw, cand_offset=off, cap=cap)
         off += min(fh * fw * 3, 1000)
         abase += fh * fw * 3
+    # the five levels in ONE launch (what the plan records): the same candidate list, bit for bit
+    ck2 = torch.full((1, cap), -1, dtype=I64, device=DEV)
+    cb2, cg2 = torch.zeros(1, cap, 4, device=DEV), torch.zeros(1, cap, dtype=I32, device=DEV)
+    ops.rpn_select_levels(dev_preds, [d(M.cell_anchors(M.ANCHOR_SIZES[li])) for li in range(5)], ck2, cb2, cg2, ld=16, batch=1, dims=dims, first_stride=4,
+                          pre_topk=1000, img_h=nh, img_w=nw, cap=cap)
+    live = (ck[0, :off] != -1).cpu()
+    assert torch.equal(ck2, ck) and torch.equal(cg2[0, :off], cg[0, :off])
+    assert torch.equal(cb2[0, :off].cpu()[live].view(torch.int32), cb[0, :off].cpu()[live].view(torch.int32))
     ref = so.rpn_proposals(logits, deltas, (nh, nw))
     keys = ck[0].cpu().numpy().view(np.uint64)
     used = keys[:off]
