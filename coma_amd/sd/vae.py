@@ -49,8 +49,9 @@ class _VaeBase:
         M = B * H * W
         h = g.buf(M, cout)
         if self._halo(cin, cout, H, W):
+            # (per-tile column sums only when their one consumer, norm2 -> conv2, reads them through the affine table: a halo convolution too)
             g.gn_silu_conv3x3_halo(x, s[p + ".norm1.weight"], s[p + ".norm1.bias"], conv_weight(s[p + ".conv1.weight"]), s[p + ".conv1.bias"], h,
-                                   batch=B, h=H, w_=W, c=cin, n=cout, eps=1e-6, stats=True)
+                                   batch=B, h=H, w_=W, c=cin, n=cout, eps=1e-6, stats=self._halo(cout, cout, H, W))
         else:
             n1 = g.buf(M, cin)
             g.groupnorm(x, s[p + ".norm1.weight"], s[p + ".norm1.bias"], n1, batch=B, hw=H * W, c0=cin, eps=1e-6, silu=True)
