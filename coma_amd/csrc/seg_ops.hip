@@ -457,13 +457,14 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* mask, const flo
         rw |= bcast64(diag, j);
       }
     }
-    // removal rows of the kept candidates, FOUR rows (eight independent loads) in flight at a time: one wave walks ~1000 kept rows per image
-    // and a load-wait-OR per row was most of this kernel's 0.5 ms
+    // removal rows of the kept candidates, SIXTEEN rows (32 independent loads) in flight at a time: one wave walks ~1000 kept rows per image
+    // and a load-wait-OR per row was most of this kernel's 0.5 ms (four rows at a time: 0.27 ms)
     const bool h0 = lane > blk && lane < nwords, h1 = lane + 64 > blk && lane + 64 < nwords;      // words behind the diagonal (the others were never written)
     for (u64 kb = keep; kb;) {
-      u64 v0[4], v1[4];
+      constexpr int NR = 16;
+      u64 v0[NR], v1[NR];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NR; ++q) {
         v0[q] = v1[q] = 0ull;
         if (kb) {
           const int j = __builtin_ctzll(kb);
@@ -473,8 +474,8 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* mask, const flo
           if (h1) v1[q] = mask[r + lane + 64];
         }
       }
-      rem0 |= (v0[0] | v0[1]) | (v0[2] | v0[3]);
-      rem1 |= (v1[0] | v1[1]) | (v1[2] | v1[3]);
+#pragma unroll
+      for (int q = 0; q < NR; ++q) { rem0 |= v0[q]; rem1 |= v1[q]; }
     }
     if ((keep >> lane) & 1ull) {
       const int pos = cnt + __popcll(keep & ((1ull << lane) - 1));

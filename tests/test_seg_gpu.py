@@ -680,3 +680,20 @@ def test_plan_batch_8_dispatch_matches_oracle(seg_setup):
         assert pdiff <= 0.002 * pm.size and pm.sum() > 0
     # equal pictures at different positions of the batch give identical records
     assert torch.equal(out["person"][0], out["person"][3]) and torch.equal(out["scores"][1], out["scores"][7])
+
+
+def test_plan_without_detections(seg_setup):
+    """A threshold nothing passes (a render without a person, with real weights): every count is 0, the mask head's launches are gated off by
+    the device-side counts (their buffers may hold anything: never read), the merged person mask is empty, nothing is non-finite -- and the
+    replayed graph gives the same answer.  The plug-in then returns an all-zero mask, which the pipeline's area test turns into the default
+    mask (utils/adaptive_mask_inpainting.py:1132)."""
+    from coma_amd.seg.model import HipPointRend
+    state, imgs, ref, trace = seg_setup
+    plan = HipPointRend(state, 2, 128, 128, DEV, score_thresh=0.99999, stage="masks", keep_masks=True)
+    for _ in range(2):                                   # eager recording run, then the hipGraph replay
+        out = plan(torch.from_numpy(imgs))
+        torch.cuda.synchronize()
+        assert out["count"].cpu().tolist() == [0, 0]
+        assert int(out["person"].sum()) == 0 and int(out["masks"].sum()) == 0 and int(out["valid"].sum()) == 0
+        assert bool(torch.isfinite(out["scores"]).all()) and bool(torch.isfinite(out["boxes"]).all())
+    assert plan.instances(0)["pred_boxes"].shape == (0, 4) and plan.instances(1)["pred_masks"].shape[0] == 0
