@@ -509,8 +509,7 @@ struct RoiArgs {
 
 // one workgroup per ROI, one wave per bin column, the bin rows in a loop: 8000 x 49 single-wave workgroups were dispatch-bound (0.62 ms for
 // 401 MB of output), and with the rows of one ROI in seven workgroups on seven XCDs the ROI's patch of the feature map was pulled into seven
-// L2s (FETCH_SIZE 4 GB per launch; 0.74 GB in this form, profiles/r06_seg_pmc.txt).  VALU-bound now (2.6e8 wave instructions per launch: every
-// lane recomputes the wave-uniform sample geometry).  Measured and NOT kept (profiles/r06_notes.md 5): the separable form -- per-axis weight
+// L2s (FETCH_SIZE 4 GB per launch; 0.74 GB in this form, profiles/r06_seg_pmc.txt).  Measured and NOT kept (profiles/r06_notes.md 5): the separable form -- per-axis weight
 // sums, each footprint pixel loaded once -- with the sums recomputed per pixel (1.7 ms: elongated proposals have 15 samples on their long
 // axis) and with the sums computed one pixel per lane through LDS (0.64 ms: two barriers per bin row, a serial chain per wave).
 __global__ __launch_bounds__(1024) void roi_align_kernel(const RoiArgs a) {
@@ -530,6 +529,73 @@ __global__ __launch_bounds__(1024) void roi_align_kernel(const RoiArgs a) {
   const float bw = rw / (float)a.out_size, bh = rh / (float)a.out_size;
   const int gh = (int)ceilf(rh / (float)a.out_size), gw = (int)ceilf(rw / (float)a.out_size);
   const int c4 = a.c / 4;
+  // ---- per-axis sample tables in LDS (r6): the geometry of a sample is wave-uniform work that every lane was redoing per sample (2.6e8 wave
+  // instructions per launch, VALU-bound).  Sample ix of bin column pw depends on (pw, ix) only, sample iy of bin row ph on (ph, iy) only: wave w
+  // fills the x table of its column and the y table of bin row w, ONE sample per lane, one barrier; a sample in the loop is then two broadcast
+  // LDS reads, four products and four 32-bit offsets.  Same weights, same order of the sum: bit-identical to the form below, which stays
+  // as the path for more than 64 samples per axis (a bin spanning > 64 pixels: not with 7 x 7 bins on these maps).
+  constexpr int TS = 64;
+  __shared__ float4 xs_t[16][TS], ys_t[16][TS];          // (lo, hi as int bits, weight of lo, weight of hi); a skipped sample has weights 0
+  const bool tables = gw <= TS && gh <= TS && (long long)H * W * a.c < 0x7fffffffLL;
+  if (tables) {
+    auto entry = [](float v, int size) __attribute__((always_inline)) {
+      const bool in = !(v < -1.f || v > (float)size);
+      if (v <= 0.f) v = 0.f;
+      if (!in) v = 0.f;
+      int lo = (int)v, hi;
+      if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else hi = lo + 1;
+      const float l = v - (float)lo, h = 1.f - l;
+      return make_float4(__int_as_float(lo), __int_as_float(hi), in ? h : 0.f, in ? l : 0.f);
+    };
+    if (lane < gw) xs_t[pw][lane] = entry(x1 + pw * bw + ((float)lane + 0.5f) * bw / (float)gw, W);
+    if (lane < gh) ys_t[pw][lane] = entry(y1 + pw * bh + ((float)lane + 0.5f) * bh / (float)gh, H);      // wave w: bin ROW w
+    __syncthreads();
+    const int ns = gh * gw;
+    for (int ph = 0; ph < a.out_size; ++ph) {
+      const int bin = ph * a.out_size + pw;
+      for (int ch = lane; ch < c4; ch += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* fc = f + 4 * ch;
+        auto corners = [&](int si, float (&w)[4], int (&o)[4]) __attribute__((always_inline)) {
+          const int iy = si / gw, ix = si - iy * gw;
+          const float4 Y = ys_t[ph][iy], X = xs_t[pw][ix];
+          const int yl = __float_as_int(Y.x), yh = __float_as_int(Y.y), xl = __float_as_int(X.x), xh = __float_as_int(X.y);
+          w[0] = Y.z * X.z; w[1] = Y.z * X.w; w[2] = Y.w * X.z; w[3] = Y.w * X.w;
+          o[0] = (yl * W + xl) * a.c; o[1] = (yl * W + xh) * a.c; o[2] = (yh * W + xl) * a.c; o[3] = (yh * W + xh) * a.c;
+        };
+        auto fma4 = [&](const float (&w)[4], const float4& v1, const float4& v2, const float4& v3, const float4& v4) __attribute__((always_inline)) {
+          acc.x += w[0] * v1.x + w[1] * v2.x + w[2] * v3.x + w[3] * v4.x;
+          acc.y += w[0] * v1.y + w[1] * v2.y + w[2] * v3.y + w[3] * v4.y;
+          acc.z += w[0] * v1.z + w[1] * v2.z + w[2] * v3.z + w[3] * v4.z;
+          acc.w += w[0] * v1.w + w[1] * v2.w + w[2] * v3.w + w[3] * v4.w;
+        };
+        int si = 0;
+        for (; si + 1 < ns; si += 2) {                   // two samples = eight loads in flight
+          float wa[4], wb[4];
+          int oa[4], ob[4];
+          corners(si, wa, oa);
+          corners(si + 1, wb, ob);
+          const float4 a1 = *reinterpret_cast<const float4*>(fc + oa[0]), a2 = *reinterpret_cast<const float4*>(fc + oa[1]);
+          const float4 a3 = *reinterpret_cast<const float4*>(fc + oa[2]), a4 = *reinterpret_cast<const float4*>(fc + oa[3]);
+          const float4 b1 = *reinterpret_cast<const float4*>(fc + ob[0]), b2 = *reinterpret_cast<const float4*>(fc + ob[1]);
+          const float4 b3 = *reinterpret_cast<const float4*>(fc + ob[2]), b4 = *reinterpret_cast<const float4*>(fc + ob[3]);
+          fma4(wa, a1, a2, a3, a4);
+          fma4(wb, b1, b2, b3, b4);
+        }
+        if (si < ns) {
+          float wa[4];
+          int oa[4];
+          corners(si, wa, oa);
+          fma4(wa, *reinterpret_cast<const float4*>(fc + oa[0]), *reinterpret_cast<const float4*>(fc + oa[1]), *reinterpret_cast<const float4*>(fc + oa[2]),
+               *reinterpret_cast<const float4*>(fc + oa[3]));
+        }
+        const float cntf = (float)max(gh * gw, 1);
+        acc.x /= cntf; acc.y /= cntf; acc.z /= cntf; acc.w /= cntf;
+        *reinterpret_cast<float4*>(a.out + ((long long)roi * a.out_size * a.out_size + bin) * a.c + 4 * ch) = acc;
+      }
+    }
+    return;
+  }
   for (int ph = 0; ph < a.out_size; ++ph) {
   const int bin = ph * a.out_size + pw;
   // one sample = four corner loads; TWO samples (eight independent loads) are requested before either is accumulated -- the sampling
