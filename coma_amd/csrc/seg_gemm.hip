@@ -46,7 +46,9 @@ __device__ float kZerosDev[4] = {0.f, 0.f, 0.f, 0.f};      // what an out-of-ran
                                                        // (GemmArgs::zeros): selecting between a kernel-argument pointer and the symbol itself made every
                                                        // load a flat_load and sent the register sets to scratch
 
-constexpr int kBK = 32, kLd = kBK + 4;      // LDS row stride in floats (144 B: 16-byte aligned, rows spread over the banks)
+constexpr int kBK = 32, kLd = kBK;          // LDS row stride in floats: 128 B, no padding -- the eight 16-byte slots of a row are XOR-swizzled with
+                                            // the row index (slot ^ (row & 7)), which spreads eight consecutive rows over all banks like the 144-byte
+                                            // stride did, and lets the 128 x 64 tile fit three times per CU (3 x 48 KB; 55 KB padded: two)
 
 struct GemmArgs {
   const float* x; const float* w; const float* bias; const float* res; float* out; const int* m_dev;
@@ -58,7 +60,7 @@ struct GemmArgs {
 };
 
 template <int WM, int WN, int TM, int TN, bool UNI, bool PRE>
-__global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, (WM * TM * WN * TN <= 8 ? 3 : 2)) void conv_gemm_f32_kernel(const GemmArgs a) {      // 128 x 64 / 128 x 32 tiles: three per CU
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int NA = BM / 32, NB = BN / 32;
   static_assert(BN % 32 == 0 && BM % 32 == 0, "whole 32-row load steps");       // float4 loads per thread and chunk (A rows / W rows in steps of 32)
@@ -186,11 +188,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
       }
     }
   };
+  const int lk_sw = (((tid & 7) ^ (lr & 7))) * 4;         // swizzled slot of this thread's 16 bytes (stage bases and the 32-row steps are multiples of 8 rows)
   auto lstore = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(As + (buf * BM + lr + 32 * j) * kLd + lk) = ra[j];
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(As + (buf * BM + lr + 32 * j) * kLd + lk_sw) = ra[j];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lr + 32 * j) * kLd + lk) = rb[j];
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lr + 32 * j) * kLd + lk_sw) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -203,8 +206,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_f32_kernel(const GemmArgs a)
 
   const int li = lane & 31, lh = lane >> 5;
   auto mma = [&](int buf, int g) __attribute__((always_inline)) {                       // 8 k values: one ds_read_b128 per operand tile, 4 MFMA steps on each tile pair
-    const float* Ab = As + (buf * BM + wm * TM * 32 + li) * kLd + lh * 4 + g * 8;
-    const float* Bb = Bs + (buf * BN + wn * TN * 32 + li) * kLd + lh * 4 + g * 8;
+    const int sw = ((lh + 2 * g) ^ (li & 7)) * 4;         // slot lh + 2 g of row li, swizzled (every row offset below is a multiple of 8 rows)
+    const float* Ab = As + (buf * BM + wm * TM * 32 + li) * kLd + sw;
+    const float* Bb = Bs + (buf * BN + wn * TN * 32 + li) * kLd + sw;
     float4 fa[TM], fb[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * kLd);
@@ -417,8 +421,8 @@ constexpr int kSlots = 512;               // 256 CUs x 2 resident workgroups
 template <int WM, int WN, int TM, int TN, bool UNI>
 static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_bytes) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t lds = (size_t)2 * (BM + BN) * kLd * sizeof(float);
-  static_assert((size_t)BM * (BN + 8) * sizeof(float) <= lds, "the epilogue staging tile must fit into the operand stages");
+  constexpr size_t lds_ops = (size_t)2 * (BM + BN) * kLd * sizeof(float), lds_epi = (size_t)BM * (BN + 8) * sizeof(float);
+  constexpr size_t lds = lds_ops > lds_epi ? lds_ops : lds_epi;      // the epilogue stages the output tile over the operand stages (128 x 128: 68 KB)
   static coma::LdsOptIn opt;
   static coma::LdsOptIn opt_pre;
   if (lds > 65536) {
@@ -432,23 +436,25 @@ static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_b
   const int nk = a.Kpad / kBK;
   const long long tiles = gx * gy;
   int S = 1;
+  constexpr int slots = 512;
   if (force_split > 0) S = force_split;
-  else if (force_split == 0 && a.ws && tiles < 2 * kSlots && nk >= 8) {
-    // cost model in units of "one chunk with two workgroups per CU" (~3.5 us on a 128 x 128 tile): a launch of W = tiles * S workgroups of
-    // nk / S chunks (+ 3 for prologue and epilogue) runs rounds(W) rounds of 512 workgroups; a last partial round costs 0.6 of a round while
-    // no CU holds two of its workgroups (<= 256) and a whole round beyond that (the CUs with two set the time).  A split launch also pays
-    // the reduce pass: a second launch (~3 us behind the GEMM inside a graph) that reads S slabs at ~4 TB/s.  Measured against forced
-    // factors on the plan's shapes (profiles/r06_notes.md 5): res5.x.conv2 picks 3 (220 us; 2: 315, 4: 250), res4.x.conv2 on 128 x 64 tiles
-    // picks 2 (227 us; unsplit 252), the point head (392 tiles x 11 chunks) stays unsplit (56 us; split in two 78).  Every slice >= 4 chunks.
-    auto rounds = [](double w) {
-      const double full = (double)(long long)(w / kSlots), frac = w / kSlots - full;
-      return full + (frac <= 0.0 ? 0.0 : (frac <= 0.5 ? 0.6 : 1.0));
+  else if (force_split == 0 && a.ws && tiles < 2 * slots && nk >= 8) {
+    // per-CU cost model, unit = one K chunk of a workgroup that shares its CU's matrix pipe with another one (~3.5 us on a 128 x 128 tile):
+    // a launch of W = tiles * S workgroups of nk / S chunks (+ 3 for prologue and epilogue) gives every CU n = ceil(W / 256) of them, and from two
+    // workgroups on the pipe is the bottleneck -- the CU needs n x (nk / S + 3) / 2 units however many of them are resident at a time; a CU with
+    // ONE workgroup cannot fill the pipe: 0.6 per chunk.  A split launch also pays the reduce pass: a second launch (~3 us behind the GEMM
+    // inside a graph) that reads S slabs at ~4 TB/s.  Measured against forced factors on the plan's shapes (profiles/r06_notes.md 5):
+    // res5.x.conv2 picks 3 (220 us; 2: 315, 4: 250), the M = 20 000 3 x 3 layers on 128 x 64 tiles pick 2 (230 us; unsplit 244-252), the point
+    // head (392 tiles x 11 chunks) stays unsplit (56 us; split in two 78).  Every slice >= 4 chunks.
+    auto cu_cost = [](double w, double chunks) {
+      const double n = (double)(long long)((w + 255.0) / 256.0);
+      return n * (chunks + 3.0) * (n <= 1.0 ? 0.6 : 0.5);
     };
-    double best = (nk + 3.0) * rounds((double)tiles);
+    double best = cu_cost((double)tiles, (double)nk);
     const double unit_us = 3.5 * ((double)BM * BN / (128.0 * 128.0));
     const double slab_units = 4.0 * (double)a.M * a.N / 4.0e6 / unit_us;      // one slab read back (the GEMM's slab writes overlap with its own work)
     for (int c = 2; c <= 16 && nk / c >= 4; ++c) {
-      const double cost = ((double)nk / c + 3.0) * rounds((double)tiles * c) + 3.0 / unit_us + c * slab_units;
+      const double cost = cu_cost((double)tiles * c, (double)nk / c) + 3.0 / unit_us + c * slab_units;
       if (cost < best * 0.95) { best = cost; S = c; }
     }
   }
