@@ -13,8 +13,9 @@
 // * rows can be limited by counts that live on the device: the M rows form units of `unit_rows` rows (one per image), and of unit u only
 //   the first m_dev[u] * rows_per_item rows are computed -- the mask heads run on however many detections each image produced without the
 //   host ever learning the number; workgroups with no valid row exit, invalid rows are neither gathered nor stored.
-// Workgroup = 4 waves, tile 128 x 128 (2 x 2 waves, 2 x 2 MFMA tiles each), 128 x 64 or 128 x 32 (4 x 1 waves); K in chunks of 32 through
-// two LDS stages (one barrier per chunk) and two register sets: a chunk's global loads are issued two chunks ahead and stored to LDS in the
+// Workgroup = 4 waves, tile 128 x 128 (2 x 2 waves, 2 x 2 MFMA tiles each; two workgroups per CU), 128 x 64 or 128 x 32 (4 x 1 waves; three per
+// CU); the grid is 1-D in an XCD-banded tile order; K in chunks of 32 through two LDS stages (unpadded rows, XOR-swizzled 16-byte slots, one
+// barrier per chunk) and two register sets: a chunk's global loads are issued two chunks ahead and stored to LDS in the
 // middle of the chunk before it is used; operand addresses of the 1 x 1 / 3 x 3 layers advance incrementally on the scalar unit (a VALU
 // instruction does not overlap with the issuing wave's own MFMAs, so address arithmetic is paid in matrix-pipe time).  Per 8 k values a wave reads
 // ONE ds_read_b128 per operand tile: lanes 0-31 take k = 8g .. 8g+3, lanes 32-63 take k = 8g+4 .. 8g+7, and MFMA step e consumes element e
@@ -22,8 +23,8 @@
 // Epilogue: the accumulators go through LDS (the two operand stages are free by then) and leave as whole rows -- float4 stores of 128 / 64 / 32
 // consecutive columns, the residual and the bias read the same way.  (Storing straight from the MFMA layout is one 4-byte column per lane,
 // two 128-byte row pieces per instruction: the layers with K <= 128 were 4 x off the HBM floor that way, profiles/r06_notes.md 3.)
-// Split-K (deterministic): launches whose tiles fill less than half the chip's 512 workgroup slots and whose K is long cut K into S slices
-// (blockIdx.z); every slice stores its raw partial tile into a slab of the caller's workspace and seg_splitk_reduce_kernel sums the slabs
+// Split-K (deterministic): launches of fewer than 1024 tiles with a long K cut K into S slices (blockIdx.z) when the per-CU cost model in
+// launch_gemm says so; every slice stores its raw partial tile into a slab of the caller's workspace and seg_splitk_reduce_kernel sums the slabs
 // in slice order and applies bias / residual / ReLU -- the same result on every run (no atomics).
 // Algorithmic bytes per launch: A read once (x taps when the window overlaps is NOT counted: the re-reads hit L2), W once, out once.
 #include <hip/hip_runtime.h>
@@ -416,7 +417,6 @@ __global__ __launch_bounds__(256) void seg_splitk_reduce_kernel(const GemmArgs a
   }
 }
 
-constexpr int kSlots = 512;               // 256 CUs x 2 resident workgroups
 
 template <int WM, int WN, int TM, int TN, bool UNI>
 static int launch_gemm(GemmArgs& a, hipStream_t st, int force_split, size_t ws_bytes) {
