@@ -540,13 +540,14 @@ extern "C" int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream) {
     tile = d->n <= 32 ? 3 : (d->n <= 64 ? 2 : 1);
     if (tile == 1) {
       // mid-size launches: 128 x 64 tiles when the 128 x 128 grid leaves the last CU round mostly empty.  Per-CU model: a CU works through
-      // ceil(tiles / 256) tiles; a 128 x 64 tile costs 0.5 (short K: prologue / epilogue bound) ... 0.6 (K >= 2048: it re-reads its A rows
-      // from LDS for half the columns) of a 128 x 128 one.  Measured on the plan's shapes (profiles/r06_notes.md 5): res3.x.conv2 241 -> 212 us,
-      // res3.x.conv1 116 -> 103, res4.x.conv1 141 -> 119, res5.x.conv3 147 -> 123; the large layers (fpn_output2 / 3, box_fc1, res2) stay.
+      // ceil(tiles / 256) tiles; a 128 x 64 tile costs 0.45 (short K: prologue / epilogue bound, three of them per CU) ... 0.58 (K >= 2048: it
+      // re-reads its A rows from LDS for half the columns) of a 128 x 128 one.  Measured on the plan's shapes (profiles/r06_notes.md 5):
+      // res3.x.conv2 241 -> 204 us, res3.x.conv1 116 -> 97, res4.x.conv1 141 -> 111, res5.x.conv3 124 -> 102, res2.x.conv3 201 -> 188,
+      // res4.x.conv3 119 -> 109; the long-K large layers (fpn_output2 / 3, rpn_conv, box_fc1) stay on 128 x 128.
       const long long t1 = ((a.M + 127) / 128) * ((d->n + 127) / 128), t2 = ((a.M + 127) / 128) * ((d->n + 63) / 64);
       const double nk = d->kpad / 32.0;
-      const double r = 0.5 + 0.1 * (nk < 64.0 ? nk / 64.0 : 1.0);
-      if ((double)((t2 + 255) / 256) * r < (double)((t1 + 255) / 256)) tile = 2;
+      const double r = 0.45 + 0.13 * (nk < 64.0 ? nk / 64.0 : 1.0);      // (three narrow-tile workgroups per CU since the unpadded LDS rows)
+      if ((double)((t2 + 255) / 256) * r < 0.95 * (double)((t1 + 255) / 256)) tile = 2;
     }
   }
   // uniform-tap addressing wherever a 32-wide K chunk lies inside one tap (every layer but the stem, C = 4, and the point head, C = 336)
