@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two CHECKOUTS of this repo on ONE box (python + library of each tree; used when the ABI differs between the two, so that
-# COMA_HIP_LIB cannot swap the library alone):   scripts/ab_trees.sh <other-tree> [rounds] [unet|bench|both]
+# COMA_HIP_LIB cannot swap the library alone):   scripts/two_trees.sh <other-tree> [rounds] [unet|bench|both]
 # per round: the captured UNet forwards (scripts/time_unet.py, batch 16 and 2) and / or bench.py --steps 5 --no-secondary for both trees;
 # the order of the two trees flips every round (A B, B A, ...) so that "first after idle" and thermal state do not favour one.
 OTHER=$1; ROUNDS=${2:-2}; WHAT=${3:-both}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The UNet at the reference's own call shape (one image per call = UNet batch 2): where the 7 ms go and what each existing switch is worth.
-#   gpurun -- 'bash scripts/ab_batch2.sh > gpurun_out/ab_batch2.log 2>&1'
+#   gpurun -- 'bash scripts/unet_batch2_switches.sh > gpurun_out/ab_batch2.log 2>&1'
 cd ${GRAFT_REPO_ROOT:-.}
 T="python scripts/time_unet.py 2 50"
 for rep in 1 2; do
