@@ -27,6 +27,7 @@ SHAPES = [
     ("res5.conv2", 8, 25, 25, 512, 512, 3, 1, False),
     ("fpn_lat2", 8, 200, 200, 256, 256, 1, 1, False),
     ("fpn_out3", 8, 100, 100, 256, 256, 3, 1, False),
+    ("fpn_out2", 8, 200, 200, 256, 256, 3, 1, False),
     ("box_fc1", 8000, 1, 1, 12544, 1024, 1, 1, False),
     ("point_fc", 25088, 1, 1, 352, 256, 1, 1, False),
 ]
