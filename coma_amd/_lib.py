@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # COMA_HIP_LIB=<path>: tuning aid -- load another BUILD of the library (A/B of two builds inside one GPU call: box-to-box spread is larger
 # than most of the effects being measured); the product and the tests use the in-tree library
 LIB_PATH = os.environ.get("COMA_HIP_LIB") or os.path.join(_HERE, "libcoma_hip.so")
-ABI_VERSION = 7                  # = COMA_ABI_VERSION of include/coma_hip.h: bumped with every change of the SIGNATURES table below
+ABI_VERSION = 8                  # = COMA_ABI_VERSION of include/coma_hip.h: bumped with every change of the SIGNATURES table below
 
 _lib = None
 
@@ -100,7 +100,7 @@ SIGNATURES = {
     "seg_subsample2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "seg_memset": (_i, [_vp, _i, C.c_size_t, _vp]),
     "seg_rpn_select": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp]),
-    "seg_rpn_select_levels": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "seg_rpn_select_levels": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "seg_sort_candidates": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "seg_nms": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "seg_roi_align_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -70,16 +70,17 @@ __device__ void radix_select_desc(KeyFn key, int n, int k, u32* hist /* LDS [256
     const int shift = 24 - 8 * pass;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    // four keys per thread in flight: with one load per iteration a 120 000-key pass was 118 dependent memory latencies long
-    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
-      u32 u[4];
+    // eight keys per thread in flight: with one load per iteration a 120 000-key pass was 118 dependent memory latencies long
+    constexpr int KQ = 8;
+    for (int i0 = threadIdx.x; i0 < n; i0 += KQ * blockDim.x) {
+      u32 u[KQ];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < KQ; ++q) {
         const int i = i0 + q * (int)blockDim.x;
         u[q] = i < n ? key(i) : 0u;
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < KQ; ++q) {
         const int i = i0 + q * (int)blockDim.x;
         const u32 bin = (u[q] >> shift) & 255;
         if (pass == 0) {
@@ -234,23 +235,25 @@ __device__ __forceinline__ float clampf(float x, float hi) { return x != x ? x :
 
 __device__ __forceinline__ void rpn_select_body(const float* pred, int ld, int fh, int fw, int stride, const float* cell, int level,
                                                 int anchor_base, int pre_topk, float img_h, float img_w, int cand_offset, int cap,
-                                                u64* keys, float* boxes, int* group) {
+                                                u64* keys, float* boxes, int* group, const u32* ckeys = nullptr) {
   __shared__ u32 hist[256];
   __shared__ u32 sh[2];
   const int b = blockIdx.x;
   const int n = fh * fw * 3;
   const int k = n < pre_topk ? n : pre_topk;
   const float* p = pred + (long long)b * fh * fw * ld;
-  auto key = [&](int i) { return asc_bits(p[(long long)(i / 3) * ld + (i % 3)]); };
+  // ckeys: this (image, level)'s keys as a dense u32 array (rpn_keys_kernel) -- the five passes over the keys then read 16 keys per 64-byte line
+  // instead of 3 (the logits are 3 of the 16 floats of a prediction row)
+  auto key = [&](int i) { return ckeys ? ckeys[i] : asc_bits(p[(long long)(i / 3) * ld + (i % 3)]); };
   u32 T = 0;
   int r = 0;
   if (k < n) radix_select_desc(key, n, k, hist, sh, T, r);
   int base_gt = 0, base_eq = 0;
   // how many are strictly greater: k - r
   const int n_gt = k < n ? k - r : 0;
-  // slots in index order (ties at the threshold go to the lowest indices): FOUR strips of blockDim.x consecutive anchors per round -- four
+  // slots in index order (ties at the threshold go to the lowest indices): EIGHT strips of blockDim.x consecutive anchors per round -- eight
   // loads in flight per thread and one pair of barriers per round for both counts (one strip per round was 118 rounds x 4 barriers at p2)
-  constexpr int Q = 4;
+  constexpr int Q = 8;
   __shared__ int wcnt[2][Q][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int i0 = 0; i0 < n; i0 += Q * blockDim.x) {
@@ -324,10 +327,21 @@ struct RpnLevels {
   int fh[6], fw[6], stride[6], anchor_base[6], cand_offset[6];
 };
 __global__ __launch_bounds__(1024) void rpn_select_levels_kernel(const RpnLevels L, int ld, int pre_topk, float img_h, float img_w, int cap, u64* keys,
-                                                                 float* boxes, int* group) {
+                                                                 float* boxes, int* group, const u32* ckeys, int n_total) {
   const int l = blockIdx.y;
   rpn_select_body(L.pred[l], ld, L.fh[l], L.fw[l], L.stride[l], L.cell[l], l, L.anchor_base[l], pre_topk, img_h, img_w, L.cand_offset[l], cap, keys,
-                  boxes, group);
+                  boxes, group, ckeys ? ckeys + (long long)blockIdx.x * n_total + L.anchor_base[l] : nullptr);
+}
+
+// the objectness keys of every anchor of every level, dense: ckeys[b][anchor_base(level) + anchor] (one thread per anchor, the whole chip)
+__global__ __launch_bounds__(256) void rpn_keys_kernel(const RpnLevels L, int n_levels, int ld, int batch, int n_total, u32* ckeys) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)batch * n_total) return;
+  const int b = (int)(t / n_total), g = (int)(t - (long long)b * n_total);
+  int l = 0;
+  while (l + 1 < n_levels && g >= L.anchor_base[l + 1]) ++l;
+  const int i = g - L.anchor_base[l];
+  ckeys[t] = asc_bits(L.pred[l][((long long)b * L.fh[l] * L.fw[l] + i / 3) * ld + (i % 3)]);
 }
 
 // ------------------------------------------------------------------ candidate sort (bitonic, one workgroup per image)
@@ -984,11 +998,11 @@ extern "C" int seg_rpn_select(const void* pred, int ld, int batch, int fh, int f
 
 extern "C" int seg_rpn_select_levels(const void* const* preds, const void* const* cell_anchors, const int* fh, const int* fw, int n_levels, int first_stride,
                                      int ld, int batch, int pre_topk, float img_h, float img_w, int cap, void* cand_keys, void* cand_boxes,
-                                     void* cand_group, void* stream) {
+                                     void* cand_group, void* key_scratch, void* stream) {
   if (!preds || !cell_anchors || !fh || !fw || n_levels <= 0 || n_levels > 6) return fail(COMA_E_INVALID, "seg_rpn_select_levels: 1 .. 6 levels, got %d", n_levels);
   SEG_REC_BEGIN(SEG_OP_RPN_SELECT_LEVELS)
     for (int l = 0; l < n_levels; ++l) { r.p[l] = (void*)preds[l]; r.p[6 + l] = (void*)cell_anchors[l]; r.i[8 + l] = fh[l]; r.i[14 + l] = fw[l]; }
-    r.p[12] = cand_keys; r.p[13] = cand_boxes; r.p[14] = cand_group;
+    r.p[12] = cand_keys; r.p[13] = cand_boxes; r.p[14] = cand_group; r.p[15] = key_scratch;
     r.i[1] = n_levels; r.i[2] = first_stride; r.i[3] = ld; r.i[4] = batch; r.i[5] = pre_topk; r.i[6] = cap; r.f[0] = img_h; r.f[1] = img_w;
   SEG_REC_END
   if (!cand_keys || !cand_boxes || !cand_group) return fail(COMA_E_INVALID, "seg_rpn_select_levels: null pointer");
@@ -1004,8 +1018,13 @@ extern "C" int seg_rpn_select_levels(const void* const* preds, const void* const
     off += n < pre_topk ? n : pre_topk;
   }
   if (off > cap) return fail(COMA_E_INVALID, "seg_rpn_select_levels: %d candidates exceed the list capacity %d", off, cap);
+  if (key_scratch) {
+    const long long nt = (long long)batch * abase;
+    hipLaunchKernelGGL(rpn_keys_kernel, dim3(blocks_for(nt, 256)), dim3(256), 0, (hipStream_t)stream, L, n_levels, ld, batch, abase, (u32*)key_scratch);
+    if (int rc = check_launch("seg::rpn_keys_kernel")) return rc;
+  }
   hipLaunchKernelGGL(rpn_select_levels_kernel, dim3(batch, n_levels), dim3(1024), 0, (hipStream_t)stream, L, ld, pre_topk, img_h, img_w, cap, (u64*)cand_keys,
-                     (float*)cand_boxes, (int*)cand_group);
+                     (float*)cand_boxes, (int*)cand_group, (const u32*)key_scratch, abase);
   return check_launch("seg::rpn_select_levels_kernel");
 }
 
@@ -1190,7 +1209,7 @@ int seg_replay(const PlanRec& r, void* st) {
       const void* preds[6]; const void* cells[6]; int fh[6], fw[6];
       for (int l = 0; l < (int)i[1]; ++l) { preds[l] = p[l]; cells[l] = p[6 + l]; fh[l] = (int)i[8 + l]; fw[l] = (int)i[14 + l]; }
       return seg_rpn_select_levels(preds, cells, fh, fw, (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], (float)f[0], (float)f[1], (int)i[6], p[12], p[13],
-                                   p[14], st);
+                                   p[14], p[15], st);
     }
     case SEG_OP_SORT: return seg_sort_candidates(p[0], p[1], p[2], (int)i[1], (int)i[2], p[3], p[4], p[5], p[6], p[7], st);
     case SEG_OP_NMS:

@@ -188,8 +188,9 @@ class HipPointRend:
             dims.append((fh, fw))
             off += min(fh * fw * 3, PRE_TOPK)
         # one launch for the five levels (a level is one workgroup per image: side by side they take as long as p2 alone)
+        kbuf = g.buf(B, sum(fh * fw * 3 for fh, fw in dims), dtype=I32)          # the objectness keys, dense (the selection's five passes read them coalesced)
         g.add(lambda: ops.rpn_select_levels(preds, cells, ck, cb, cg, ld=16, batch=B, dims=dims, first_stride=4, pre_topk=PRE_TOPK, img_h=nh, img_w=nw,
-                                            cap=CAP), tag="seg rpn select p2..p6")
+                                            cap=CAP, key_scratch=kbuf), tag="seg rpn select p2..p6")
         self.n_rpn_cand = off
         sb, ss, sg, ssrc, nv = g.buf(B, CAP, 4, dtype=F32), g.buf(B, CAP, dtype=F32), g.buf(B, CAP, dtype=I32), g.buf(B, CAP, dtype=I32), g.buf(B, dtype=I32)
         mask_ws = g.buf(B, CAP, CAP // 64, dtype=I64)

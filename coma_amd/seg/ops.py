@@ -67,7 +67,7 @@ def rpn_select(pred, cell, keys, boxes, group, *, ld, batch, fh, fw, stride, lev
     _lib.check(rc, "seg_rpn_select")
 
 
-def rpn_select_levels(preds, cells, keys, boxes, group, *, ld, batch, dims, first_stride, pre_topk, img_h, img_w, cap):
+def rpn_select_levels(preds, cells, keys, boxes, group, *, ld, batch, dims, first_stride, pre_topk, img_h, img_w, cap, key_scratch=None):
     """seg_rpn_select for consecutive FPN levels in one launch; dims: [(fh, fw), ...] per level."""
     n = len(preds)
     pa = (C.c_void_p * n)(*[_p(t, "pred", F32) for t in preds])
@@ -75,7 +75,7 @@ def rpn_select_levels(preds, cells, keys, boxes, group, *, ld, batch, dims, firs
     fh = (C.c_int * n)(*[d[0] for d in dims])
     fw = (C.c_int * n)(*[d[1] for d in dims])
     rc = _lib.lib().seg_rpn_select_levels(pa, ca, fh, fw, n, first_stride, ld, batch, pre_topk, float(img_h), float(img_w), cap, _p(keys, "keys", I64),
-                                          _p(boxes, "boxes", F32), _p(group, "group", I32), _stream(preds[0]))
+                                          _p(boxes, "boxes", F32), _p(group, "group", I32), _p(key_scratch, "key_scratch", I32), _stream(preds[0]))
     _lib.check(rc, "seg_rpn_select_levels")
 
 

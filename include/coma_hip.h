@@ -28,7 +28,7 @@ extern "C" {
 
 /* bumped whenever ANY exported signature of coma_hip.h / sd_hip.h / seg_hip.h changes; coma_amd/_lib.py refuses a library that
  * reports another value (a stale build loaded through COMA_HIP_LIB would otherwise be called with mismatched argument lists) */
-#define COMA_ABI_VERSION 7
+#define COMA_ABI_VERSION 8
 
 #define COMA_OK 0
 #define COMA_E_INVALID (-1) /* bad argument (null pointer, non-positive size, unsupported shape) */

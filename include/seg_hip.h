@@ -84,7 +84,8 @@ int seg_rpn_select(const void* pred, int ld, int batch, int fh, int fw, int stri
  * produces (utils/adaptive_mask_inpainting.py:1225-1236 -> detectron2 find_top_rpn_proposals).  preds / cell_anchors / fh / fw: HOST arrays. */
 int seg_rpn_select_levels(const void* const* preds, const void* const* cell_anchors, const int* fh, const int* fw, int n_levels, int first_stride,
                           int ld, int batch, int pre_topk, float img_h, float img_w, int cap, void* cand_keys, void* cand_boxes, void* cand_group,
-                          void* stream);
+                          void* key_scratch /* optional u32 [batch][anchors of all levels]: the objectness keys are first written densely (one more
+                          launch over the whole chip) and the selection's five passes read them coalesced; NULL: read in place */, void* stream);
 
 /* Sort the cap (a power of two <= 8192) candidate slots of each image by key, ascending (= score descending, ties ascending index).
  * -> sorted boxes / scores / group / source (low 32 bits of the key), n_valid i32 [batch] = slots with key != ~0. */

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound(hip_lib):
 
 
 def test_abi_version_and_error_text(hip_lib):
-    assert hip_lib.coma_abi_version() == 7
+    assert hip_lib.coma_abi_version() == 8
     rc = hip_lib.coma_nearest_vertex_i64(None, None, 1, 1, None, None)
     assert rc == -1 and b"null pointer" in hip_lib.coma_last_error()
     one = C.c_void_p(8)   # never dereferenced: size validation fails first

@@ -293,6 +293,14 @@ def test_rpn_select_takes_the_oracles_candidates(hip_lib):
                           pre_topk=1000, img_h=nh, img_w=nw, cap=cap)
     live = (ck[0, :off] != -1).cpu()
     assert torch.equal(ck2, ck) and torch.equal(cg2[0, :off], cg[0, :off])
+    # ... and with the keys compacted first (the plan's form): the same list again
+    ck3 = torch.full((1, cap), -1, dtype=I64, device=DEV)
+    cb3, cg3 = torch.zeros(1, cap, 4, device=DEV), torch.zeros(1, cap, dtype=I32, device=DEV)
+    kbuf = torch.zeros(1, sum(fh * fw * 3 for fh, fw in dims), dtype=I32, device=DEV)
+    ops.rpn_select_levels(dev_preds, [d(M.cell_anchors(M.ANCHOR_SIZES[li])) for li in range(5)], ck3, cb3, cg3, ld=16, batch=1, dims=dims, first_stride=4,
+                          pre_topk=1000, img_h=nh, img_w=nw, cap=cap, key_scratch=kbuf)
+    assert torch.equal(ck3, ck) and torch.equal(cg3[0, :off], cg[0, :off])
+    assert torch.equal(cb3[0, :off].cpu()[live].view(torch.int32), cb[0, :off].cpu()[live].view(torch.int32))
     assert torch.equal(cb2[0, :off].cpu()[live].view(torch.int32), cb[0, :off].cpu()[live].view(torch.int32))
     ref = so.rpn_proposals(logits, deltas, (nh, nw))
     keys = ck[0].cpu().numpy().view(np.uint64)
