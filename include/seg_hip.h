@@ -48,11 +48,13 @@ typedef struct seg_conv_desc {
   const void* m_dev;    /* i32 [M / unit_rows] on the device or NULL: of every unit of unit_rows consecutive rows (one image's ROIs) only the
                            first m_dev[u] * rows_per_item rows are computed */
   int rows_per_item, unit_rows;
-  int tile;             /* 0 = by width; 1 / 2 / 3 = 128x128 / 128x64 / 128x32 (tests) */
+  int tile;             /* 0 = by rule (n <= 32: 128x32, n <= 64: 128x64, else 128x128 -- or 128x64 where the 128x128 grid leaves the last
+                           round of the CUs mostly empty); 1 / 2 / 3 = 128x128 / 128x64 / 128x32 (tests, tuning) */
   void* workspace;      /* f32 scratch for split-K partial tiles or NULL (then K is never split) */
   size_t workspace_bytes;
-  int split_k;          /* 0 = by rule (tiles fill < half the chip and K >= 256: up to 512 / tiles slices of >= 128 k values, as many as the
-                           workspace holds), -1 = never, S > 1 = exactly S slices (tests); the slices are summed in order: deterministic */
+  int split_k;          /* 0 = by rule (fewer than 1024 tiles and K >= 256: the slice count a per-CU cost model picks, slices of >= 128 k values,
+                           as many as the workspace holds), -1 = never, S > 1 = exactly S slices (tests); the slices are summed in order:
+                           deterministic */
 } seg_conv_desc;
 int seg_conv_gemm_f32(const seg_conv_desc* d, void* stream);
 
