@@ -353,6 +353,28 @@ def test_roi_align_and_level_assignment(hip_lib):
     assert int(l[0, 0]) == 1 and float(o[0, 2].abs().max()) == 0.0
 
 
+def test_roi_align_beyond_the_sample_tables(hip_lib):
+    """A ROI whose bins span more than 64 pixels of its level (a panorama-wide box: 65 samples per bin on the x axis) takes the kernel's
+    general path -- the sample geometry recomputed per lane instead of read from the 64-entry LDS tables -- and a tall one the same on y;
+    both against the oracle, next to an ordinary ROI that uses the tables."""
+    from coma_amd.seg import ops
+    g = torch.Generator().manual_seed(13)
+    B, R, C, h2, w2 = 1, 4, 8, 64, 3712                      # p5 is 8 x 464: a 14 400-pixel-wide box is 450 p5 pixels = 64.3 per bin
+    feats = [torch.randn(B, C, h2 >> l, w2 >> l, generator=g) for l in range(4)]
+    boxes = np.zeros((B, R, 4), np.float32)
+    boxes[0, 0] = [100, 20, 14500, 84]                       # wide: gw = 65, level p5
+    boxes[0, 1] = [300, 40, 420, 150]                        # ordinary
+    boxes[0, 2] = [10, 0, 14848, 256]                        # the whole map: gw = 67
+    boxes[0, 3] = [2000, 100, 2300, 180]
+    out = torch.full((B * R, 49 * C), 9.0, device=DEV)
+    lv = torch.full((B * R,), -3, dtype=I32, device=DEV)
+    ops.roi_align([d(f.permute(0, 2, 3, 1)) for f in feats], d(boxes, F32), d(np.asarray([R]), I32), out, lv, h2=h2, w2=w2, c=C, batch=B, R=R, out_size=7)
+    ref, rl = so.box_pooler([f[0] for f in feats], torch.from_numpy(boxes[0]))
+    o = out.cpu().view(R, 7, 7, C).permute(0, 3, 1, 2)
+    assert torch.equal(lv.cpu().long(), rl) and int(rl[0]) == 3 and int(rl[2]) == 3
+    assert _rel(o, ref) <= 1e-5
+
+
 def test_box_predictor_candidates(hip_lib):
     from coma_amd.seg import ops
     g = torch.Generator().manual_seed(5)
